@@ -1,0 +1,170 @@
+// Short-Weierstrass point arithmetic (a = 0 curves) on the device.
+//
+// Replaces the reference's bucket / projective formulas on the MSM hot path:
+//   ec/src/models/short_weierstrass/bucket.rs:21-30 (Bucket = extended Jacobian X,Y,ZZ,ZZZ),
+//   :78-83 (ZERO = (1,1,0,0)), :112-146 (double_in_place), :168-244 (+= / -= Affine, madd-2008-s),
+//   :256-343 (+= / -= Bucket, add-2008-s), :389-397 (Bucket -> Projective: (X*ZZ, Y*ZZZ, ZZ)),
+//   ec/src/models/short_weierstrass/affine.rs:91-104 (identity = (0,0) when ZeroFlag = ()),
+//   :169-201 (double_to_bucket, mdbl-2008-s-1),
+//   ec/src/models/short_weierstrass/group.rs:171-221 (Jacobian doubling, a = 0), :450-538 (Jacobian add).
+// All five curves served here have COEFF_A = 0 (bn254 g1.rs:21, bls12_381 g1.rs:43, g2.rs:58,
+// bls12_377 g1.rs:42, g2.rs:47), so the a*ZZ^2 term of the doubling formulas is dropped.
+// Only the group element matters for parity (the reference compares after into_affine()), so
+// the formulas need to be correct, not operation-for-operation identical.
+#pragma once
+#include "fp.cuh"
+
+namespace arkhip {
+
+template <class F>
+struct Affine {
+  F x, y;
+  static constexpr int BYTES = 2 * F::BYTES;
+  ARK_HD bool is_zero() const { return x.is_zero() && y.is_zero(); }  // affine.rs:91-104
+  ARK_HD static Affine load(const void* p) {
+    Affine a;
+    a.x = F::load(p);
+    a.y = F::load((const char*)p + F::BYTES);
+    return a;
+  }
+};
+
+template <class F>
+struct XYZZ {
+  F x, y, zz, zzz;
+  static constexpr int BYTES = 4 * F::BYTES;
+  ARK_HD static XYZZ zero() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }  // bucket.rs:78-83
+  ARK_HD bool is_zero() const { return zz.is_zero(); }
+  ARK_HD static XYZZ load(const void* p) {
+    XYZZ r;
+    const char* q = (const char*)p;
+    r.x = F::load(q);
+    r.y = F::load(q + F::BYTES);
+    r.zz = F::load(q + 2 * F::BYTES);
+    r.zzz = F::load(q + 3 * F::BYTES);
+    return r;
+  }
+  ARK_HD void store(void* p) const {
+    char* q = (char*)p;
+    x.store(q);
+    y.store(q + F::BYTES);
+    zz.store(q + 2 * F::BYTES);
+    zzz.store(q + 3 * F::BYTES);
+  }
+  ARK_HD static XYZZ from_affine(const Affine<F>& a) {
+    if (a.is_zero()) return zero();
+    return XYZZ{a.x, a.y, F::one(), F::one()};
+  }
+  ARK_HD static XYZZ neg(const XYZZ& a) { return XYZZ{a.x, F::neg(a.y), a.zz, a.zzz}; }  // bucket.rs:158-166
+};
+
+template <class F>
+struct Jac {
+  F x, y, z;
+  static constexpr int BYTES = 3 * F::BYTES;
+  ARK_HD static Jac zero() { return Jac{F::one(), F::one(), F::zero()}; }  // group.rs:145-151
+  ARK_HD bool is_zero() const { return z.is_zero(); }
+  ARK_HD void store(void* p) const {
+    char* q = (char*)p;
+    x.store(q);
+    y.store(q + F::BYTES);
+    z.store(q + 2 * F::BYTES);
+  }
+};
+
+// affine doubling into XYZZ (mdbl-2008-s-1, a = 0)            affine.rs:169-201
+template <class F>
+ARK_HD XYZZ<F> xyzz_mdbl(const F& x1, const F& y1) {
+  F u = F::dbl(y1);
+  F v = F::sqr(u);
+  F w = F::mul(u, v);
+  F s = F::mul(x1, v);
+  F xx = F::sqr(x1);
+  F m = F::add(F::dbl(xx), xx);
+  XYZZ<F> r;
+  r.x = F::sub(F::sqr(m), F::dbl(s));
+  r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, y1));
+  r.zz = v;
+  r.zzz = w;
+  return r;
+}
+
+// XYZZ doubling (dbl-2008-s-1, a = 0)                         bucket.rs:112-146
+template <class F>
+ARK_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+  if (p.is_zero()) return p;
+  F u = F::dbl(p.y);
+  F v = F::sqr(u);
+  F w = F::mul(u, v);
+  F s = F::mul(p.x, v);
+  F xx = F::sqr(p.x);
+  F m = F::add(F::dbl(xx), xx);
+  XYZZ<F> r;
+  r.x = F::sub(F::sqr(m), F::dbl(s));
+  r.y = F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y));
+  r.zz = F::mul(v, p.zz);
+  r.zzz = F::mul(w, p.zzz);
+  return r;
+}
+
+// acc += (x2, y2)  with (x2,y2) a non-identity affine point   bucket.rs:168-238 (madd-2008-s)
+// Branches: acc = inf -> copy; same x: same y -> mdbl, opposite y -> inf.
+template <class F>
+ARK_HD void xyzz_madd(XYZZ<F>& acc, const F& x2, const F& y2) {
+  if (acc.is_zero()) {
+    acc.x = x2; acc.y = y2; acc.zz = F::one(); acc.zzz = F::one();
+    return;
+  }
+  F p = F::sub(F::mul(x2, acc.zz), acc.x);
+  F r = F::sub(F::mul(y2, acc.zzz), acc.y);
+  if (p.is_zero()) {
+    if (r.is_zero()) acc = xyzz_mdbl<F>(x2, y2);
+    else acc = XYZZ<F>::zero();
+    return;
+  }
+  F pp = F::sqr(p);
+  F ppp = F::mul(p, pp);
+  F q = F::mul(acc.x, pp);
+  F x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(q));
+  F y3 = F::sub(F::mul(r, F::sub(q, x3)), F::mul(acc.y, ppp));
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = F::mul(acc.zz, pp);
+  acc.zzz = F::mul(acc.zzz, ppp);
+}
+
+// acc += b (both XYZZ)                                        bucket.rs:256-337 (add-2008-s)
+template <class F>
+ARK_HD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {
+  if (b.is_zero()) return;
+  if (acc.is_zero()) { acc = b; return; }
+  F u1 = F::mul(acc.x, b.zz);
+  F u2 = F::mul(b.x, acc.zz);
+  F s1 = F::mul(acc.y, b.zzz);
+  F s2 = F::mul(b.y, acc.zzz);
+  F p = F::sub(u2, u1);
+  F r = F::sub(s2, s1);
+  if (p.is_zero()) {
+    if (r.is_zero()) acc = xyzz_dbl<F>(acc);
+    else acc = XYZZ<F>::zero();
+    return;
+  }
+  F pp = F::sqr(p);
+  F ppp = F::mul(p, pp);
+  F q = F::mul(u1, pp);
+  F x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(q));
+  F y3 = F::sub(F::mul(r, F::sub(q, x3)), F::mul(s1, ppp));
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = F::mul(F::mul(acc.zz, b.zz), pp);
+  acc.zzz = F::mul(F::mul(acc.zzz, b.zzz), ppp);
+}
+
+// XYZZ -> Jacobian (X*ZZ, Y*ZZZ, ZZ): valid because ZZ^3 = ZZZ^2   bucket.rs:389-397
+template <class F>
+ARK_HD Jac<F> xyzz_to_jac(const XYZZ<F>& p) {
+  if (p.is_zero()) return Jac<F>::zero();
+  return Jac<F>{F::mul(p.x, p.zz), F::mul(p.y, p.zzz), p.zz};
+}
+
+}  // namespace arkhip

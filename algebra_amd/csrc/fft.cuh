@@ -1,0 +1,371 @@
+// Radix-2 FFT / IFFT over a scalar field on one MI355X, in place, natural order in and out.
+//
+// Replaces the reference's Radix2EvaluationDomain kernels:
+//   poly/src/domain/radix2/mod.rs:140-153 (fft_in_place / ifft_in_place dispatch),
+//   poly/src/domain/radix2/fft.rs:74-119 (in_order_fft/ifft_in_place, coset scaling),
+//   :124-187 (roots_of_unity table), :190-210 (butterflies), :252-349 (io_helper/oi_helper),
+//   :373-380 (derange), poly/src/domain/mod.rs:115-148 (distribute_powers).
+// Contract: forward X[j] = sum_i x[i] (h g^j)^i ; inverse
+// x[i] = n^-1 h^-i sum_j X[j] g^-ij ; all values canonical Montgomery residues, so any correct
+// schedule is bit-identical to the reference.
+//
+// GPU organisation: decimation-in-frequency with the reference's own twiddle convention
+// (stage with half-width `gap` uses roots[j * n/(2 gap)]), executed as P = ceil(k/8) passes over
+// HBM; each pass runs up to 8 consecutive stages on a tile held in LDS.  A tile is
+// 2^kp butterfly rows x 8 adjacent columns (256-byte contiguous segments in HBM), the last pass
+// takes its 8 "columns" from the top index bits so that the bit-reversed write-back -- which
+// replaces the reference's serial derange() -- is also made of 256-byte segments.  Coset
+// pre-scaling (x[i] *= h^i) is fused into the first pass's loads, and the inverse transform's
+// n^-1 h^-i scaling into the last pass's stores (two-level power tables).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <array>
+#include <mutex>
+#include "msm.cuh"  // DevBuf, ARK_HIP_TRY
+
+namespace arkhip {
+
+static constexpr int FFT_LANE_BITS = 3;    // 8 adjacent elements = 256 B segments
+static constexpr int FFT_MAX_KP = 8;       // stages per pass
+static constexpr int FFT_SINGLE_MAX = 10;  // whole transform in one workgroup up to 2^10
+static constexpr int PW_LO_BITS = 10;      // two-level power tables: h^i = hi[i >> 10] * lo[i & 1023]
+
+__device__ __forceinline__ u32 bitrev32(u32 x, int bits) { return bits == 0 ? 0u : (__brev(x) >> (32 - bits)); }
+
+// out[j] = base^(j * stride), j < count   (binary exponentiation; tables are tiny or built once)
+template <class FP>
+__global__ void __launch_bounds__(256) fft_pow_table_kernel(const u32* __restrict__ base, u64 stride, u32 count,
+                                                            const u32* __restrict__ mulby, u32* __restrict__ out) {
+  typedef Fp<FP> F;
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  F b = F::load(base);
+  F r = mulby ? F::load(mulby) : F::one();
+  u64 e = (u64)j * stride;
+  while (e) {
+    if (e & 1) r = F::mul(r, b);
+    b = F::sqr(b);
+    e >>= 1;
+  }
+  r.store(out + (size_t)j * F::N);
+}
+// roots[j] = hi[j >> LO] * lo[j & mask]
+template <class FP>
+__global__ void __launch_bounds__(256) fft_expand_table_kernel(const u32* __restrict__ lo, const u32* __restrict__ hi,
+                                                               int lo_bits, size_t count, u32* __restrict__ out) {
+  typedef Fp<FP> F;
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  F a = F::load(lo + (j & ((1u << lo_bits) - 1)) * F::N);
+  F b = F::load(hi + (j >> lo_bits) * F::N);
+  F::mul(a, b).store(out + j * F::N);
+}
+
+struct FftPassArgs {
+  int k;       // log2 n
+  int s0;      // first global stage of this pass
+  int kp;      // stages in this pass
+  int t;       // log2 lanes
+  int last;    // last pass: lanes = top bits, bit-reversed write-back
+  const u32* roots;    // w^j, j < n/2
+  const u32* pre_lo;   // first pass: x[pos] *= pre_hi[pos >> 10] * pre_lo[pos & 1023]   (nullable)
+  const u32* pre_hi;
+  const u32* post_lo;  // last pass: out[pos] *= post_hi[pos >> 10] * post_lo[pos & 1023]  (nullable)
+  const u32* post_hi;
+  const u32* post_const;  // last pass: out *= const (nullable; used when post tables are absent)
+};
+
+template <class FP>
+__global__ void __launch_bounds__(256) fft_pass_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
+                                                       FftPassArgs a) {
+  typedef Fp<FP> F;
+  extern __shared__ uint4 lds[];
+  const int kp = a.kp, t = a.t, k = a.k;
+  const u32 E = 1u << (kp + t);
+  uint4* pl0 = lds;
+  uint4* pl1 = lds + E;
+  const u32 tile = blockIdx.x;
+  const int lo_shift = k - a.s0 - kp;
+  const u32 T1 = (1u << t) - 1u;
+  const u32 Q1 = (1u << kp) - 1u;
+  u32 mid = 0, hi_bits = 0;
+  if (!a.last) {
+    mid = tile & ((1u << (lo_shift - t)) - 1u);
+    hi_bits = tile >> (lo_shift - t);
+  }
+  // ---- load tile ----
+  for (u32 e = threadIdx.x; e < E; e += blockDim.x) {
+    size_t pos;
+    if (!a.last) {
+      u32 q = e >> t, r = e & T1;
+      pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
+    } else {
+      u32 r = e >> kp, q = e & Q1;
+      pos = ((size_t)r << (k - t)) | ((size_t)tile << kp) | q;
+    }
+    const uint4* g = (const uint4*)(src + pos * F::N);
+    uint4 v0 = g[0], v1 = g[1];
+    if (a.pre_lo) {
+      F x;
+      x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w;
+      x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
+      F pw = F::mul(F::load(a.pre_hi + (pos >> PW_LO_BITS) * F::N), F::load(a.pre_lo + (pos & ((1u << PW_LO_BITS) - 1)) * F::N));
+      x = F::mul(x, pw);
+      v0 = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+      v1 = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    }
+    pl0[e] = v0;
+    pl1[e] = v1;
+  }
+  __syncthreads();
+  // ---- kp butterfly stages in LDS ----
+  for (int ls = 0; ls < kp; ls++) {
+    const u32 lg = 1u << (kp - 1 - ls);
+    const int s = a.s0 + ls;
+    for (u32 b = threadIdx.x; b < E / 2; b += blockDim.x) {
+      u32 i0, i1;
+      size_t tw;
+      if (!a.last) {
+        u32 r = b & T1, qq = b >> t;
+        u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
+        i0 = (q << t) | r;
+        i1 = i0 + (lg << t);
+        tw = ((((size_t)(q & (lg - 1))) << lo_shift) | ((size_t)mid << t) | r) << s;
+      } else {
+        u32 qq = b & ((1u << (kp - 1)) - 1u), r = b >> (kp - 1);
+        u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
+        i0 = (r << kp) | q;
+        i1 = i0 + lg;
+        tw = ((size_t)(q & (lg - 1))) << s;
+      }
+      uint4 a0 = pl0[i0], a1 = pl1[i0], b0 = pl0[i1], b1 = pl1[i1];
+      F lo, hi;
+      lo.l[0] = a0.x; lo.l[1] = a0.y; lo.l[2] = a0.z; lo.l[3] = a0.w;
+      lo.l[4] = a1.x; lo.l[5] = a1.y; lo.l[6] = a1.z; lo.l[7] = a1.w;
+      hi.l[0] = b0.x; hi.l[1] = b0.y; hi.l[2] = b0.z; hi.l[3] = b0.w;
+      hi.l[4] = b1.x; hi.l[5] = b1.y; hi.l[6] = b1.z; hi.l[7] = b1.w;
+      F sum = F::add(lo, hi);          // fft.rs:190-198 butterfly_fn_io
+      F dif = F::sub(lo, hi);
+      if (tw != 0) dif = F::mul(dif, F::load(a.roots + tw * F::N));
+      pl0[i0] = make_uint4(sum.l[0], sum.l[1], sum.l[2], sum.l[3]);
+      pl1[i0] = make_uint4(sum.l[4], sum.l[5], sum.l[6], sum.l[7]);
+      pl0[i1] = make_uint4(dif.l[0], dif.l[1], dif.l[2], dif.l[3]);
+      pl1[i1] = make_uint4(dif.l[4], dif.l[5], dif.l[6], dif.l[7]);
+    }
+    __syncthreads();
+  }
+  // ---- store tile ----
+  if (!a.last) {
+    for (u32 e = threadIdx.x; e < E; e += blockDim.x) {
+      u32 q = e >> t, r = e & T1;
+      size_t pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
+      uint4* g = (uint4*)(dst + pos * F::N);
+      g[0] = pl0[e];
+      g[1] = pl1[e];
+    }
+  } else {
+    // position p = r<<(k-t) | tile<<kp | q holds X[bitrev_k(p)]  (replaces derange(), fft.rs:373-380)
+    const int tb = k - kp - t;
+    const size_t tile_rev = bitrev32(tile, tb);
+    for (u32 e = threadIdx.x; e < E; e += blockDim.x) {
+      u32 r2 = e & T1, q2 = e >> t;  // output-side coordinates
+      size_t opos = ((size_t)q2 << (k - kp)) | (tile_rev << t) | r2;
+      u32 i = (bitrev32(r2, t) << kp) | bitrev32(q2, kp);
+      uint4 v0 = pl0[i], v1 = pl1[i];
+      if (a.post_lo || a.post_const) {
+        F x;
+        x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w;
+        x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
+        F pw;
+        if (a.post_lo)
+          pw = F::mul(F::load(a.post_hi + (opos >> PW_LO_BITS) * F::N),
+                      F::load(a.post_lo + (opos & ((1u << PW_LO_BITS) - 1)) * F::N));
+        else
+          pw = F::load(a.post_const);
+        x = F::mul(x, pw);
+        v0 = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+        v1 = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+      }
+      uint4* g = (uint4*)(dst + opos * F::N);
+      g[0] = v0;
+      g[1] = v1;
+    }
+  }
+}
+
+// ---- host side: cached twiddle tables + pass plan ------------------------------------------------
+struct FftTables {
+  DevBuf roots;   // n/2 entries
+  DevBuf small;   // scratch for the two-level build + generator copy
+};
+struct FftKey {
+  int field, k;
+  std::array<uint64_t, 4> gen;
+  bool operator<(const FftKey& o) const {
+    if (field != o.field) return field < o.field;
+    if (k != o.k) return k < o.k;
+    return gen < o.gen;
+  }
+};
+struct FftWorkspace {
+  std::map<FftKey, FftTables> tables;  // per (field, log n, root)
+  DevBuf tmp;                          // ping buffer for the multi-pass transform
+  DevBuf pw;                           // coset power tables + constants
+  DevBuf stage;                        // host-pointer entry: device copy of the data
+  std::mutex mu;
+  void release() {
+    for (auto& kv : tables) { kv.second.roots.release(); kv.second.small.release(); }
+    tables.clear();
+    tmp.release(); pw.release(); stage.release();
+  }
+};
+struct FftTimings { float total = 0; float pass[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int npass = 0; };
+
+template <class FP>
+int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t stream, const u32** out) {
+  typedef Fp<FP> F;
+  FftKey key{FP::ID, k, {root4[0], root4[1], root4[2], root4[3]}};
+  auto it = ws.tables.find(key);
+  if (it != ws.tables.end()) { *out = (const u32*)it->second.roots.p; return 0; }
+  FftTables& tb = ws.tables[key];
+  size_t half = k >= 1 ? ((size_t)1 << (k - 1)) : 1;
+  if (tb.roots.ensure(half * F::BYTES)) return -3;
+  const int LB = 11;
+  size_t nlo = half < ((size_t)1 << LB) ? half : ((size_t)1 << LB);
+  size_t nhi = half >> LB; if (nhi == 0) nhi = 1;
+  if (tb.small.ensure((1 + nlo + nhi) * F::BYTES)) return -3;
+  u32* d_gen = (u32*)tb.small.p;
+  u32* d_lo = d_gen + F::N;
+  u32* d_hi = d_lo + nlo * F::N;
+  ARK_HIP_TRY(hipMemcpyAsync(d_gen, root4, F::BYTES, hipMemcpyHostToDevice, stream));
+  if (half <= ((size_t)1 << LB)) {
+    hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, d_gen, (u64)1,
+                       (u32)half, (const u32*)nullptr, (u32*)tb.roots.p);
+  } else {
+    hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nlo + 255) / 256)), dim3(256), 0, stream, d_gen, (u64)1,
+                       (u32)nlo, (const u32*)nullptr, d_lo);
+    hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nhi + 255) / 256)), dim3(256), 0, stream, d_gen,
+                       (u64)1 << LB, (u32)nhi, (const u32*)nullptr, d_hi);
+    hipLaunchKernelGGL((fft_expand_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, d_lo, d_hi,
+                       LB, half, (u32*)tb.roots.p);
+  }
+  ARK_HIP_TRY(hipStreamSynchronize(stream));  // root4 is a caller stack pointer
+  *out = (const u32*)tb.roots.p;
+  return 0;
+}
+
+// d_data: device pointer to 2^k elements (Montgomery, reference layout).
+// root4:  group_gen (forward) or group_gen_inv (inverse) of the size-2^k domain, host pointer.
+// pre4:   coset offset h (forward coset FFT) or nullptr.        x[i] *= h^i before the transform
+// post4:  inverse: h^-1 or nullptr;  postc4: constant multiplier of every output (size_inv) or nullptr
+template <class FP>
+int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4,
+                   const uint64_t* post4, const uint64_t* postc4, hipStream_t stream, FftTimings* tm) {
+  typedef Fp<FP> F;
+  std::lock_guard<std::mutex> lock(ws.mu);
+  if (k < 0 || k > 30 || k > FP::TWO_ADICITY) return -2;
+  const size_t n = (size_t)1 << k;
+  const u32* roots = nullptr;
+  if (k >= 1) {
+    int rc = fft_get_roots<FP>(ws, k, root4, stream, &roots);
+    if (rc) return rc;
+  }
+  // power tables for coset scaling: [pre_lo | pre_hi | post_lo | post_hi | consts(h, h^-1, postc)]
+  const size_t nlo = (size_t)1 << PW_LO_BITS;
+  const size_t nhi = k > PW_LO_BITS ? ((size_t)1 << (k - PW_LO_BITS)) : 1;
+  const u32 *pre_lo = nullptr, *pre_hi = nullptr, *post_lo = nullptr, *post_hi = nullptr, *post_const = nullptr;
+  if (pre4 || post4 || postc4) {
+    if (ws.pw.ensure((2 * (nlo + nhi) + 3) * F::BYTES)) return -3;
+    u32* base = (u32*)ws.pw.p;
+    u32* d_c = base + 2 * (nlo + nhi) * F::N;
+    if (pre4) ARK_HIP_TRY(hipMemcpyAsync(d_c, pre4, F::BYTES, hipMemcpyHostToDevice, stream));
+    if (post4) ARK_HIP_TRY(hipMemcpyAsync(d_c + F::N, post4, F::BYTES, hipMemcpyHostToDevice, stream));
+    if (postc4) ARK_HIP_TRY(hipMemcpyAsync(d_c + 2 * F::N, postc4, F::BYTES, hipMemcpyHostToDevice, stream));
+    if (pre4) {
+      u32* lo = base;
+      u32* hi = base + nlo * F::N;
+      hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)(nlo / 256)), dim3(256), 0, stream, d_c, (u64)1, (u32)nlo,
+                         (const u32*)nullptr, lo);
+      hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nhi + 255) / 256)), dim3(256), 0, stream, d_c,
+                         (u64)nlo, (u32)nhi, (const u32*)nullptr, hi);
+      pre_lo = lo;
+      pre_hi = hi;
+    }
+    if (post4) {
+      u32* lo = base + (nlo + nhi) * F::N;
+      u32* hi = lo + nlo * F::N;
+      hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)(nlo / 256)), dim3(256), 0, stream, d_c + F::N, (u64)1,
+                         (u32)nlo, (const u32*)nullptr, lo);
+      hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nhi + 255) / 256)), dim3(256), 0, stream, d_c + F::N,
+                         (u64)nlo, (u32)nhi, postc4 ? (const u32*)(d_c + 2 * F::N) : (const u32*)nullptr, hi);
+      post_lo = lo;
+      post_hi = hi;
+    } else if (postc4) {
+      post_const = d_c + 2 * F::N;
+    }
+    ARK_HIP_TRY(hipStreamSynchronize(stream));  // the constants were copied from caller memory
+  }
+  if (k == 0) {
+    // size-1 domain: X[0] = x[0] (h^0 = 1, n^-1 = 1)
+    return 0;
+  }
+  hipEvent_t ev[10];
+  int nev = 0;
+  if (tm) {
+    for (auto& e : ev) ARK_HIP_TRY(hipEventCreate(&e));
+    ARK_HIP_TRY(hipEventRecord(ev[nev++], stream));
+  }
+  // pass plan
+  int P, kps[8], t;
+  if (k <= FFT_SINGLE_MAX) {
+    P = 1; kps[0] = k; t = 0;
+  } else {
+    int maxkp = FFT_MAX_KP;
+    const char* env = getenv("ARK_HIP_FFT_KP");
+    if (env && atoi(env) >= 5 && atoi(env) <= 8) maxkp = atoi(env);
+    P = (k + maxkp - 1) / maxkp;
+    int base = k / P, rem = k % P;
+    for (int i = 0; i < P; i++) kps[i] = base + (i < rem ? 1 : 0);
+    t = FFT_LANE_BITS;
+  }
+  u32* data = (u32*)d_data;
+  u32* tmp = nullptr;
+  if (P > 1) {
+    if (ws.tmp.ensure(n * F::BYTES)) return -3;
+    tmp = (u32*)ws.tmp.p;
+  }
+  int s0 = 0;
+  for (int i = 0; i < P; i++) {
+    FftPassArgs a;
+    a.k = k; a.s0 = s0; a.kp = kps[i]; a.t = t; a.last = (i == P - 1) ? 1 : 0;
+    a.roots = roots;
+    a.pre_lo = (i == 0) ? pre_lo : nullptr;
+    a.pre_hi = (i == 0) ? pre_hi : nullptr;
+    a.post_lo = a.last ? post_lo : nullptr;
+    a.post_hi = a.last ? post_hi : nullptr;
+    a.post_const = a.last ? post_const : nullptr;
+    const u32* src;
+    u32* dst;
+    if (P == 1) { src = data; dst = data; }
+    else if (i == 0) { src = data; dst = tmp; }
+    else if (i == P - 1) { src = tmp; dst = data; }
+    else { src = tmp; dst = tmp; }
+    u32 tiles = (u32)(n >> (kps[i] + t));
+    size_t lds_bytes = ((size_t)2 << (kps[i] + t)) * sizeof(uint4);
+    hipLaunchKernelGGL((fft_pass_kernel<FP>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, a);
+    if (tm) ARK_HIP_TRY(hipEventRecord(ev[nev++], stream));
+    s0 += kps[i];
+  }
+  ARK_HIP_TRY(hipGetLastError());
+  if (tm) {
+    ARK_HIP_TRY(hipStreamSynchronize(stream));
+    tm->npass = P;
+    for (int i = 0; i < P; i++) (void)hipEventElapsedTime(&tm->pass[i], ev[i], ev[i + 1]);
+    (void)hipEventElapsedTime(&tm->total, ev[0], ev[nev - 1]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  return 0;
+}
+
+}  // namespace arkhip

@@ -1,0 +1,34 @@
+// Internal glue between the per-curve / per-field translation units and the C ABI (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace arkhip {
+struct MsmWorkspace;
+struct MsmTimings;
+struct FftWorkspace;
+struct FftTimings;
+
+// one function per curve / field, defined in msm_<curve>.hip / fft_<field>.hip
+#define ARK_DECL_CURVE(NAME)                                                                                    \
+  int msm_run_##NAME(MsmWorkspace& ws, const void* d_bases, const void* d_scalars, size_t n, int mont,           \
+                     uint64_t* out_xyz, hipStream_t stream, MsmTimings* tm);                                      \
+  int test_basefield_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);    \
+  int test_point_op_##NAME(int kind, const void* d_acc, const void* d_other, void* d_out, size_t n, hipStream_t s);
+ARK_DECL_CURVE(BN254_G1)
+ARK_DECL_CURVE(BLS12_381_G1)
+ARK_DECL_CURVE(BLS12_377_G1)
+ARK_DECL_CURVE(BLS12_377_G2)
+ARK_DECL_CURVE(BLS12_381_G2)
+#undef ARK_DECL_CURVE
+
+#define ARK_DECL_FIELD(NAME)                                                                                    \
+  int fft_run_##NAME(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4,         \
+                     const uint64_t* post4, const uint64_t* postc4, hipStream_t stream, FftTimings* tm);          \
+  int test_field_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);
+ARK_DECL_FIELD(BN254_FR)
+ARK_DECL_FIELD(BLS12_381_FR)
+ARK_DECL_FIELD(BLS12_377_FR)
+#undef ARK_DECL_FIELD
+}  // namespace arkhip

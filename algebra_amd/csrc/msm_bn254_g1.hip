@@ -1,0 +1,17 @@
+// Instantiation of the MSM pipeline and the point-arithmetic test hooks for BN254_G1 (one TU per curve so
+// the five heavy template expansions compile in parallel).
+#include "msm.cuh"
+#include "testops.cuh"
+#include "internal.hpp"
+namespace arkhip {
+int msm_run_BN254_G1(MsmWorkspace& ws, const void* d_bases, const void* d_scalars, size_t n, int mont, uint64_t* out_xyz,
+               hipStream_t stream, MsmTimings* tm) {
+  return msm_run_device<BN254_G1>(ws, d_bases, d_scalars, n, mont, out_xyz, stream, tm);
+}
+int test_basefield_op_BN254_G1(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
+  return test_field_op_launch<BN254_G1::F, false>(op, a, b, r, n, s);
+}
+int test_point_op_BN254_G1(int kind, const void* acc, const void* other, void* out, size_t n, hipStream_t s) {
+  return test_point_op_launch<BN254_G1>(kind, acc, other, out, n, s);
+}
+}  // namespace arkhip

@@ -1,0 +1,83 @@
+// Elementwise test kernels: expose the device field / point arithmetic to tests/ through the C ABI
+// so that every formula the MSM and FFT kernels use is checked against the oracle on its own.
+#pragma once
+#include "curves.cuh"
+
+namespace arkhip {
+
+template <class F, bool IS_PRIME>
+__global__ void __launch_bounds__(256) test_field_op_kernel(int op, const char* __restrict__ a, const char* __restrict__ b,
+                                                            char* __restrict__ r, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F x = F::load(a + i * F::BYTES);
+  F y = b ? F::load(b + i * F::BYTES) : x;
+  F z = x;
+  switch (op) {
+    case 0: z = F::add(x, y); break;
+    case 1: z = F::sub(x, y); break;
+    case 2: z = F::mul(x, y); break;
+    case 3: z = F::sqr(x); break;
+    case 4: z = F::neg(x); break;
+    case 5: z = F::dbl(x); break;
+    default:
+      if constexpr (IS_PRIME) {
+        if (op == 7) z = F::from_mont(x);
+        if (op == 8) z = F::to_mont(x);
+      }
+      break;
+  }
+  z.store(r + i * F::BYTES);
+}
+
+template <class F, bool IS_PRIME>
+int test_field_op_launch(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((test_field_op_kernel<F, IS_PRIME>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op,
+                     (const char*)a, (const char*)b, (char*)r, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// acc: XYZZ (kinds 2..6) or affine (kind 7); other: affine (2,3) or XYZZ (4); out: XYZZ, or Jacobian for kind 6
+template <class C>
+__global__ void __launch_bounds__(128) test_point_op_kernel(int kind, const char* __restrict__ acc_in,
+                                                            const char* __restrict__ other, char* __restrict__ out,
+                                                            size_t n) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (kind == 7) {
+    Affine<F> p = Affine<F>::load(acc_in + i * Affine<F>::BYTES);
+    Pt r = p.is_zero() ? Pt::zero() : xyzz_mdbl<F>(p.x, p.y);
+    r.store(out + i * Pt::BYTES);
+    return;
+  }
+  Pt acc = Pt::load(acc_in + i * Pt::BYTES);
+  if (kind == 2 || kind == 3) {
+    Affine<F> p = Affine<F>::load(other + i * Affine<F>::BYTES);
+    if (!p.is_zero()) {
+      F y = F::cond_neg(p.y, kind == 3);
+      xyzz_madd<F>(acc, p.x, y);
+    }
+    acc.store(out + i * Pt::BYTES);
+  } else if (kind == 4) {
+    Pt o = Pt::load(other + i * Pt::BYTES);
+    xyzz_add<F>(acc, o);
+    acc.store(out + i * Pt::BYTES);
+  } else if (kind == 5) {
+    xyzz_dbl<F>(acc).store(out + i * Pt::BYTES);
+  } else if (kind == 6) {
+    xyzz_to_jac<F>(acc).store(out + i * Jac<F>::BYTES);
+  }
+}
+
+template <class C>
+int test_point_op_launch(int kind, const void* acc, const void* other, void* out, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((test_point_op_kernel<C>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, kind,
+                     (const char*)acc, (const char*)other, (char*)out, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+}  // namespace arkhip

@@ -1,0 +1,120 @@
+/*
+ * ark_hip.h -- C ABI of libark_hip.so: MI355X (gfx950) implementation of the one data-parallel hot
+ * path of arkworks-rs/algebra:
+ *     ark_ec::VariableBaseMSM::msm over short-Weierstrass G1/G2   (Pippenger bucket method)
+ *     ark_poly::Radix2EvaluationDomain::{fft,ifft}_in_place over Fr (Cooley-Tukey radix-2)
+ * Every entry point below is what the reference's Rust side would bind through FFI; the
+ * reference item each one replaces is cited (paths relative to the arkworks-rs/algebra tree).
+ * INTEGRATION.md shows the Rust `extern "C"` block and the trait impls that call them.
+ *
+ * Data layout == the reference's in-memory layout, no conversion on either side:
+ *   Fp           N little-endian u64 limbs, Montgomery form, value < p   (ff/src/biginteger/mod.rs:34,
+ *                                                                          ff/src/fields/models/fp/mod.rs:109-115)
+ *   Fp2          c0 | c1                                                  (quadratic_extension.rs:100-106)
+ *   Affine       x | y, identity = all-zero (ZeroFlag = ())               (short_weierstrass/affine.rs:30-37,91-104)
+ *   Projective   x | y | z Jacobian, identity = (R, R, 0)                 (short_weierstrass/group.rs:34-41,145-151)
+ *   scalar       4 u64 limbs: BigInt<4> canonical, or Fr Montgomery
+ * All functions return 0 on success and a negative code on error; none throws or aborts.
+ * Thread safety: calls are serialised per process on an internal context (one GPU per process,
+ * the torch.distributed / RCCL model).
+ */
+#ifndef ARK_HIP_H
+#define ARK_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* field ids */
+enum { ARK_HIP_BN254_FQ = 0, ARK_HIP_BN254_FR = 1, ARK_HIP_BLS12_381_FQ = 2, ARK_HIP_BLS12_381_FR = 3,
+       ARK_HIP_BLS12_377_FQ = 4, ARK_HIP_BLS12_377_FR = 5 };
+/* curve ids (SWCurveConfig instances) */
+enum { ARK_HIP_BN254_G1 = 0, ARK_HIP_BLS12_381_G1 = 1, ARK_HIP_BLS12_377_G1 = 2, ARK_HIP_BLS12_377_G2 = 3,
+       ARK_HIP_BLS12_381_G2 = 4 };
+/* error codes */
+enum { ARK_HIP_OK = 0, ARK_HIP_ERR_ARG = -1, ARK_HIP_ERR_SIZE = -2, ARK_HIP_ERR_NOMEM = -3,
+       ARK_HIP_ERR_SCALAR_RANGE = -4, ARK_HIP_ERR_NO_DEVICE = -5 /* HIP runtime errors: <= -1000 */ };
+
+/* ---- runtime ---- */
+int ark_hip_device_count(void);
+/* Bind this process to GPU `device` and create the context (streams, workspaces).  Idempotent. */
+int ark_hip_init(int device);
+void ark_hip_shutdown(void);
+int ark_hip_synchronize(void);
+const char* ark_hip_version(void);
+/* u64 words per base-field element (4, 6 or 12), scalar field id, base field id, extension degree */
+int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_field, int* ext_degree);
+
+/* ---- MSM ----
+ * Replaces SWCurveConfig::msm (ec/src/models/short_weierstrass/mod.rs:112-119) -> 
+ * VariableBaseMSM::msm_unchecked / msm_bigint (ec/src/scalar_mul/variable_base/mod.rs:59-85).
+ * bases: n Affine points; scalars: n x 4 limbs; scalars_are_montgomery != 0 for the `msm(&[Fr])`
+ * entry (the into_bigint pass of mod.rs:60-62 then runs on the device), 0 for `msm_bigint`.
+ * The length check (Err(min_len), mod.rs:73-77) stays on the caller's side: one n here.
+ * out_xyz: Projective.  Scalars must be < r (as into_bigint() guarantees), bases in the
+ * prime-order subgroup (as Affine deserialisation guarantees). */
+int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int scalars_are_montgomery,
+                   uint64_t* out_xyz);
+/* Same with bases/scalars already in this GPU's memory (device pointers); out_xyz is a host pointer. */
+int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalars_are_montgomery,
+                          uint64_t* out_xyz);
+/* Per-phase device times of the last ark_hip_msm_sw_device call made with timing enabled (ms):
+ * [digits, scan, scatter, accumulate, reduce, total, window_bits, windows] */
+int ark_hip_msm_set_timing(int enable);
+int ark_hip_msm_last_timing(double out[8]);
+
+/* ---- host-side group helpers (run on the CPU; tiny) ----
+ * Sum of n Projective points: the multi-GPU combine of per-rank partial MSMs (the reference's
+ * chunk sum, ec/src/scalar_mul/variable_base/mod.rs:542-557).  The reduction operator is
+ * elliptic-curve addition, so it cannot be an RCCL sum: ranks all-gather 3 field elements each. */
+int ark_hip_sw_sum(int curve, const uint64_t* jac_points, size_t n, uint64_t* out_xyz);
+/* From<Projective> for Affine (ec/src/models/short_weierstrass/affine.rs:374-396): the unique
+ * representative the reference's assert_eq! compares; identity -> (0, 0). */
+int ark_hip_sw_into_affine(int curve, const uint64_t* jac_points, size_t n, uint64_t* out_xy);
+
+/* ---- Radix-2 evaluation domain ----
+ * Mirror of Radix2EvaluationDomain<F>'s public fields (poly/src/domain/radix2/mod.rs:22-42). */
+typedef struct {
+  uint64_t size;
+  uint32_t log_size_of_group;
+  uint32_t _pad;
+  uint64_t size_as_field_element[4];
+  uint64_t size_inv[4];
+  uint64_t group_gen[4];
+  uint64_t group_gen_inv[4];
+  uint64_t offset[4];
+  uint64_t offset_inv[4];
+  uint64_t offset_pow_size[4];
+} ark_hip_radix2_domain;
+
+/* Radix2EvaluationDomain::new (radix2/mod.rs:55-83): size = num_coeffs.next_power_of_two();
+ * returns ARK_HIP_ERR_SIZE where the reference returns None (log size > TWO_ADICITY). */
+int ark_hip_radix2_domain_new(int field, size_t num_coeffs, ark_hip_radix2_domain* out);
+/* get_coset (radix2/mod.rs:85-92); ARK_HIP_ERR_ARG if offset == 0 (reference: None) */
+int ark_hip_radix2_domain_get_coset(int field, const ark_hip_radix2_domain* dom, const uint64_t* offset,
+                                    ark_hip_radix2_domain* out);
+/* fft_in_place / ifft_in_place (radix2/mod.rs:140-153) on exactly dom->size elements (the caller
+ * has already done the reference's resize(size, zero)); natural order in and out. */
+int ark_hip_fft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t* data);
+int ark_hip_ifft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t* data);
+/* Same on device memory; asynchronous on the context stream (ark_hip_synchronize() to wait). */
+int ark_hip_fft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d_data);
+int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d_data);
+int ark_hip_fft_set_timing(int enable);
+/* [total_ms, npass, pass0_ms, pass1_ms, ...] of the last timed device transform */
+int ark_hip_fft_last_timing(double out[10]);
+
+/* ---- device-arithmetic test hooks (used by tests/ to check the kernels' field and point
+ * arithmetic against the oracle; host pointers) ----
+ * op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 dbl, 7 into_bigint, 8 from_bigint */
+int ark_hip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
+int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
+/* kind: 2 bucket += affine, 3 bucket -= affine, 4 bucket += bucket, 5 bucket double, 6 bucket -> jacobian,
+ * 7 affine double_to_bucket.  acc/other/out are arrays of n elements. */
+int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64_t* other, uint64_t* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
