@@ -1,0 +1,15 @@
+"""algebra_amd -- MI355X-native MSM and radix-2 FFT behind the arkworks trait surface.
+
+Host-side mirror (Python, for tests/bench/multi-GPU plumbing) of the two reference interfaces the
+HIP library replaces:
+
+    ark_ec::VariableBaseMSM            -> algebra_amd.msm   (msm, msm_unchecked, msm_bigint)
+    ark_poly::Radix2EvaluationDomain   -> algebra_amd.domain.Radix2EvaluationDomain
+
+All arithmetic runs in libark_hip.so (hand-written HIP for gfx950) through the C ABI of
+include/ark_hip.h; this package holds no arithmetic and no CPU fallback.
+"""
+from . import curves  # noqa: F401
+from ._lib import ArkHipError, LIB_PATH, lib  # noqa: F401
+from .msm import MsmLengthMismatch, into_affine, msm, msm_bigint, msm_unchecked, sum_projective  # noqa: F401
+from .domain import Radix2EvaluationDomain  # noqa: F401

@@ -1,0 +1,98 @@
+"""ctypes binding of libark_hip.so (the C ABI declared in include/ark_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible, every compute
+entry point raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C algebra_amd/csrc -j8``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libark_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class ArkHipError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed with code %d" % (what, code))
+        self.code = code
+
+
+class Radix2DomainStruct(C.Structure):
+    """``ark_hip_radix2_domain``: mirror of Radix2EvaluationDomain<F>'s fields (poly/src/domain/radix2/mod.rs:22-42)."""
+    _fields_ = [
+        ("size", C.c_uint64),
+        ("log_size_of_group", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("size_as_field_element", C.c_uint64 * 4),
+        ("size_inv", C.c_uint64 * 4),
+        ("group_gen", C.c_uint64 * 4),
+        ("group_gen_inv", C.c_uint64 * 4),
+        ("offset", C.c_uint64 * 4),
+        ("offset_inv", C.c_uint64 * 4),
+        ("offset_pow_size", C.c_uint64 * 4),
+    ]
+
+
+# symbol -> (restype, argtypes); must list every function include/ark_hip.h declares
+SYMBOLS = {
+    "ark_hip_device_count": (C.c_int, []),
+    "ark_hip_init": (C.c_int, [C.c_int]),
+    "ark_hip_shutdown": (None, []),
+    "ark_hip_synchronize": (C.c_int, []),
+    "ark_hip_version": (C.c_char_p, []),
+    "ark_hip_curve_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
+    "ark_hip_curve_generator": (C.c_int, [C.c_int, C.c_void_p]),
+    "ark_hip_msm_sw": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ark_hip_msm_sw_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ark_hip_msm_set_timing": (C.c_int, [C.c_int]),
+    "ark_hip_msm_last_timing": (C.c_int, [C.POINTER(C.c_double)]),
+    "ark_hip_sw_sum": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ark_hip_sw_into_affine": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ark_hip_sw_add_affine_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ark_hip_radix2_domain_new": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(Radix2DomainStruct)]),
+    "ark_hip_radix2_domain_get_coset": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p,
+                                                  C.POINTER(Radix2DomainStruct)]),
+    "ark_hip_fft_in_place": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p]),
+    "ark_hip_ifft_in_place": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p]),
+    "ark_hip_fft_in_place_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p]),
+    "ark_hip_ifft_in_place_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p]),
+    "ark_hip_fft_set_timing": (C.c_int, [C.c_int]),
+    "ark_hip_fft_last_timing": (C.c_int, [C.POINTER(C.c_double)]),
+    "ark_hip_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_test_basefield_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_test_point_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "algebra_amd: %s not found -- the HIP extension is not built and there is no CPU fallback "
+                "(run `make -C algebra_amd/csrc -j8` or __graft_entry__.build())" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and cannot
+        # initialise if a second copy (the system ROCm one this library would otherwise pull in)
+        # is already loaded.  Importing torch first makes the dynamic linker resolve our
+        # DT_NEEDED libamdhip64.so.7 to the copy torch loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise ArkHipError(code, what)

@@ -5,6 +5,7 @@
 #include "msm.cuh"
 #include "fft.cuh"
 #include "internal.hpp"
+#include "curve_consts.hpp"
 
 using namespace arkhip;
 
@@ -85,21 +86,8 @@ Fp<FP> host_pow(Fp<FP> b, const uint64_t* e, int words) {
   }
   return r;
 }
-template <class FP>
-Fp<FP> host_inverse(const Fp<FP>& a) {  // a^(p-2)
-  constexpr int M = FP::N / 2;
-  uint64_t e[M];
-  for (int i = 0; i < M; i++) e[i] = ((uint64_t)FP::P[2 * i + 1] << 32) | FP::P[2 * i];
-  e[0] -= 2;  // p is odd and > 2: no borrow
-  return host_pow<FP>(a, e, M);
-}
-template <class FP, int NB>
-Fp2<FP, NB> host_inverse(const Fp2<FP, NB>& a) {  // conj(a) / (c0^2 - beta c1^2)   (quadratic_extension.rs:322-339)
-  typedef Fp<FP> B;
-  B norm = B::add(B::sqr(a.c0), Fp2<FP, NB>::mul_neg_beta(B::sqr(a.c1)));
-  B ni = host_inverse<FP>(norm);
-  return Fp2<FP, NB>{B::mul(a.c0, ni), B::neg(B::mul(a.c1, ni))};
-}
+template <class F>
+F host_inverse(const F& a) { return F::inverse(a); }
 
 // Projective (Jacobian) -> XYZZ: (X, Y, Z^2, Z^3)
 template <class F>
@@ -173,9 +161,9 @@ int domain_new(size_t num_coeffs, ark_hip_radix2_domain* out) {
   sz = F::to_mont(sz);
   F one = F::one();
   sz.store(out->size_as_field_element);
-  host_inverse<FP>(sz).store(out->size_inv);
+  host_inverse(sz).store(out->size_inv);
   g.store(out->group_gen);
-  host_inverse<FP>(g).store(out->group_gen_inv);
+  host_inverse(g).store(out->group_gen_inv);
   one.store(out->offset);
   one.store(out->offset_inv);
   one.store(out->offset_pow_size);
@@ -188,7 +176,7 @@ int domain_coset(const ark_hip_radix2_domain* dom, const uint64_t* offset, ark_h
   if (h.is_zero()) return ARK_HIP_ERR_ARG;  // inverse() -> None
   ark_hip_radix2_domain d = *dom;
   h.store(d.offset);
-  host_inverse<FP>(h).store(d.offset_inv);
+  host_inverse(h).store(d.offset_inv);
   uint64_t e[1] = {dom->size};
   host_pow<FP>(h, e, 1).store(d.offset_pow_size);
   *out = d;
@@ -296,6 +284,21 @@ int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_fi
   return 0;
 }
 
+int ark_hip_curve_generator(int curve, uint64_t* out_xy) {
+  if (!out_xy) return ARK_HIP_ERR_ARG;
+  const uint64_t* g = nullptr;
+  switch (curve) {
+    case 0: g = GEN_BN254_G1; break;
+    case 1: g = GEN_BLS12_381_G1; break;
+    case 2: g = GEN_BLS12_377_G1; break;
+    case 3: g = GEN_BLS12_377_G2; break;
+    case 4: g = GEN_BLS12_381_G2; break;
+    default: return ARK_HIP_ERR_ARG;
+  }
+  memcpy(out_xy, g, (size_t)CURVES[curve].fe_words * 16);
+  return 0;
+}
+
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont, uint64_t* out_xyz) {
   if (curve < 0 || curve > 4 || !out_xyz || (n && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
   int rc = ensure_ctx();
@@ -400,6 +403,27 @@ int ark_hip_sw_into_affine(int curve, const uint64_t* jac_points, size_t n, uint
     case 4: return host_into_affine<BLS12_381_G2>(jac_points, n, out_xy);
   }
   return ARK_HIP_ERR_ARG;
+}
+
+// out[i] = in[i] + delta on the device (affine in/out); d_in may equal d_out
+int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_t n, const uint64_t* delta_xy) {
+  if (curve < 0 || curve > 4 || !delta_xy || (n && (!d_in || !d_out))) return ARK_HIP_ERR_ARG;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Context* c = g_ctx;
+  size_t ab = (size_t)CURVES[curve].fe_words * 16;
+  if (c->stage_c.ensure(ab)) return ARK_HIP_ERR_NOMEM;
+  ARK_HIP_TRY(hipMemcpyAsync(c->stage_c.p, delta_xy, ab, hipMemcpyHostToDevice, c->stream));
+  switch (curve) {
+    case 0: rc = sw_add_affine_BN254_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
+    case 1: rc = sw_add_affine_BLS12_381_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
+    case 2: rc = sw_add_affine_BLS12_377_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
+    case 3: rc = sw_add_affine_BLS12_377_G2(d_in, d_out, n, c->stage_c.p, c->stream); break;
+    case 4: rc = sw_add_affine_BLS12_381_G2(d_in, d_out, n, c->stage_c.p, c->stream); break;
+  }
+  if (rc) return rc;
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 // ---- test hooks ----

@@ -281,6 +281,24 @@ struct Fp {
     return mul(a, r2);
   }
   ARK_HD static Fp cond_neg(const Fp& a, bool n) { return n ? neg(a) : a; }
+  // a^(p-2) (Fermat).  The reference uses a binary extended Euclid (montgomery_backend.rs:319-378);
+  // the value is the same canonical residue.  Off the hot path: domain constants, into_affine,
+  // synthetic-base generation.
+  ARK_HD static Fp inverse(const Fp& a) {
+    u32 e[N];
+    u32 borrow = 2;
+    for (int i = 0; i < N; i++) {
+      u64 x = (u64)P::P[i] - borrow;
+      e[i] = (u32)x;
+      borrow = (u32)(x >> 63);
+    }
+    Fp r = one();
+    for (int i = 32 * N - 1; i >= 0; i--) {
+      r = sqr(r);
+      if ((e[i >> 5] >> (i & 31)) & 1) r = mul(r, a);
+    }
+    return r;
+  }
 
   // ---- memory: 16-byte vector loads/stores of the reference layout ----
   ARK_HD static Fp load(const void* p) {
@@ -331,6 +349,12 @@ struct Fp2 {
   ARK_HD static Fp2 dbl(const Fp2& a) { return Fp2{B::dbl(a.c0), B::dbl(a.c1)}; }
   ARK_HD static Fp2 neg(const Fp2& a) { return Fp2{B::neg(a.c0), B::neg(a.c1)}; }
   ARK_HD static Fp2 cond_neg(const Fp2& a, bool n) { return n ? neg(a) : a; }
+  // conj(a) / (c0^2 - beta c1^2)      quadratic_extension.rs:322-339
+  ARK_HD static Fp2 inverse(const Fp2& a) {
+    B norm = B::add(B::sqr(a.c0), mul_neg_beta(B::sqr(a.c1)));
+    B ni = B::inverse(norm);
+    return Fp2{B::mul(a.c0, ni), B::neg(B::mul(a.c1, ni))};
+  }
   // x * NEG_BETA for the small non-residues used here (1 or 5)
   ARK_HD static B mul_neg_beta(const B& x) {
     if constexpr (NEG_BETA == 1) return x;

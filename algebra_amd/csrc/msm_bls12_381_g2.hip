@@ -14,4 +14,7 @@ int test_basefield_op_BLS12_381_G2(int op, const void* a, const void* b, void* r
 int test_point_op_BLS12_381_G2(int kind, const void* acc, const void* other, void* out, size_t n, hipStream_t s) {
   return test_point_op_launch<BLS12_381_G2>(kind, acc, other, out, n, s);
 }
+int sw_add_affine_BLS12_381_G2(const void* in, void* out, size_t n, const void* d_delta, hipStream_t s) {
+  return sw_add_affine_launch<BLS12_381_G2>(in, out, n, d_delta, s);
+}
 }  // namespace arkhip

@@ -72,6 +72,37 @@ __global__ void __launch_bounds__(128) test_point_op_kernel(int kind, const char
   }
 }
 
+// out[i] = in[i] + delta, affine in / affine out (one Fermat inversion per point).  Used to grow
+// synthetic base sets on the device: P[i + m] = P[i] + (m*b)G continues P_i = (a + i*b)G
+// (SURVEY.md 8d synthetic inputs); also the device analogue of normalize_batch's output form.
+template <class C>
+__global__ void __launch_bounds__(128) sw_add_affine_kernel(const char* __restrict__ in, char* __restrict__ out,
+                                                            size_t n, const char* __restrict__ delta) {
+  typedef typename C::F F;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> d = Affine<F>::load(delta);
+  Affine<F> p = Affine<F>::load(in + i * Affine<F>::BYTES);
+  XYZZ<F> acc = XYZZ<F>::from_affine(d);
+  if (!p.is_zero()) xyzz_madd<F>(acc, p.x, p.y);
+  F x = F::zero(), y = F::zero();
+  if (!acc.is_zero()) {
+    F zzzi = F::inverse(acc.zzz);
+    F zzi = F::sqr(F::mul(acc.zz, zzzi));  // ZZ^-1 = (ZZ * ZZZ^-1)^2 since ZZ^3 = ZZZ^2
+    x = F::mul(acc.x, zzi);
+    y = F::mul(acc.y, zzzi);
+  }
+  x.store(out + i * Affine<F>::BYTES);
+  y.store(out + i * Affine<F>::BYTES + F::BYTES);
+}
+template <class C>
+int sw_add_affine_launch(const void* in, void* out, size_t n, const void* d_delta, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((sw_add_affine_kernel<C>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, (const char*)in,
+                     (char*)out, n, (const char*)d_delta);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 template <class C>
 int test_point_op_launch(int kind, const void* acc, const void* other, void* out, size_t n, hipStream_t s) {
   if (n == 0) return 0;

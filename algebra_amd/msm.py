@@ -1,0 +1,99 @@
+"""Host mirror of ark_ec::VariableBaseMSM for short-Weierstrass curves.
+
+Reference interface (ec/src/scalar_mul/variable_base/mod.rs:37-151, short_weierstrass/mod.rs:112-119):
+    msm(bases, scalars)            -> Result<Projective, usize>   Err(min_len) on length mismatch
+    msm_unchecked(bases, scalars)  -> Projective                  truncates to the shorter input
+    msm_bigint(bases, bigints)     -> Projective                  scalars already canonical BigInt<4>
+
+Points and scalars are numpy uint64 arrays (host) or torch tensors on the GPU (device), in the
+reference's in-memory layout: bases[n, 2*fe_words] (x|y Montgomery limbs, identity all-zero),
+scalars[n, 4]; the result is a numpy uint64 array of 3*fe_words limbs (Jacobian x|y|z).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import curves as cv
+from ._lib import check, lib
+
+
+class MsmLengthMismatch(ValueError):
+    """The reference's Err(min_len) (variable_base/mod.rs:73-77)."""
+
+    def __init__(self, min_len):
+        super().__init__("bases and scalars differ in length; shorter is %d" % min_len)
+        self.min_len = min_len
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _rows(x, words):
+    if _is_torch(x):
+        return x.numel() * x.element_size() // (8 * words)
+    return x.size // words
+
+
+def _host(x):
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _run(curve, bases, scalars, n, montgomery):
+    cid = cv.curve_id(curve)
+    out = np.zeros(cv.projective_words(cid), dtype=np.uint64)
+    L = lib()
+    if _is_torch(bases) or _is_torch(scalars):
+        if not (_is_torch(bases) and _is_torch(scalars) and bases.is_cuda and scalars.is_cuda):
+            raise TypeError("bases and scalars must both be CUDA tensors or both be numpy arrays")
+        assert bases.is_contiguous() and scalars.is_contiguous()
+        import torch
+        torch.cuda.current_stream().synchronize()  # inputs may have been produced on torch's stream
+        check(L.ark_hip_msm_sw_device(cid, bases.data_ptr(), scalars.data_ptr(), n, int(montgomery),
+                                      out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_sw_device")
+    else:
+        b, bp = _host(bases)
+        s, sp = _host(scalars)
+        check(L.ark_hip_msm_sw(cid, bp, sp, n, int(montgomery), out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_sw")
+    return out
+
+
+def msm_unchecked(curve, bases, scalars):
+    """VariableBaseMSM::msm_unchecked: scalars are Fr elements (Montgomery); inputs truncated to the shorter."""
+    n = min(_rows(bases, cv.affine_words(curve)), _rows(scalars, cv.SCALAR_WORDS))
+    return _run(curve, bases, scalars, n, True)
+
+
+def msm(curve, bases, scalars):
+    """VariableBaseMSM::msm / SWCurveConfig::msm: length check, then msm_unchecked."""
+    nb, ns = _rows(bases, cv.affine_words(curve)), _rows(scalars, cv.SCALAR_WORDS)
+    if nb != ns:
+        raise MsmLengthMismatch(min(nb, ns))
+    return _run(curve, bases, scalars, nb, True)
+
+
+def msm_bigint(curve, bases, bigints):
+    """VariableBaseMSM::msm_bigint: scalars are canonical BigInt<4> (< r)."""
+    n = min(_rows(bases, cv.affine_words(curve)), _rows(bigints, cv.SCALAR_WORDS))
+    return _run(curve, bases, bigints, n, False)
+
+
+def sum_projective(curve, points):
+    """Sum of Projective points on the host (Projective: Sum, group.rs:659-663): the multi-GPU combine."""
+    cid = cv.curve_id(curve)
+    p, pp = _host(points)
+    n = p.size // cv.projective_words(cid)
+    out = np.zeros(cv.projective_words(cid), dtype=np.uint64)
+    check(lib().ark_hip_sw_sum(cid, pp, n, out.ctypes.data_as(C.c_void_p)), "ark_hip_sw_sum")
+    return out
+
+
+def into_affine(curve, points):
+    """CurveGroup::into_affine for one or more Projective points (affine.rs:374-396)."""
+    cid = cv.curve_id(curve)
+    p, pp = _host(points)
+    n = p.size // cv.projective_words(cid)
+    out = np.zeros((n, cv.affine_words(cid)), dtype=np.uint64)
+    check(lib().ark_hip_sw_into_affine(cid, pp, n, out.ctypes.data_as(C.c_void_p)), "ark_hip_sw_into_affine")
+    return out[0] if p.ndim == 1 else out

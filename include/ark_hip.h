@@ -46,6 +46,9 @@ const char* ark_hip_version(void);
 /* u64 words per base-field element (4, 6 or 12), scalar field id, base field id, extension degree */
 int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_field, int* ext_degree);
 
+/* SWCurveConfig::GENERATOR (e.g. curves/bls12_381/src/curves/g1.rs:199-205) as Affine limbs */
+int ark_hip_curve_generator(int curve, uint64_t* out_xy);
+
 /* ---- MSM ----
  * Replaces SWCurveConfig::msm (ec/src/models/short_weierstrass/mod.rs:112-119) -> 
  * VariableBaseMSM::msm_unchecked / msm_bigint (ec/src/scalar_mul/variable_base/mod.rs:59-85).
@@ -72,6 +75,11 @@ int ark_hip_sw_sum(int curve, const uint64_t* jac_points, size_t n, uint64_t* ou
 /* From<Projective> for Affine (ec/src/models/short_weierstrass/affine.rs:374-396): the unique
  * representative the reference's assert_eq! compares; identity -> (0, 0). */
 int ark_hip_sw_into_affine(int curve, const uint64_t* jac_points, size_t n, uint64_t* out_xy);
+
+/* out[i] = in[i] + delta for n affine points in device memory (affine result, one inversion per
+ * point; d_in may equal d_out).  Used to grow synthetic base sets P_i = (a + i*b)G on the device
+ * (bench.py / tests); mathematically Affine + Affine -> into_affine (group.rs:332-413, affine.rs:374-396). */
+int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_t n, const uint64_t* delta_xy);
 
 /* ---- Radix-2 evaluation domain ----
  * Mirror of Radix2EvaluationDomain<F>'s public fields (poly/src/domain/radix2/mod.rs:22-42). */

@@ -1,0 +1,108 @@
+"""CPU-side checks of the product library (no GPU needed): it loads, exports every symbol the header
+declares, and its host-side pieces (domain constants, projective sum, into_affine -- the same
+templated formulas the kernels use, compiled for the host) agree with the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import algebra_amd as A
+from algebra_amd import _lib
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A4 = np.array([0xA11CE, 1, 2, 0], dtype=np.uint64)
+B4 = np.array([0xB0B, 3, 0, 0], dtype=np.uint64)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ark_hip.h")).read()
+    declared = set(re.findall(r"\b(ark_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = _lib.lib()  # raises if the .so is missing
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert b"gfx950" in L.ark_hip_version()
+
+
+def test_curve_info_matches_oracle():
+    import ctypes as C
+    for cid in range(5):
+        fw, sf, bf, ext = (C.c_int() for _ in range(4))
+        assert _lib.lib().ark_hip_curve_info(cid, C.byref(fw), C.byref(sf), C.byref(bf), C.byref(ext)) == 0
+        ob, os_, oe = O.curve_info(cid)
+        assert (fw.value, sf.value, bf.value, ext.value) == (O.fe_words(cid), os_, ob, oe)
+
+
+@pytest.mark.parametrize("fname", ["BN254_FR", "BLS12_381_FR", "BLS12_377_FR"])
+def test_domain_new_matches_oracle(fname):
+    fid = O.FID[fname]
+    for log_n in [0, 1, 2, 5, 10, 16, 22, 28]:
+        d = A.Radix2EvaluationDomain.new(fname, 1 << log_n)
+        g, gi, si = O.domain(fid, log_n)
+        assert d.size() == 1 << log_n and d.log_size_of_group() == log_n
+        assert np.array_equal(d.group_gen(), g)
+        assert np.array_equal(d.group_gen_inv(), gi)
+        assert np.array_equal(d.size_inv(), si)
+        one = O.field_const(fid, 1)
+        assert np.array_equal(d.coset_offset(), one) and np.array_equal(d.coset_offset_pow_size(), one)
+        # size_as_field_element = F::from(size)
+        sz = np.array([1 << log_n, 0, 0, 0], dtype=np.uint64)
+        assert np.array_equal(d.size_as_field_element(), O.field_op(fid, "from_bigint", sz))
+    # next_power_of_two semantics and the None case (radix2/mod.rs:55-64)
+    assert A.Radix2EvaluationDomain.new(fname, 0).size() == 1
+    assert A.Radix2EvaluationDomain.new(fname, 1000).size() == 1024
+    two_adicity = {"BN254_FR": 28, "BLS12_381_FR": 32, "BLS12_377_FR": 47}[fname]
+    if two_adicity < 40:
+        assert A.Radix2EvaluationDomain.new(fname, (1 << two_adicity) + 1) is None
+    # coset: offset = GENERATOR as in poly/benches/fft.rs:107
+    gen = O.field_const(fid, 3)
+    d = A.Radix2EvaluationDomain.new(fname, 64).get_coset(gen)
+    assert np.array_equal(d.coset_offset(), gen)
+    assert np.array_equal(O.field_op(fid, "mul", d.coset_offset(), d.coset_offset_inv()), O.field_const(fid, 1))
+    p = gen
+    for _ in range(6):
+        p = O.field_op(fid, "sqr", p)
+    assert np.array_equal(d.coset_offset_pow_size(), p)
+    assert A.Radix2EvaluationDomain.new(fname, 64).get_coset(np.zeros(4, dtype=np.uint64)) is None
+
+
+@pytest.mark.parametrize("cname", O.CURVES)
+def test_host_sum_and_into_affine_match_oracle(cname):
+    cid = O.CID[cname]
+    bases = O.gen_bases(cid, A4, B4, 6)
+    sc = O.gen_scalars(O.curve_info(cid)[1], 7, 6)
+    pts = np.stack([O.scalar_mul(cid, bases[i], sc[i]) for i in range(6)])
+    # into_affine
+    got = A.into_affine(cid, pts)
+    assert np.array_equal(got, O.to_affine(cid, pts))
+    # identity -> (0,0)
+    ident = O.msm(cid, bases[:0], sc[:0], O.NAIVE)
+    assert np.array_equal(A.into_affine(cid, ident), np.zeros(2 * O.fe_words(cid), dtype=np.uint64))
+    # sum of projective points == naive msm
+    total = A.sum_projective(cid, pts)
+    expect = O.msm(cid, bases, sc, O.NAIVE)
+    assert np.array_equal(A.into_affine(cid, total), O.to_affine(cid, expect))
+    # P + (-P) = identity ; P + P = 2P (doubling branch) ; with identity operand
+    negp = pts[0].copy()
+    fw = O.fe_words(cid)
+    negp[fw:2 * fw] = O.basefield_op(cid, "neg", pts[0][fw:2 * fw])
+    z = A.sum_projective(cid, np.stack([pts[0], negp]))
+    assert np.array_equal(A.into_affine(cid, z), np.zeros(2 * fw, dtype=np.uint64))
+    dbl = A.sum_projective(cid, np.stack([pts[0], pts[0], ident]))
+    two = np.array([2, 0, 0, 0], dtype=np.uint64)
+    s2 = O.field_op(O.curve_info(cid)[1], "mul", O.field_op(O.curve_info(cid)[1], "from_bigint", sc[0]),
+                    O.field_op(O.curve_info(cid)[1], "from_bigint", two))
+    s2 = O.field_op(O.curve_info(cid)[1], "into_bigint", s2)
+    assert np.array_equal(A.into_affine(cid, dbl), O.to_affine(cid, O.scalar_mul(cid, bases[0], s2)))
+
+
+def test_length_mismatch_is_reported_like_the_reference():
+    # variable_base/mod.rs:73-77: Err(min(len)) ; raised before any device work
+    bases = np.zeros((3, 12), dtype=np.uint64)
+    scalars = np.zeros((2, 4), dtype=np.uint64)
+    with pytest.raises(A.MsmLengthMismatch) as e:
+        A.msm("BLS12_381_G1", bases, scalars)
+    assert e.value.min_len == 2

@@ -1,0 +1,98 @@
+"""Radix-2 FFT / IFFT parity (GPU): HIP path through the C ABI vs the oracle (serial Cooley-Tukey
+restatement and direct Horner evaluation), mirroring poly/src/domain/radix2/mod.rs:351-536 and
+poly/src/test.rs:12-60.  Outputs are compared limb-for-limb (field elements are canonical)."""
+import numpy as np
+import pytest
+
+import algebra_amd as A
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+FR = ["BN254_FR", "BLS12_381_FR", "BLS12_377_FR"]
+
+
+def rand_fr(fid, n, seed):
+    return O.gen_scalars(fid, seed, max(n, 1), montgomery=True)[:n]
+
+
+@pytest.mark.parametrize("fname", FR)
+@pytest.mark.parametrize("log_n", list(range(0, 15)))
+def test_fft_matches_oracle_all_small_sizes(fname, log_n):
+    fid = O.FID[fname]
+    n = 1 << log_n
+    x = rand_fr(fid, n, 100 + log_n)
+    d = A.Radix2EvaluationDomain.new(fname, n)
+    got = d.fft(x)
+    assert np.array_equal(got.reshape(-1), O.fft(fid, x, log_n, None, False, 4))
+    goti = d.ifft(x)
+    assert np.array_equal(goti.reshape(-1), O.fft(fid, x, log_n, None, True, 4))
+    # coset (offset = GENERATOR, poly/benches/fft.rs:107)
+    gen = O.field_const(fid, 3)
+    dc = d.get_coset(gen)
+    assert np.array_equal(dc.fft(x).reshape(-1), O.fft(fid, x, log_n, gen, False, 4))
+    assert np.array_equal(dc.ifft(x).reshape(-1), O.fft(fid, x, log_n, gen, True, 4))
+
+
+@pytest.mark.parametrize("fname", FR)
+def test_fft_is_polynomial_evaluation(fname):
+    # test_fft_correctness (radix2/mod.rs:351-391): fft(p)[i] == p(domain.element(i)), degree 31 on 32/64
+    fid = O.FID[fname]
+    coeffs = rand_fr(fid, 32, 5)
+    gen = O.field_const(fid, 3)
+    for log_n in (5, 6):
+        d = A.Radix2EvaluationDomain.new(fname, 1 << log_n)
+        assert np.array_equal(d.fft(coeffs).reshape(-1), O.dft_naive(fid, coeffs, log_n, None))  # zero-extended input
+        dc = d.get_coset(gen)
+        assert np.array_equal(dc.fft(coeffs).reshape(-1), O.dft_naive(fid, coeffs, log_n, gen))
+        back = dc.ifft(dc.fft(coeffs))
+        assert np.array_equal(back[:32], coeffs) and not back[32:].any()
+
+
+def test_fft_ifft_identity_small_vector():
+    # test_fft_ifft_identity on [1..8] (radix2/mod.rs:581-600)
+    fid = O.FID["BLS12_381_FR"]
+    v = np.zeros((8, 4), dtype=np.uint64)
+    v[:, 0] = np.arange(1, 9)
+    x = O.field_op(fid, "from_bigint", v).reshape(8, 4)
+    d = A.Radix2EvaluationDomain.new("BLS12_381_FR", 8)
+    assert np.array_equal(d.ifft(d.fft(x)), x)
+
+
+@pytest.mark.parametrize("fname,log_n", [("BLS12_381_FR", 16), ("BLS12_381_FR", 20), ("BN254_FR", 17),
+                                         ("BLS12_377_FR", 19)])
+def test_fft_large_matches_oracle(fname, log_n):
+    fid = O.FID[fname]
+    n = 1 << log_n
+    x = rand_fr(fid, n, 31 + log_n)
+    d = A.Radix2EvaluationDomain.new(fname, n)
+    assert np.array_equal(d.fft(x).reshape(-1), O.fft(fid, x, log_n, None, False, 8))
+    gen = O.field_const(fid, 3)
+    dc = d.get_coset(gen)
+    assert np.array_equal(dc.ifft(x).reshape(-1), O.fft(fid, x, log_n, gen, True, 8))
+
+
+def test_fft_2_22_bls12_381_device_resident():
+    # BASELINE config 3: BLS12-381 Fr, domain 2^22, on device memory; vs the oracle and round trip
+    import torch
+    fname, log_n = "BLS12_381_FR", 22
+    fid = O.FID[fname]
+    n = 1 << log_n
+    x = rand_fr(fid, n, 2222)
+    d = A.Radix2EvaluationDomain.new(fname, n)
+    dx = torch.from_numpy(x.view(np.int64)).cuda()
+    y = d.fft(dx)
+    exp = O.fft(fid, x, log_n, None, False, 8)
+    assert np.array_equal(y.cpu().numpy().view(np.uint64).reshape(-1), exp)
+    back = d.ifft_in_place(y)
+    assert torch.equal(back, dx)
+    # coset round trip at full size
+    dc = d.get_coset(O.field_const(fid, 3))
+    assert torch.equal(dc.ifft(dc.fft(dx)), dx)
+    # linearity: fft(a + b) = fft(a) + fft(b) on a slice
+    b = rand_fr(fid, n, 3333)
+    ab = O.field_op(fid, "add", x, b).reshape(n, 4)
+    ya = y = d.fft(dx).cpu().numpy().view(np.uint64).reshape(n, 4)
+    yb = d.fft(b).reshape(n, 4)
+    yab = d.fft(ab).reshape(n, 4)
+    assert np.array_equal(O.field_op(fid, "add", ya, yb).reshape(n, 4), yab)

@@ -1,0 +1,180 @@
+"""MSM parity (GPU): the HIP path through the C ABI vs the oracle's restatement of
+msm_bigint_wnaf / the naive sum, mirroring test-templates/src/msm.rs:17-110 and the edge cases of
+SURVEY.md 8(d).  Comparison is on into_affine() limbs, bit-exact."""
+import numpy as np
+import pytest
+
+import algebra_amd as A
+import oracle_lib as O
+import hip_lib as H
+import pyref as P
+
+pytestmark = pytest.mark.gpu
+
+A4 = np.array([0xA11CE, 1, 2, 0], dtype=np.uint64)
+B4 = np.array([0xB0B, 3, 0, 0], dtype=np.uint64)
+
+
+def sf(cid):
+    return O.curve_info(cid)[1]
+
+
+def check(cid, bases, scalars, variant=O.SIGNED, threads=4):
+    got = A.msm_bigint(cid, bases, scalars)
+    exp = O.msm(cid, bases, scalars, variant, threads)
+    assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp))
+    return got
+
+
+@pytest.mark.parametrize("cname", O.CURVES)
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 1000, 1 << 12])
+def test_msm_random_matches_oracle(cname, n):
+    # test_var_base_msm (msm.rs:17-32) at n = 2^10-ish plus the n in {0,1,31,32,33} boundary sizes
+    cid = O.CID[cname]
+    if cname.endswith("G2") and n > 1000:
+        n = 1 << 11
+    bases = O.gen_bases(cid, A4, B4, max(n, 1))[:n]
+    scalars = O.gen_scalars(sf(cid), 0xA11CE + n, max(n, 1))[:n]
+    check(cid, bases, scalars)
+
+
+@pytest.mark.parametrize("cname", ["BN254_G1", "BLS12_381_G1", "BLS12_377_G2"])
+def test_msm_montgomery_scalar_entry(cname):
+    # VariableBaseMSM::msm takes Fr elements: the into_bigint pass (mod.rs:60-62) runs on the device
+    cid = O.CID[cname]
+    n = 777
+    bases = O.gen_bases(cid, A4, B4, n)
+    mont = O.gen_scalars(sf(cid), 99, n, montgomery=True)
+    got = A.msm(cid, bases, mont)
+    exp = O.msm(cid, bases, mont, O.SIGNED, 4, montgomery_scalars=True)
+    assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp))
+    # msm_unchecked truncates to the shorter input (mod.rs:59-64)
+    got2 = A.msm_unchecked(cid, bases, mont[:500])
+    exp2 = O.msm(cid, bases[:500], mont[:500], O.SIGNED, 4, montgomery_scalars=True)
+    assert np.array_equal(A.into_affine(cid, got2), O.to_affine(cid, exp2))
+
+
+@pytest.mark.parametrize("cname", ["BN254_G1", "BLS12_381_G1", "BLS12_377_G2"])
+def test_msm_edge_cases(cname):
+    cid = O.CID[cname]
+    cvp = P.Curve(cname)
+    r = cvp.r
+    fw = O.fe_words(cid)
+    n = 64
+    bases = O.gen_bases(cid, A4, B4, n)
+    rng = np.random.default_rng(3)
+    lim = lambda v: np.array(P.to_limbs(v % r, 4), dtype=np.uint64)
+    # zero scalars, scalar = 1, scalar = r-1, small and negative-small scalars
+    vals = [0, 1, r - 1, 2, r - 2, 255, r - 255, (1 << 64) - 1, r - (1 << 64), (r - 1) // 2, (r + 1) // 2]
+    vals += [int.from_bytes(rng.bytes(40), "little") % r for _ in range(n - len(vals))]
+    scalars = np.stack([lim(v) for v in vals])
+    check(cid, bases, scalars)
+    # all-zero scalars -> identity
+    z = A.msm_bigint(cid, bases, np.zeros((n, 4), dtype=np.uint64))
+    assert np.array_equal(A.into_affine(cid, z), np.zeros(2 * fw, dtype=np.uint64))
+    # identity bases are skipped
+    b2 = bases.copy()
+    b2[::3] = 0
+    check(cid, b2, scalars)
+    # duplicate bases with equal scalars: forces the doubling branch inside a bucket
+    b3 = bases.copy()
+    b3[1] = b3[0]
+    b3[5] = b3[4]
+    s3 = scalars.copy()
+    s3[0] = s3[1] = lim(12345)
+    s3[4] = s3[5]
+    check(cid, b3, s3)
+    # P and -P with equal scalars: bucket returns to infinity
+    b4 = bases.copy()
+    b4[3] = b4[2]
+    b4[3, fw:] = O.basefield_op(cid, "neg", b4[2, fw:])
+    s4 = scalars.copy()
+    s4[2] = s4[3] = lim(0xDEADBEEF)
+    check(cid, b4, s4)
+    # every scalar the same: one bucket per window takes all points
+    check(cid, bases, np.tile(lim(0x1234567 + (1 << 200)), (n, 1)))
+
+
+@pytest.mark.parametrize("cname", ["BN254_G1", "BLS12_381_G1"])
+def test_msm_mixed_scalar_classes(cname):
+    # test_var_base_msm_mixed_scalars (msm.rs:36-72): +-bool, +-u8, +-u16, +-u32, +-u64, random, shuffled
+    cid = O.CID[cname]
+    r = P.Curve(cname).r
+    rng = np.random.default_rng(8)
+    m = 128
+    vals = []
+    for bits in (1, 8, 16, 32, 64):
+        pos = [int(x) for x in rng.integers(0, 1 << min(bits, 63), size=m, dtype=np.uint64)]
+        vals += pos + [(r - v) % r for v in pos]
+    vals += [int.from_bytes(rng.bytes(40), "little") % r for _ in range(m)]
+    perm = rng.permutation(len(vals))
+    vals = [vals[i] for i in perm]
+    n = len(vals)
+    bases = O.gen_bases(cid, A4, B4, n)
+    scalars = np.array([P.to_limbs(v, 4) for v in vals], dtype=np.uint64)
+    check(cid, bases, scalars)
+
+
+def test_msm_known_answer_table_bls12_381_g1():
+    # reference KAT: k*G for k = 0..999 (curves/bls12_381/src/curves/tests/g1_uncompressed_valid_test_vectors.dat,
+    # checked by tests/mod.rs:69-111); MSM over entries 1..44 with all-ones scalars = entry 990
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bls12_381_g1_multiples.npz"))
+    xy = g["xy"]  # canonical limbs [1000, 2, 6]
+    fq = O.FID["BLS12_381_FQ"]
+    mont = O.field_op(fq, "from_bigint", xy.reshape(-1, 6)).reshape(1000, 12)
+    cid = O.CID["BLS12_381_G1"]
+    ones = np.zeros((44, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    got = A.into_affine(cid, A.msm_bigint(cid, mont[1:45], ones))
+    assert np.array_equal(got, mont[990])
+    # sum_k k * (kG) over k = 1..13 = (sum k^2) G = 819 G
+    sc = np.zeros((13, 4), dtype=np.uint64)
+    sc[:, 0] = np.arange(1, 14)
+    got = A.into_affine(cid, A.msm_bigint(cid, mont[1:14], sc))
+    assert np.array_equal(got, mont[819])
+
+
+@pytest.mark.parametrize("cname,logn", [("BN254_G1", 16), ("BLS12_381_G1", 18), ("BLS12_377_G2", 14)])
+def test_msm_medium_vs_oracle_wnaf(cname, logn):
+    # BASELINE config 1 size (BN254 2^16) and friends against the multi-threaded msm_bigint_wnaf restatement
+    cid = O.CID[cname]
+    n = 1 << logn
+    seed = O.gen_bases(cid, A4, B4, 1 << 10)
+    import torch
+    d = H.gpu_extend_bases(cid, seed, n, lambda m: _delta(cid, m))
+    bases = d.cpu().numpy().view(np.uint64).reshape(n, -1)
+    # the device-grown bases are the oracle's arithmetic progression
+    spot = O.gen_bases(cid, A4, B4, (1 << 10) + 8)
+    assert np.array_equal(bases[: (1 << 10) + 8], spot)
+    scalars = O.gen_scalars(sf(cid), 4242, n)
+    got = A.msm_bigint(cid, d, torch.from_numpy(scalars.view(np.int64)).cuda())
+    exp = O.msm(cid, bases, scalars, O.WNAF, 8)
+    assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp))
+    # and equals k*G with k = sum s_i (a + i b)  (exact discrete-log check)
+    k = O.msm_dlog(cid, scalars, A4, B4)
+    kg = O.scalar_mul(cid, O.generator(cid), k)
+    assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, kg))
+
+
+def _delta(cid, m):
+    """(m*b) G as affine limbs."""
+    r = P.MODULI[O.FIELDS[sf(cid)]][0]
+    k = (m * P.from_limbs(B4)) % r
+    return O.to_affine(cid, O.scalar_mul(cid, O.generator(cid), np.array(P.to_limbs(k, 4), dtype=np.uint64)))
+
+
+@pytest.mark.parametrize("logn", [20, 22])
+def test_msm_bls12_381_g1_large_dlog(logn):
+    # BASELINE config 2: bit-exact at 2^20 / 2^22 through the discrete-log identity
+    # (result == k*G, k = sum_i s_i (a + i b) mod r) -- a size-independent exact check.
+    import torch
+    cid = O.CID["BLS12_381_G1"]
+    n = 1 << logn
+    seed = O.gen_bases(cid, A4, B4, 1 << 10)
+    d = H.gpu_extend_bases(cid, seed, n, lambda m: _delta(cid, m))
+    scalars = O.gen_scalars(sf(cid), 777 + logn, n)
+    got = A.msm_bigint(cid, d, torch.from_numpy(scalars.view(np.int64)).cuda())
+    k = O.msm_dlog(cid, scalars, A4, B4)
+    kg = O.scalar_mul(cid, O.generator(cid), k)
+    assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, kg))
