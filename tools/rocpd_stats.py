@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (ROCm 7.2) `--kernel-trace` result database (rocpd sqlite, *_results.db) as the
+per-kernel statistics table `--stats` would print: calls, total/avg/min/max duration, share of GPU time.
+Launches shorter than --min-us are also reported separately so that the tiny set-up launches of bench.py
+(1-point MSMs that build the synthetic bases) do not dilute the averages of the timed launches.
+
+usage: tools/rocpd_stats.py gpurun_out/prof/r1_results.db [--min-us 1000] > profiles/<name>.txt
+"""
+import argparse
+import sqlite3
+
+
+def table(c, where, title):
+    rows = c.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e6, min(end-start)/1e6, "
+                     "max(end-start)/1e6, max(vgpr_count), max(lds_size), max(scratch_size) from kernels %s "
+                     "group by name order by 3 desc" % where).fetchall()
+    tot = sum(r[2] for r in rows) or 1.0
+    print("## " + title)
+    print("%-72s %6s %11s %10s %10s %10s %6s %5s %7s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "min_ms", "max_ms",
+                                                          "pct", "vgpr", "lds", "scratch"))
+    for r in rows:
+        print("%-72s %6d %11.3f %10.4f %10.4f %10.4f %6.2f %5d %7d %7d" % (r[0][:72], r[1], r[2], r[3], r[4], r[5],
+                                                                       100 * r[2] / tot, r[6], r[7], r[8]))
+    print()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--min-us", type=float, default=1000.0)
+    a = ap.parse_args()
+    c = sqlite3.connect(a.db)
+    table(c, "", "all kernel launches")
+    table(c, "where (end-start) >= %d" % int(a.min_us * 1000), "launches >= %.0f us (the timed full-size steps)" % a.min_us)
+
+
+if __name__ == "__main__":
+    main()
