@@ -44,8 +44,8 @@ static constexpr u32 KEY_NONE = 0xffffffffu;
 // ---- K1: signed-digit recoding + bucket histogram ---------------------------------------------
 template <class SP>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__ scalars, u32 n, int mont, int c,
-                                                         int W, u32* __restrict__ keys, u32* __restrict__ hist,
-                                                         u32* __restrict__ err) {
+                                                         int W, u32* __restrict__ keys, u32* __restrict__ ranks,
+                                                         u32* __restrict__ hist, u32* __restrict__ err) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   typedef Fp<SP> S;
@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
       }
       u32 sign = (d < 0 ? 0x80000000u : 0u) ^ flip;
       key = sign | (mag - 1);
-      atomicAdd(&hist[((size_t)w << (c - 1)) + (mag - 1)], 1u);
+      // the returned old count is this point's rank inside its bucket: the scatter needs no second atomic
+      ranks[(size_t)w * n + i] = atomicAdd(&hist[((size_t)w << (c - 1)) + (mag - 1)], 1u);
     }
     keys[(size_t)w * n + i] = key;
   }
@@ -145,9 +146,9 @@ static __global__ void __launch_bounds__(1024) scan_sums_inplace(u32* sums, u32 
     __syncthreads();
   }
 }
-// each block rescans its tile; writes offsets (exclusive) and a cursor copy; offsets[m] = total
+// each block rescans its tile; writes offsets (exclusive); offsets[m] = total
 static __global__ void __launch_bounds__(256) scan_apply(const u32* __restrict__ in, size_t m, const u32* __restrict__ sums,
-                                                  u32* __restrict__ offsets, u32* __restrict__ cursor) {
+                                                  u32* __restrict__ offsets) {
   __shared__ u32 sh[256];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
   u32 x[8];
@@ -170,26 +171,67 @@ static __global__ void __launch_bounds__(256) scan_apply(const u32* __restrict__
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     size_t j = base + k;
-    if (j < m) {
-      offsets[j] = run;
-      cursor[j] = run;
-    }
+    if (j < m) offsets[j] = run;
     run += x[k];
     if (j == m - 1) offsets[m] = run;
   }
 }
 
 // ---- K3: scatter point indices into bucket order ------------------------------------------------
-static __global__ void __launch_bounds__(256) msm_scatter_kernel(const u32* __restrict__ keys, u32 n, int c,
-                                                          u32* __restrict__ cursor, u32* __restrict__ sorted) {
+static __global__ void __launch_bounds__(256) msm_scatter_kernel(const u32* __restrict__ keys,
+                                                                 const u32* __restrict__ ranks, u32 n, int c,
+                                                                 const u32* __restrict__ offsets,
+                                                                 u32* __restrict__ sorted) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   u32 w = blockIdx.y;
   if (i >= n) return;
   u32 key = keys[(size_t)w * n + i];
   if (key == KEY_NONE) return;
   size_t g = ((size_t)w << (c - 1)) + (key & 0x7fffffffu);
-  u32 pos = atomicAdd(&cursor[g], 1u);
+  u32 pos = offsets[g] + ranks[(size_t)w * n + i];
   sorted[pos] = i | (key & 0x80000000u);
+}
+
+// ---- K3b: bucket processing order, heaviest first -------------------------------------------------
+// Lanes of one wave should own buckets of (nearly) equal load, otherwise the wave runs for its
+// longest bucket (Poisson loads: ~30% of the lanes' time idle at mean 32).  Counting sort of bucket
+// ids by load class (load >> shift, clamped to 255), descending; per-block LDS histograms keep the
+// global atomics out of it.
+static constexpr int ORDER_TILE = 2048;
+static constexpr int ORDER_BINS = 256;
+static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* __restrict__ hist, size_t nb, int shift,
+                                                                    u32 nblocks, u32* __restrict__ block_hist) {
+  __shared__ u32 sh[ORDER_BINS];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * ORDER_TILE;
+  for (int k = 0; k < ORDER_TILE / 256; k++) {
+    size_t g = base + threadIdx.x + (size_t)k * 256;
+    if (g < nb) {
+      u32 cls = hist[g] >> shift;
+      if (cls > ORDER_BINS - 1) cls = ORDER_BINS - 1;
+      atomicAdd(&sh[ORDER_BINS - 1 - cls], 1u);  // class 0 of the output = heaviest
+    }
+  }
+  __syncthreads();
+  block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = sh[threadIdx.x];  // bin-major
+}
+static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32* __restrict__ hist, size_t nb, int shift,
+                                                                       u32 nblocks, const u32* __restrict__ block_off,
+                                                                       u32* __restrict__ order) {
+  __shared__ u32 sh[ORDER_BINS];
+  sh[threadIdx.x] = block_off[(size_t)threadIdx.x * nblocks + blockIdx.x];
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * ORDER_TILE;
+  for (int k = 0; k < ORDER_TILE / 256; k++) {
+    size_t g = base + threadIdx.x + (size_t)k * 256;
+    if (g < nb) {
+      u32 cls = hist[g] >> shift;
+      if (cls > ORDER_BINS - 1) cls = ORDER_BINS - 1;
+      u32 pos = atomicAdd(&sh[ORDER_BINS - 1 - cls], 1u);
+      order[pos] = (u32)g;
+    }
+  }
 }
 
 // ---- K4: bucket accumulation --------------------------------------------------------------------
@@ -334,12 +376,13 @@ struct DevBuf {
 };
 
 struct MsmWorkspace {
-  DevBuf keys, sorted, hist, offsets, cursor, sums, buckets, lvlS[2], lvlA[2], err;
+  DevBuf keys, ranks, sorted, hist, offsets, sums, buckets, lvlS[2], lvlA[2], err, order, ohist, ooff;
   void* pinned = nullptr;  // host staging for the window sums
   size_t pinned_cap = 0;
   std::mutex mu;
   void release() {
-    keys.release(); sorted.release(); hist.release(); offsets.release(); cursor.release(); sums.release();
+    keys.release(); ranks.release(); sorted.release(); hist.release(); offsets.release(); sums.release();
+    order.release(); ohist.release(); ooff.release();
     buckets.release(); err.release();
     for (int i = 0; i < 2; i++) { lvlS[i].release(); lvlA[i].release(); }
     if (pinned) (void)hipHostFree(pinned);
@@ -374,9 +417,13 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   if (ws.sorted.ensure((size_t)W * n * 4)) return -3;
   if (ws.hist.ensure(nb * 4)) return -3;
   if (ws.offsets.ensure((nb + 1) * 4)) return -3;
-  if (ws.cursor.ensure(nb * 4)) return -3;
+  if (ws.ranks.ensure((size_t)W * n * 4)) return -3;
   const u32 nscan = (u32)((nb + SCAN_TILE - 1) / SCAN_TILE);
-  if (ws.sums.ensure((size_t)nscan * 4)) return -3;
+  const u32 noblk = (u32)((nb + ORDER_TILE - 1) / ORDER_TILE);
+  const size_t nohist = (size_t)noblk * ORDER_BINS;
+  const u32 noscan = (u32)((nohist + SCAN_TILE - 1) / SCAN_TILE);
+  if (ws.sums.ensure((size_t)(nscan > noscan ? nscan : noscan) * 4)) return -3;
+  if (ws.order.ensure(nb * 4) || ws.ohist.ensure(nohist * 4) || ws.ooff.ensure((nohist + 1) * 4)) return -3;
   if (ws.buckets.ensure(nb * Pt::BYTES)) return -3;
   if (ws.pinned_cap < (size_t)W * Pt::BYTES + 64) {
     if (ws.pinned) (void)hipHostFree(ws.pinned);
@@ -396,7 +443,8 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   u32* sorted = (u32*)ws.sorted.p;
   u32* hist = (u32*)ws.hist.p;
   u32* offsets = (u32*)ws.offsets.p;
-  u32* cursor = (u32*)ws.cursor.p;
+  u32* ranks = (u32*)ws.ranks.p;
+  u32* order = (u32*)ws.order.p;
   u32* sums = (u32*)ws.sums.p;
 
   if (ws.err.ensure(16)) return -3;
@@ -404,16 +452,29 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   ARK_HIP_TRY(hipMemsetAsync(ws.err.p, 0, 4, stream));
   const u32 nblk = (u32)((n + 255) / 256);
   hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
-                     (u32)n, scalars_mont, c, W, keys, hist, (u32*)ws.err.p);
+                     (u32)n, scalars_mont, c, W, keys, ranks, hist, (u32*)ws.err.p);
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL(scan_block_sums, dim3(nscan), dim3(256), 0, stream, hist, nb, sums);
   hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, nscan);
-  hipLaunchKernelGGL(scan_apply, dim3(nscan), dim3(256), 0, stream, hist, nb, sums, offsets, cursor);
+  hipLaunchKernelGGL(scan_apply, dim3(nscan), dim3(256), 0, stream, hist, nb, sums, offsets);
+  {
+    // load classes: width 2^shift so that the mean load falls around class 32..63
+    size_t mean = ((size_t)n * W) / nb;
+    int shift = 0;
+    while ((mean >> shift) >= 64) shift++;
+    u32* ohist = (u32*)ws.ohist.p;
+    u32* ooff = (u32*)ws.ooff.p;
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk), dim3(256), 0, stream, hist, nb, shift, noblk, ohist);
+    hipLaunchKernelGGL(scan_block_sums, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums);
+    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, noscan);
+    hipLaunchKernelGGL(scan_apply, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums, ooff);
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk), dim3(256), 0, stream, hist, nb, shift, noblk, ooff, order);
+  }
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[2], stream));
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk, W), dim3(256), 0, stream, keys, (u32)n, c, cursor, sorted);
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk, W), dim3(256), 0, stream, keys, ranks, (u32)n, c, offsets, sorted);
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[3], stream));
   hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
-                     (const char*)d_bases, sorted, offsets, (const u32*)nullptr, (u32)nb, (char*)ws.buckets.p);
+                     (const char*)d_bases, sorted, offsets, order, (u32)nb, (char*)ws.buckets.p);
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[4], stream));
 
   // bucket reduction levels

@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--fft-log-n", type=int, default=22)
     ap.add_argument("--fft-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=18)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=22)
     args = ap.parse_args()
 
     import torch
@@ -149,16 +149,11 @@ def main():
     scalars = torch.from_numpy(scalars_h.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
-    gather_buf = [torch.zeros(cv.projective_words(cid), dtype=torch.int64, device="cuda") for _ in range(world)]
+    from algebra_amd import dist as D
 
     def step():
-        part = A.msm_bigint(cid, bases, scalars)
-        if world == 1:
-            return part
-        t = torch.from_numpy(part.view(np.int64)).cuda()
-        dist.all_gather(gather_buf, t)
-        allp = torch.stack(gather_buf).cpu().numpy().view(np.uint64)
-        return A.sum_projective(cid, allp)
+        # local MSM on this rank's base range, then (N > 1) RCCL all-gather of the 144-byte partials + EC sum
+        return D.msm_bigint_sharded(cid, bases, scalars)
 
     def barrier():
         if world > 1:
