@@ -57,11 +57,19 @@ const CurveInfo CURVES[5] = {
 int msm_dispatch(int curve, MsmWorkspace& ws, const void* b, const void* s, size_t n, int mont, uint64_t* out,
                  hipStream_t st, MsmTimings* tm) {
   switch (curve) {
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BN254_G1: return msm_run_BN254_G1(ws, b, s, n, mont, out, st, tm);
+#endif
     case ARK_HIP_BLS12_381_G1: return msm_run_BLS12_381_G1(ws, b, s, n, mont, out, st, tm);
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BLS12_377_G1: return msm_run_BLS12_377_G1(ws, b, s, n, mont, out, st, tm);
+#endif
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BLS12_377_G2: return msm_run_BLS12_377_G2(ws, b, s, n, mont, out, st, tm);
+#endif
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BLS12_381_G2: return msm_run_BLS12_381_G2(ws, b, s, n, mont, out, st, tm);
+#endif
   }
   return ARK_HIP_ERR_ARG;
 }
@@ -69,9 +77,13 @@ int msm_dispatch(int curve, MsmWorkspace& ws, const void* b, const void* s, size
 int fft_dispatch(int field, FftWorkspace& ws, void* d, int k, const uint64_t* root, const uint64_t* pre,
                  const uint64_t* post, const uint64_t* postc, hipStream_t st, FftTimings* tm) {
   switch (field) {
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BN254_FR: return fft_run_BN254_FR(ws, d, k, root, pre, post, postc, st, tm);
+#endif
     case ARK_HIP_BLS12_381_FR: return fft_run_BLS12_381_FR(ws, d, k, root, pre, post, postc, st, tm);
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BLS12_377_FR: return fft_run_BLS12_377_FR(ws, d, k, root, pre, post, postc, st, tm);
+#endif
   }
   return ARK_HIP_ERR_ARG;
 }
@@ -415,11 +427,19 @@ int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_
   if (c->stage_c.ensure(ab)) return ARK_HIP_ERR_NOMEM;
   ARK_HIP_TRY(hipMemcpyAsync(c->stage_c.p, delta_xy, ab, hipMemcpyHostToDevice, c->stream));
   switch (curve) {
+#ifndef ARK_HIP_DEV
     case 0: rc = sw_add_affine_BN254_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
+#endif
     case 1: rc = sw_add_affine_BLS12_381_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
+#ifndef ARK_HIP_DEV
     case 2: rc = sw_add_affine_BLS12_377_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
+#endif
+#ifndef ARK_HIP_DEV
     case 3: rc = sw_add_affine_BLS12_377_G2(d_in, d_out, n, c->stage_c.p, c->stream); break;
+#endif
+#ifndef ARK_HIP_DEV
     case 4: rc = sw_add_affine_BLS12_381_G2(d_in, d_out, n, c->stage_c.p, c->stream); break;
+#endif
   }
   if (rc) return rc;
   ARK_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -429,6 +449,7 @@ int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_
 // ---- test hooks ----
 static int run_elementwise(size_t abytes, size_t bbytes, size_t rbytes, const void* a, const void* b, void* r,
                            int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t), int op, size_t n) {
+  if (!fn) return ARK_HIP_ERR_ARG;  // curve/field not in this (development) build
   int rc = ensure_ctx();
   if (rc) return rc;
   Context* c = g_ctx;
@@ -448,13 +469,21 @@ int ark_hip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* 
   size_t fb = field_bytes(field);
   int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t) = nullptr;
   switch (field) {
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BN254_FR: fn = test_field_op_BN254_FR; break;
+#endif
     case ARK_HIP_BLS12_381_FR: fn = test_field_op_BLS12_381_FR; break;
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BLS12_377_FR: fn = test_field_op_BLS12_377_FR; break;
+#endif
     // base fields: through the G1 curve that lives over them (ops 0..5)
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BN254_FQ: fn = test_basefield_op_BN254_G1; break;
+#endif
     case ARK_HIP_BLS12_381_FQ: fn = test_basefield_op_BLS12_381_G1; break;
+#ifndef ARK_HIP_DEV
     case ARK_HIP_BLS12_377_FQ: fn = test_basefield_op_BLS12_377_G1; break;
+#endif
     default: return ARK_HIP_ERR_ARG;
   }
   if ((field == ARK_HIP_BN254_FQ || field == ARK_HIP_BLS12_381_FQ || field == ARK_HIP_BLS12_377_FQ) && op > 5)
@@ -467,11 +496,19 @@ int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64
   size_t fb = (size_t)CURVES[curve].fe_words * 8;
   int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t) = nullptr;
   switch (curve) {
+#ifndef ARK_HIP_DEV
     case 0: fn = test_basefield_op_BN254_G1; break;
+#endif
     case 1: fn = test_basefield_op_BLS12_381_G1; break;
+#ifndef ARK_HIP_DEV
     case 2: fn = test_basefield_op_BLS12_377_G1; break;
+#endif
+#ifndef ARK_HIP_DEV
     case 3: fn = test_basefield_op_BLS12_377_G2; break;
+#endif
+#ifndef ARK_HIP_DEV
     case 4: fn = test_basefield_op_BLS12_381_G2; break;
+#endif
   }
   return run_elementwise(n * fb, b ? n * fb : 0, n * fb, a, b, r, fn, op, n);
 }
@@ -485,11 +522,19 @@ int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64
   if (bbytes && !other) return ARK_HIP_ERR_ARG;
   int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t) = nullptr;
   switch (curve) {
+#ifndef ARK_HIP_DEV
     case 0: fn = test_point_op_BN254_G1; break;
+#endif
     case 1: fn = test_point_op_BLS12_381_G1; break;
+#ifndef ARK_HIP_DEV
     case 2: fn = test_point_op_BLS12_377_G1; break;
+#endif
+#ifndef ARK_HIP_DEV
     case 3: fn = test_point_op_BLS12_377_G2; break;
+#endif
+#ifndef ARK_HIP_DEV
     case 4: fn = test_point_op_BLS12_381_G2; break;
+#endif
   }
   return run_elementwise(abytes, bbytes, rbytes, acc, bbytes ? other : nullptr, out, fn, kind, n);
 }

@@ -47,9 +47,9 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
                                                          int W, u32* __restrict__ keys, u32* __restrict__ ranks,
                                                          u32* __restrict__ hist, u32* __restrict__ err) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;  // no early return: the wave-level ballots below need every lane
   typedef Fp<SP> S;
-  S s = S::load(scalars + (size_t)i * S::N);
+  S s = live ? S::load(scalars + (size_t)i * S::N) : S::zero();
   if (mont) s = S::from_mont(s);  // mod.rs:60-62 into_bigint
   // t = r - s ; use it (and negate the point) when t < s
   u32 t[S::N];
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
       carry = 0;
     }
     int d = (int)raw - (int)(carry << c);
-    if (d != 0) {
+    if (d != 0 && live) {
       u32 mag = d < 0 ? (u32)(-d) : (u32)d;
       if (mag > half) {  // only reachable for a scalar >= 2^BITS, which the reference does not accept either
         atomicOr(err, 1u);
@@ -95,10 +95,36 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
       }
       u32 sign = (d < 0 ? 0x80000000u : 0u) ^ flip;
       key = sign | (mag - 1);
-      // the returned old count is this point's rank inside its bucket: the scatter needs no second atomic
-      ranks[(size_t)w * n + i] = atomicAdd(&hist[((size_t)w << (c - 1)) + (mag - 1)], 1u);
     }
-    keys[(size_t)w * n + i] = key;
+    // The histogram atomic returns the point's rank inside its bucket, so the scatter needs no second
+    // atomic.  Lanes of the wave that hit the same bucket are combined first (ballot + prefix count):
+    // uniform scalars never collide, but the reference's small-scalar distributions
+    // (bench-templates/src/macros/ec.rs:244-372) put whole waves on one counter.
+    {
+      const u32 bkt = key & 0x7fffffffu;
+      bool pending = key != KEY_NONE;
+      u32 rank = 0;
+      u32* ctr = &hist[((size_t)w << (c - 1)) + (pending ? bkt : 0u)];
+      for (int round = 0; round < 2; round++) {
+        unsigned long long act = __ballot(pending);
+        if (act == 0) break;
+        int leader = __ffsll((long long)act) - 1;
+        u32 lkey = (u32)__shfl((int)bkt, leader);
+        unsigned long long same = __ballot(pending && bkt == lkey);
+        int cnt = __popcll(same);
+        if (cnt < 4) break;  // no real contention: fall through to one atomic per lane
+        u32 base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(ctr, (u32)cnt);
+        base = (u32)__shfl((int)base, leader);
+        if (pending && bkt == lkey) {
+          rank = base + (u32)__popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+          pending = false;
+        }
+      }
+      if (pending) rank = atomicAdd(ctr, 1u);
+      if (key != KEY_NONE) ranks[(size_t)w * n + i] = rank;
+    }
+    if (live) keys[(size_t)w * n + i] = key;
   }
 }
 
@@ -242,12 +268,13 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restr
                                                              const u32* __restrict__ sorted,
                                                              const u32* __restrict__ offsets,
                                                              const u32* __restrict__ order, u32 nbuckets,
-                                                             char* __restrict__ buckets) {
+                                                             u32 heavy_thresh, char* __restrict__ buckets) {
   typedef typename C::F F;
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nbuckets) return;
   u32 g = order ? order[t] : t;
   u32 j = offsets[g], end = offsets[g + 1];
+  if (end - j > heavy_thresh) return;  // left to the heavy-bucket kernels
   XYZZ<F> acc = XYZZ<F>::zero();
   if (j < end) {
     u32 e = sorted[j];
@@ -271,6 +298,158 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restr
     }
   }
   acc.store(buckets + (size_t)g * XYZZ<F>::BYTES);
+}
+
+// ---- K4h: heavy buckets --------------------------------------------------------------------------
+// A bucket far above the mean load (non-uniform scalars: the reference's bool / u8 / ... benches, or
+// many equal scalars) would pin one lane for its whole length.  Buckets above `thresh` are skipped by
+// the lane-per-bucket kernel, cut into chunks of HEAVY_CHUNK entries, each chunk summed by one
+// workgroup (256 lanes striding + LDS tree), and the chunk partials combined per bucket.
+static constexpr u32 HEAVY_CHUNK = 16384;
+struct HeavyEntry { u32 bucket, first_item, items; };
+
+static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* __restrict__ offsets, u32 nbuckets,
+                                                                    u32 thresh, u32* __restrict__ ctr /*[2]*/,
+                                                                    HeavyEntry* __restrict__ list,
+                                                                    uint2* __restrict__ items) {
+  u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nbuckets) return;
+  u32 cnt = offsets[g + 1] - offsets[g];
+  if (cnt <= thresh) return;
+  u32 k = (cnt + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
+  u32 first = atomicAdd(&ctr[0], k);
+  u32 slot = atomicAdd(&ctr[1], 1u);
+  list[slot] = HeavyEntry{g, first, k};
+  for (u32 q = 0; q < k; q++) items[first + q] = make_uint2(g, q);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __restrict__ bases,
+                                                                const u32* __restrict__ sorted,
+                                                                const u32* __restrict__ offsets,
+                                                                const u32* __restrict__ ctr,
+                                                                const uint2* __restrict__ items,
+                                                                char* __restrict__ partials) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  extern __shared__ uint4 heavy_lds[];
+  char* sh = (char*)heavy_lds;
+  const u32 nitems = ctr[0];
+  for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+    uint2 it = items[item];
+    u32 lo = offsets[it.x] + it.y * HEAVY_CHUNK;
+    u32 hi = offsets[it.x + 1];
+    if (hi > lo + HEAVY_CHUNK) hi = lo + HEAVY_CHUNK;
+    Pt acc = Pt::zero();
+    for (u32 j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+      u32 e = sorted[j];
+      Affine<F> p = Affine<F>::load(bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+      if (!p.is_zero()) {
+        F y = F::cond_neg(p.y, (e >> 31) != 0);
+        xyzz_madd<F>(acc, p.x, y);
+      }
+    }
+    // workgroup tree sum through LDS
+    acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
+    __syncthreads();
+    for (u32 o = blockDim.x / 2; o > 0; o >>= 1) {
+      if (threadIdx.x < o) {
+        Pt other = Pt::load(sh + (size_t)(threadIdx.x + o) * Pt::BYTES);
+        xyzz_add<F>(acc, other);
+        acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) acc.store(partials + (size_t)item * Pt::BYTES);
+    __syncthreads();
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __restrict__ ctr,
+                                                               const HeavyEntry* __restrict__ list,
+                                                               const char* __restrict__ partials,
+                                                               char* __restrict__ buckets) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= ctr[1]) return;
+  HeavyEntry h = list[slot];
+  Pt acc = Pt::zero();
+  for (u32 q = 0; q < h.items; q++) {
+    Pt x = Pt::load(partials + (size_t)(h.first_item + q) * Pt::BYTES);
+    xyzz_add<F>(acc, x);
+  }
+  acc.store(buckets + (size_t)h.bucket * Pt::BYTES);
+}
+
+// ---- K4 (lazy form): base conversion pre-pass + bucket accumulation in 28-bit limbs -------------------
+// bases (reference layout, canonical Montgomery) -> x*2^(28L), y*2^(28L) as 2L u32 words per point
+template <class C>
+__global__ void __launch_bounds__(256) msm_bases_to_lazy_kernel(const char* __restrict__ bases, u32 n,
+                                                                u32* __restrict__ out) {
+  typedef typename C::F F;
+  typedef FpLazy<typename F::P> LZ;
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = Affine<F>::load(bases + (size_t)i * Affine<F>::BYTES);
+  LZ x = LZ::from_canonical(p.x), y = LZ::from_canonical(p.y);  // identity (0,0) stays all-zero
+  u32* o = out + (size_t)i * 2 * LZ::L;
+  x.store(o);
+  y.store(o + LZ::L);
+}
+
+template <class LZ>
+__device__ __forceinline__ void lazy_point_load(const u32* __restrict__ q, LZ& x, LZ& y) {
+  constexpr int WORDS = 2 * LZ::L;  // 28 or 20: a multiple of 4
+  u32 w[WORDS];
+#pragma unroll
+  for (int k = 0; k < WORDS / 4; k++) {
+    uint4 v = ((const uint4*)q)[k];
+    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < LZ::L; k++) { x.l[k] = w[k]; y.l[k] = w[LZ::L + k]; }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const u32* __restrict__ lbases,
+                                                                  const u32* __restrict__ sorted,
+                                                                  const u32* __restrict__ offsets,
+                                                                  const u32* __restrict__ order, u32 nbuckets,
+                                                                  u32 heavy_thresh, char* __restrict__ buckets) {
+  typedef typename C::F F;
+  typedef typename F::P P;
+  typedef FpLazy<P> LZ;
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  u32 g = order ? order[t] : t;
+  u32 j = offsets[g], end = offsets[g + 1];
+  if (end - j > heavy_thresh) return;
+  XYZZLazy<P> acc;
+  acc.inf = true;
+  acc.x = acc.y = acc.zz = acc.zzz = LZ::zero();
+  if (j < end) {
+    u32 e = sorted[j];
+    LZ px, py;
+    lazy_point_load<LZ>(lbases + (size_t)(e & 0x7fffffffu) * 2 * LZ::L, px, py);
+    for (;;) {
+      u32 e_next = 0;
+      LZ nx = px, ny = py;
+      bool more = j + 1 < end;
+      if (more) {
+        e_next = sorted[j + 1];
+        lazy_point_load<LZ>(lbases + (size_t)(e_next & 0x7fffffffu) * 2 * LZ::L, nx, ny);
+      }
+      if (!(px.limbs_all_zero() && py.limbs_all_zero())) xyzz_madd_lazy<P>(acc, px, py, (e >> 31) != 0);
+      if (!more) break;
+      e = e_next;
+      px = nx;
+      py = ny;
+      j++;
+    }
+  }
+  xyzz_from_lazy<P>(acc).store(buckets + (size_t)g * XYZZ<F>::BYTES);
 }
 
 // ---- K5: one level of the bucket reduction ---------------------------------------------------------
@@ -376,12 +555,13 @@ struct DevBuf {
 };
 
 struct MsmWorkspace {
-  DevBuf keys, ranks, sorted, hist, offsets, sums, buckets, lvlS[2], lvlA[2], err, order, ohist, ooff;
+  DevBuf hctr, hlist, hitems, hpart, lbases, keys, ranks, sorted, hist, offsets, sums, buckets, lvlS[2], lvlA[2], err, order, ohist, ooff;
   void* pinned = nullptr;  // host staging for the window sums
   size_t pinned_cap = 0;
   std::mutex mu;
   void release() {
-    keys.release(); ranks.release(); sorted.release(); hist.release(); offsets.release(); sums.release();
+    hctr.release(); hlist.release(); hitems.release(); hpart.release();
+    lbases.release(); keys.release(); ranks.release(); sorted.release(); hist.release(); offsets.release(); sums.release();
     order.release(); ohist.release(); ooff.release();
     buckets.release(); err.release();
     for (int i = 0; i < 2; i++) { lvlS[i].release(); lvlA[i].release(); }
@@ -448,6 +628,16 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   u32* sums = (u32*)ws.sums.p;
 
   if (ws.err.ensure(16)) return -3;
+  // heavy buckets: load above max(2048, 16 x mean)
+  const size_t total_entries = (size_t)n * W;
+  size_t mean_load = total_entries / nb;
+  const u32 heavy_thresh = (u32)(mean_load * 16 > 2048 ? mean_load * 16 : 2048);
+  const size_t max_heavy = total_entries / heavy_thresh + 1;
+  const size_t max_items = total_entries / HEAVY_CHUNK + max_heavy + 1;
+  if (ws.hctr.ensure(16) || ws.hlist.ensure(max_heavy * sizeof(HeavyEntry)) || ws.hitems.ensure(max_items * 8) ||
+      ws.hpart.ensure(max_items * Pt::BYTES))
+    return -3;
+  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 8, stream));
   ARK_HIP_TRY(hipMemsetAsync(hist, 0, nb * 4, stream));
   ARK_HIP_TRY(hipMemsetAsync(ws.err.p, 0, 4, stream));
   const u32 nblk = (u32)((n + 255) / 256);
@@ -473,8 +663,27 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[2], stream));
   hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk, W), dim3(256), 0, stream, keys, ranks, (u32)n, c, offsets, sorted);
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[3], stream));
-  hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
-                     (const char*)d_bases, sorted, offsets, order, (u32)nb, (char*)ws.buckets.p);
+  if constexpr (C::LAZY) {
+    typedef FpLazy<typename F::P> LZ;
+    if (ws.lbases.ensure(n * 2 * LZ::L * 4)) return -3;
+    hipLaunchKernelGGL((msm_bases_to_lazy_kernel<C>), dim3(nblk), dim3(256), 0, stream, (const char*)d_bases, (u32)n,
+                       (u32*)ws.lbases.p);
+    hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
+                       (const u32*)ws.lbases.p, sorted, offsets, order, (u32)nb, heavy_thresh, (char*)ws.buckets.p);
+  } else {
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
+                       (const char*)d_bases, sorted, offsets, order, (u32)nb, heavy_thresh, (char*)ws.buckets.p);
+  }
+  {
+    u32* hctr = (u32*)ws.hctr.p;
+    hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
+                       heavy_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
+    const u32 hthreads = Pt::BYTES > 192 ? 128 : 256;  // keep the LDS tree within 48 KiB
+    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), hthreads * Pt::BYTES, stream,
+                       (const char*)d_bases, sorted, offsets, hctr, (const uint2*)ws.hitems.p, (char*)ws.hpart.p);
+    hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3((u32)((max_heavy + 63) / 64)), dim3(64), 0, stream, hctr,
+                       (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, (char*)ws.buckets.p);
+  }
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[4], stream));
 
   // bucket reduction levels

@@ -1,0 +1,125 @@
+// Bucket sort of the (window, scalar) keys for the MSM: replaces one device-scope atomic per key (the
+// histogram / scatter of a naive counting sort: 2.2e8 atomics at 2^24 x 13 windows, ~27 G/s on this chip)
+// by two partition passes whose counters live in LDS.
+//
+//   pass A  (msm_part_hist / msm_part_scatter)   split every window's keys by the HIGH bits of the bucket
+//           id into 2^HB "super-buckets": per-workgroup LDS histogram -> global exclusive scan over
+//           (super-bucket, workgroup) -> second sweep recomputes its local ranks with LDS atomics and
+//           writes (low bits | sign, point index) pairs to its reserved slots.
+//   pass B  (msm_part_finish)   one workgroup per super-bucket (<= 1024 buckets, ~32 K entries, 256 KiB:
+//           L2 resident): LDS histogram of the LOW bits, LDS scan -> bucket offsets, then places the
+//           point indices.  Wave-level work only, no cross-workgroup communication.
+//
+// Output is exactly what the accumulate kernels consume: `sorted` (point index, sign in bit 31, grouped
+// by global bucket id) and `offsets` (exclusive prefix sums of the bucket loads, nb + 1 entries).
+// The order of the points inside a bucket is unspecified -- it only changes the Projective representative,
+// never the group element.  (Role in the reference: none -- the CPU walks scalars and adds into
+// `buckets[|digit|-1]` directly, ec/src/scalar_mul/variable_base/mod.rs:464-475.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fp.cuh"
+
+namespace arkhip {
+
+static constexpr int PART_LO_BITS = 10;        // buckets per super-bucket = 2^10
+static constexpr int PART_TILE = 16384;        // keys per workgroup in pass A (256 lanes x 64)
+static constexpr u32 PART_KEY_NONE = 0xffffffffu;
+
+// A1: per-workgroup histogram over the high bits.  grid = (tiles, W); dynamic LDS = 4 << HB bytes.
+static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __restrict__ keys, u32 n, int HB, int LB,
+                                                                   u32 ntiles, u32* __restrict__ tile_hist) {
+  extern __shared__ u32 part_lds[];
+  const u32 nbins = 1u << HB;
+  for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) part_lds[b] = 0;
+  __syncthreads();
+  const u32 w = blockIdx.y;
+  const size_t base = (size_t)w * n;
+  const u32 lo = blockIdx.x * PART_TILE;
+  const u32 hi = lo + PART_TILE < n ? lo + PART_TILE : n;
+  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 key = keys[base + i];
+    if (key != PART_KEY_NONE) atomicAdd(&part_lds[(key & 0x7fffffffu) >> LB], 1u);
+  }
+  __syncthreads();
+  // bin-major: [(w << HB | bin)][tile]
+  for (u32 b = threadIdx.x; b < nbins; b += blockDim.x)
+    tile_hist[((size_t)((w << HB) | b)) * ntiles + blockIdx.x] = part_lds[b];
+}
+
+// A2: same sweep; LDS cursors start at the scanned (super-bucket, tile) offsets.
+static __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const u32* __restrict__ keys, u32 n, int HB, int LB,
+                                                                      u32 ntiles, const u32* __restrict__ tile_off,
+                                                                      uint2* __restrict__ part) {
+  extern __shared__ u32 part_lds[];
+  const u32 nbins = 1u << HB;
+  const u32 w = blockIdx.y;
+  for (u32 b = threadIdx.x; b < nbins; b += blockDim.x)
+    part_lds[b] = tile_off[((size_t)((w << HB) | b)) * ntiles + blockIdx.x];
+  __syncthreads();
+  const size_t base = (size_t)w * n;
+  const u32 lo = blockIdx.x * PART_TILE;
+  const u32 hi = lo + PART_TILE < n ? lo + PART_TILE : n;
+  const u32 lmask = (1u << LB) - 1u;
+  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 key = keys[base + i];
+    if (key != PART_KEY_NONE) {
+      u32 bkt = key & 0x7fffffffu;
+      u32 pos = atomicAdd(&part_lds[bkt >> LB], 1u);
+      part[pos] = make_uint2((bkt & lmask) | (key & 0x80000000u), i);
+    }
+  }
+}
+
+// B: one workgroup per super-bucket sb = (w << HB | hb): buckets g = sb << LB | low.
+static __global__ void __launch_bounds__(256) msm_part_finish_kernel(const uint2* __restrict__ part,
+                                                                     const u32* __restrict__ tile_off, u32 ntiles,
+                                                                     int LB, u32 nsuper, u32* __restrict__ offsets,
+                                                                     u32* __restrict__ sorted) {
+  __shared__ u32 cnt[1 << PART_LO_BITS];
+  __shared__ u32 wsum[256];
+  const u32 sb = blockIdx.x;
+  const u32 nlow = 1u << LB;
+  const u32 start = tile_off[(size_t)sb * ntiles];
+  const u32 end = tile_off[(size_t)(sb + 1) * ntiles];  // tile_off has nsuper * ntiles + 1 entries
+  for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
+  __syncthreads();
+  const u32 lmask = nlow - 1u;
+  for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&cnt[part[j].x & lmask], 1u);
+  __syncthreads();
+  // exclusive scan of cnt[0..nlow) with 256 lanes: each lane owns nlow/256 consecutive bins (>= 1 when LB >= 8)
+  const u32 per = (nlow + blockDim.x - 1) / blockDim.x;
+  u32 local[4];  // per <= 4 for LB <= 10
+  u32 s = 0;
+  for (u32 k = 0; k < per; k++) {
+    u32 b = threadIdx.x * per + k;
+    u32 v = b < nlow ? cnt[b] : 0;
+    local[k] = s;
+    s += v;
+  }
+  wsum[threadIdx.x] = s;
+  __syncthreads();
+  for (u32 o = 1; o < blockDim.x; o <<= 1) {
+    u32 y = threadIdx.x >= o ? wsum[threadIdx.x - o] : 0;
+    __syncthreads();
+    wsum[threadIdx.x] += y;
+    __syncthreads();
+  }
+  const u32 lane_base = start + wsum[threadIdx.x] - s;
+  for (u32 k = 0; k < per; k++) {
+    u32 b = threadIdx.x * per + k;
+    if (b < nlow) {
+      u32 off = lane_base + local[k];
+      cnt[b] = off;                                     // becomes the placement cursor
+      offsets[((size_t)sb << LB) + b] = off;
+    }
+  }
+  if (sb == nsuper - 1 && threadIdx.x == 0) offsets[(size_t)nsuper << LB] = end;
+  __syncthreads();
+  for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) {
+    uint2 e = part[j];
+    u32 pos = atomicAdd(&cnt[e.x & lmask], 1u);
+    sorted[pos] = e.y | (e.x & 0x80000000u);
+  }
+}
+
+}  // namespace arkhip

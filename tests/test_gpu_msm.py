@@ -178,3 +178,29 @@ def test_msm_bls12_381_g1_large_dlog(logn):
     k = O.msm_dlog(cid, scalars, A4, B4)
     kg = O.scalar_mul(cid, O.generator(cid), k)
     assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, kg))
+
+
+@pytest.mark.parametrize("cname", ["BLS12_381_G1", "BN254_G1", "BLS12_377_G2"])
+def test_msm_skewed_scalars_heavy_buckets(cname):
+    # non-uniform scalars (the reference's bool / u8 / "all equal" shapes, bench-templates/src/macros/ec.rs:244-372):
+    # a few buckets receive thousands of points -> heavy-bucket kernels + wave-combined histogram atomics
+    cid = O.CID[cname]
+    r = P.Curve(cname).r
+    n = 1 << (13 if cname.endswith("G2") else 15)
+    seed = O.gen_bases(cid, A4, B4, 1 << 10)
+    import torch
+    d = H.gpu_extend_bases(cid, seed, n, lambda m: _delta(cid, m))
+    bases = d.cpu().numpy().view(np.uint64).reshape(n, -1)
+    rng = np.random.default_rng(21)
+    lim = lambda v: P.to_limbs(v % r, 4)
+    cases = {
+        "all_equal": [0x1234567 + (1 << 200)] * n,
+        "bool": [int(x) for x in rng.integers(0, 2, size=n)],
+        "pm_u8": [int(x) if i % 2 else (r - int(x)) % r for i, x in enumerate(rng.integers(0, 256, size=n))],
+        "half_equal_half_random": [7 if i % 2 else int.from_bytes(rng.bytes(40), "little") % r for i in range(n)],
+    }
+    for name, vals in cases.items():
+        scalars = np.array([lim(v) for v in vals], dtype=np.uint64)
+        got = A.msm_bigint(cid, d, torch.from_numpy(scalars.view(np.int64)).cuda())
+        exp = O.msm(cid, bases, scalars, O.SIGNED, 8)
+        assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp)), (cname, name)
