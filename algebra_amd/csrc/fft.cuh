@@ -76,9 +76,29 @@ struct FftPassArgs {
   const u32* post_const;  // last pass: out *= const (nullable; used when post tables are absent)
 };
 
+// element <-> two 16-byte LDS planes
+template <class F>
+__device__ __forceinline__ F fft_unpack(const uint4& a, const uint4& b) {
+  F x;
+  x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w;
+  x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w;
+  return x;
+}
+template <class F>
+__device__ __forceinline__ void fft_pack(const F& x, uint4& a, uint4& b) {
+  a = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+  b = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+}
+
+static constexpr int FFT_THREADS = 256;
+static constexpr int FFT_MAX_EPT = 8;  // elements per lane: tiles of up to 2048 elements
+
+// One pass = load tile -> kp butterfly stages in LDS -> store tile.  Loops over the lane's elements /
+// butterflies are fully unrolled with predication so that all global loads of a phase (tile rows,
+// twiddles of a stage) are in flight together before the first dependent use.
 template <class FP>
-__global__ void __launch_bounds__(256) fft_pass_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
-                                                       FftPassArgs a) {
+__global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
+                                                               FftPassArgs a) {
   typedef Fp<FP> F;
   extern __shared__ uint4 lds[];
   const int kp = a.kp, t = a.t, k = a.k;
@@ -89,107 +109,150 @@ __global__ void __launch_bounds__(256) fft_pass_kernel(const u32* __restrict__ s
   const int lo_shift = k - a.s0 - kp;
   const u32 T1 = (1u << t) - 1u;
   const u32 Q1 = (1u << kp) - 1u;
+  const u32 tid = threadIdx.x;
   u32 mid = 0, hi_bits = 0;
   if (!a.last) {
     mid = tile & ((1u << (lo_shift - t)) - 1u);
     hi_bits = tile >> (lo_shift - t);
   }
-  // ---- load tile ----
-  for (u32 e = threadIdx.x; e < E; e += blockDim.x) {
-    size_t pos;
-    if (!a.last) {
-      u32 q = e >> t, r = e & T1;
-      pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
-    } else {
-      u32 r = e >> kp, q = e & Q1;
-      pos = ((size_t)r << (k - t)) | ((size_t)tile << kp) | q;
+  // ---- load tile: issue every global load, then fill LDS ----
+  {
+    uint4 v0[FFT_MAX_EPT], v1[FFT_MAX_EPT];
+    size_t ps[FFT_MAX_EPT];
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      if (e < E) {
+        size_t pos;
+        if (!a.last) {
+          u32 q = e >> t, r = e & T1;
+          pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
+        } else {
+          u32 r = e >> kp, q = e & Q1;
+          pos = ((size_t)r << (k - t)) | ((size_t)tile << kp) | q;
+        }
+        ps[it] = pos;
+        const uint4* g = (const uint4*)(src + pos * F::N);
+        v0[it] = g[0];
+        v1[it] = g[1];
+      }
     }
-    const uint4* g = (const uint4*)(src + pos * F::N);
-    uint4 v0 = g[0], v1 = g[1];
-    if (a.pre_lo) {
-      F x;
-      x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w;
-      x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
-      F pw = F::mul(F::load(a.pre_hi + (pos >> PW_LO_BITS) * F::N), F::load(a.pre_lo + (pos & ((1u << PW_LO_BITS) - 1)) * F::N));
-      x = F::mul(x, pw);
-      v0 = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-      v1 = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      if (e < E) {
+        if (a.pre_lo) {
+          size_t pos = ps[it];
+          F x = fft_unpack<F>(v0[it], v1[it]);
+          F pw = F::mul(F::load(a.pre_hi + (pos >> PW_LO_BITS) * F::N),
+                        F::load(a.pre_lo + (pos & ((1u << PW_LO_BITS) - 1)) * F::N));
+          x = F::mul(x, pw);
+          fft_pack<F>(x, v0[it], v1[it]);
+        }
+        pl0[e] = v0[it];
+        pl1[e] = v1[it];
+      }
     }
-    pl0[e] = v0;
-    pl1[e] = v1;
   }
   __syncthreads();
   // ---- kp butterfly stages in LDS ----
   for (int ls = 0; ls < kp; ls++) {
     const u32 lg = 1u << (kp - 1 - ls);
     const int s = a.s0 + ls;
-    for (u32 b = threadIdx.x; b < E / 2; b += blockDim.x) {
-      u32 i0, i1;
-      size_t tw;
-      if (!a.last) {
-        u32 r = b & T1, qq = b >> t;
-        u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
-        i0 = (q << t) | r;
-        i1 = i0 + (lg << t);
-        tw = ((((size_t)(q & (lg - 1))) << lo_shift) | ((size_t)mid << t) | r) << s;
-      } else {
-        u32 qq = b & ((1u << (kp - 1)) - 1u), r = b >> (kp - 1);
-        u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
-        i0 = (r << kp) | q;
-        i1 = i0 + lg;
-        tw = ((size_t)(q & (lg - 1))) << s;
+    u32 i0s[FFT_MAX_EPT / 2], i1s[FFT_MAX_EPT / 2];
+    uint4 w0[FFT_MAX_EPT / 2], w1[FFT_MAX_EPT / 2];
+    bool hasw[FFT_MAX_EPT / 2];
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 2; it++) {
+      u32 b = tid + it * FFT_THREADS;
+      hasw[it] = false;
+      if (b < E / 2) {
+        u32 i0, i1;
+        size_t tw;
+        if (!a.last) {
+          u32 r = b & T1, qq = b >> t;
+          u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
+          i0 = (q << t) | r;
+          i1 = i0 + (lg << t);
+          tw = ((((size_t)(q & (lg - 1))) << lo_shift) | ((size_t)mid << t) | r) << s;
+        } else {
+          u32 qq = b & ((1u << (kp - 1)) - 1u), r = b >> (kp - 1);
+          u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
+          i0 = (r << kp) | q;
+          i1 = i0 + lg;
+          tw = ((size_t)(q & (lg - 1))) << s;
+        }
+        i0s[it] = i0;
+        i1s[it] = i1;
+        if (tw != 0) {  // twiddle loads of the whole stage go out before any butterfly waits on one
+          const uint4* g = (const uint4*)(a.roots + tw * F::N);
+          w0[it] = g[0];
+          w1[it] = g[1];
+          hasw[it] = true;
+        }
       }
-      uint4 a0 = pl0[i0], a1 = pl1[i0], b0 = pl0[i1], b1 = pl1[i1];
-      F lo, hi;
-      lo.l[0] = a0.x; lo.l[1] = a0.y; lo.l[2] = a0.z; lo.l[3] = a0.w;
-      lo.l[4] = a1.x; lo.l[5] = a1.y; lo.l[6] = a1.z; lo.l[7] = a1.w;
-      hi.l[0] = b0.x; hi.l[1] = b0.y; hi.l[2] = b0.z; hi.l[3] = b0.w;
-      hi.l[4] = b1.x; hi.l[5] = b1.y; hi.l[6] = b1.z; hi.l[7] = b1.w;
-      F sum = F::add(lo, hi);          // fft.rs:190-198 butterfly_fn_io
-      F dif = F::sub(lo, hi);
-      if (tw != 0) dif = F::mul(dif, F::load(a.roots + tw * F::N));
-      pl0[i0] = make_uint4(sum.l[0], sum.l[1], sum.l[2], sum.l[3]);
-      pl1[i0] = make_uint4(sum.l[4], sum.l[5], sum.l[6], sum.l[7]);
-      pl0[i1] = make_uint4(dif.l[0], dif.l[1], dif.l[2], dif.l[3]);
-      pl1[i1] = make_uint4(dif.l[4], dif.l[5], dif.l[6], dif.l[7]);
+    }
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 2; it++) {
+      u32 b = tid + it * FFT_THREADS;
+      if (b < E / 2) {
+        const u32 i0 = i0s[it], i1 = i1s[it];
+        F lo = fft_unpack<F>(pl0[i0], pl1[i0]);
+        F hi = fft_unpack<F>(pl0[i1], pl1[i1]);
+        F sum = F::add(lo, hi);  // fft.rs:190-198 butterfly_fn_io
+        F dif = F::sub(lo, hi);
+        if (hasw[it]) dif = F::mul(dif, fft_unpack<F>(w0[it], w1[it]));
+        uint4 o0, o1;
+        fft_pack<F>(sum, o0, o1);
+        pl0[i0] = o0;
+        pl1[i0] = o1;
+        fft_pack<F>(dif, o0, o1);
+        pl0[i1] = o0;
+        pl1[i1] = o1;
+      }
     }
     __syncthreads();
   }
   // ---- store tile ----
   if (!a.last) {
-    for (u32 e = threadIdx.x; e < E; e += blockDim.x) {
-      u32 q = e >> t, r = e & T1;
-      size_t pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
-      uint4* g = (uint4*)(dst + pos * F::N);
-      g[0] = pl0[e];
-      g[1] = pl1[e];
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      if (e < E) {
+        u32 q = e >> t, r = e & T1;
+        size_t pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
+        uint4* g = (uint4*)(dst + pos * F::N);
+        g[0] = pl0[e];
+        g[1] = pl1[e];
+      }
     }
   } else {
     // position p = r<<(k-t) | tile<<kp | q holds X[bitrev_k(p)]  (replaces derange(), fft.rs:373-380)
     const int tb = k - kp - t;
     const size_t tile_rev = bitrev32(tile, tb);
-    for (u32 e = threadIdx.x; e < E; e += blockDim.x) {
-      u32 r2 = e & T1, q2 = e >> t;  // output-side coordinates
-      size_t opos = ((size_t)q2 << (k - kp)) | (tile_rev << t) | r2;
-      u32 i = (bitrev32(r2, t) << kp) | bitrev32(q2, kp);
-      uint4 v0 = pl0[i], v1 = pl1[i];
-      if (a.post_lo || a.post_const) {
-        F x;
-        x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w;
-        x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
-        F pw;
-        if (a.post_lo)
-          pw = F::mul(F::load(a.post_hi + (opos >> PW_LO_BITS) * F::N),
-                      F::load(a.post_lo + (opos & ((1u << PW_LO_BITS) - 1)) * F::N));
-        else
-          pw = F::load(a.post_const);
-        x = F::mul(x, pw);
-        v0 = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-        v1 = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      if (e < E) {
+        u32 r2 = e & T1, q2 = e >> t;  // output-side coordinates
+        size_t opos = ((size_t)q2 << (k - kp)) | (tile_rev << t) | r2;
+        u32 i = (bitrev32(r2, t) << kp) | bitrev32(q2, kp);
+        uint4 v0 = pl0[i], v1 = pl1[i];
+        if (a.post_lo || a.post_const) {
+          F x = fft_unpack<F>(v0, v1);
+          F pw;
+          if (a.post_lo)
+            pw = F::mul(F::load(a.post_hi + (opos >> PW_LO_BITS) * F::N),
+                        F::load(a.post_lo + (opos & ((1u << PW_LO_BITS) - 1)) * F::N));
+          else
+            pw = F::load(a.post_const);
+          x = F::mul(x, pw);
+          fft_pack<F>(x, v0, v1);
+        }
+        uint4* g = (uint4*)(dst + opos * F::N);
+        g[0] = v0;
+        g[1] = v1;
       }
-      uint4* g = (uint4*)(dst + opos * F::N);
-      g[0] = v0;
-      g[1] = v1;
     }
   }
 }

@@ -142,14 +142,16 @@ struct Fp {
     return o == 0;
   }
   // r = t - p if t >= p else t       (t < 2p < 2^(32N): every modulus here has a spare top bit)
+  // Carry chains are written with __builtin_addc/__builtin_subc: hipcc lowers them to one
+  // v_add_co/v_addc_co (v_sub_co/v_subb_co) per limb.
   ARK_HD static Fp reduce_once(const u32* t) {
     u32 d[N];
     u32 borrow = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      u64 x = (u64)t[i] - P::P[i] - borrow;
-      d[i] = (u32)x;
-      borrow = (u32)(x >> 63);
+      u32 bo;
+      d[i] = __builtin_subc(t[i], (u32)P::P[i], borrow, &bo);
+      borrow = bo;
     }
     Fp r;
 #pragma unroll
@@ -158,12 +160,12 @@ struct Fp {
   }
   ARK_HD static Fp add(const Fp& a, const Fp& b) {  // montgomery_backend.rs:129-136
     u32 t[N];
-    u64 c = 0;
+    u32 c = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      c += (u64)a.l[i] + b.l[i];
-      t[i] = (u32)c;
-      c >>= 32;
+      u32 co;
+      t[i] = __builtin_addc(a.l[i], b.l[i], c, &co);
+      c = co;
     }
     return reduce_once(t);
   }
@@ -179,18 +181,18 @@ struct Fp {
     u32 borrow = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      u64 x = (u64)a.l[i] - b.l[i] - borrow;
-      d[i] = (u32)x;
-      borrow = (u32)(x >> 63);
+      u32 bo;
+      d[i] = __builtin_subc(a.l[i], b.l[i], borrow, &bo);
+      borrow = bo;
     }
-    u32 mask = 0u - borrow;
+    const u32 mask = 0u - borrow;
     Fp r;
-    u64 c = 0;
+    u32 c = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      c += (u64)d[i] + (P::P[i] & mask);
-      r.l[i] = (u32)c;
-      c >>= 32;
+      u32 co;
+      r.l[i] = __builtin_addc(d[i], (u32)P::P[i] & mask, c, &co);
+      c = co;
     }
     return r;
   }
@@ -198,14 +200,14 @@ struct Fp {
     u32 nz = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) nz |= a.l[i];
-    u32 mask = nz ? 0xffffffffu : 0u;
+    const u32 mask = nz ? 0xffffffffu : 0u;
     Fp r;
     u32 borrow = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      u64 x = (u64)(P::P[i] & mask) - a.l[i] - borrow;
-      r.l[i] = (u32)x;
-      borrow = (u32)(x >> 63);
+      u32 bo;
+      r.l[i] = __builtin_subc((u32)P::P[i] & mask, a.l[i], borrow, &bo);
+      borrow = bo;
     }
     return r;
   }

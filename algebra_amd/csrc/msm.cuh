@@ -27,6 +27,7 @@
 #include <vector>
 #include <mutex>
 #include "curves.cuh"
+#include "msm_sort.cuh"
 
 namespace arkhip {
 
@@ -41,15 +42,14 @@ namespace arkhip {
 
 static constexpr u32 KEY_NONE = 0xffffffffu;
 
-// ---- K1: signed-digit recoding + bucket histogram ---------------------------------------------
+// ---- K1: signed-digit recoding -------------------------------------------------------------------
 template <class SP>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__ scalars, u32 n, int mont, int c,
-                                                         int W, u32* __restrict__ keys, u32* __restrict__ ranks,
-                                                         u32* __restrict__ hist, u32* __restrict__ err) {
+                                                         int W, u32* __restrict__ keys, u32* __restrict__ err) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;  // no early return: the wave-level ballots below need every lane
+  if (i >= n) return;
   typedef Fp<SP> S;
-  S s = live ? S::load(scalars + (size_t)i * S::N) : S::zero();
+  S s = S::load(scalars + (size_t)i * S::N);
   if (mont) s = S::from_mont(s);  // mod.rs:60-62 into_bigint
   // t = r - s ; use it (and negate the point) when t < s
   u32 t[S::N];
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
       carry = 0;
     }
     int d = (int)raw - (int)(carry << c);
-    if (d != 0 && live) {
+    if (d != 0) {
       u32 mag = d < 0 ? (u32)(-d) : (u32)d;
       if (mag > half) {  // only reachable for a scalar >= 2^BITS, which the reference does not accept either
         atomicOr(err, 1u);
@@ -96,35 +96,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
       u32 sign = (d < 0 ? 0x80000000u : 0u) ^ flip;
       key = sign | (mag - 1);
     }
-    // The histogram atomic returns the point's rank inside its bucket, so the scatter needs no second
-    // atomic.  Lanes of the wave that hit the same bucket are combined first (ballot + prefix count):
-    // uniform scalars never collide, but the reference's small-scalar distributions
-    // (bench-templates/src/macros/ec.rs:244-372) put whole waves on one counter.
-    {
-      const u32 bkt = key & 0x7fffffffu;
-      bool pending = key != KEY_NONE;
-      u32 rank = 0;
-      u32* ctr = &hist[((size_t)w << (c - 1)) + (pending ? bkt : 0u)];
-      for (int round = 0; round < 2; round++) {
-        unsigned long long act = __ballot(pending);
-        if (act == 0) break;
-        int leader = __ffsll((long long)act) - 1;
-        u32 lkey = (u32)__shfl((int)bkt, leader);
-        unsigned long long same = __ballot(pending && bkt == lkey);
-        int cnt = __popcll(same);
-        if (cnt < 4) break;  // no real contention: fall through to one atomic per lane
-        u32 base = 0;
-        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(ctr, (u32)cnt);
-        base = (u32)__shfl((int)base, leader);
-        if (pending && bkt == lkey) {
-          rank = base + (u32)__popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
-          pending = false;
-        }
-      }
-      if (pending) rank = atomicAdd(ctr, 1u);
-      if (key != KEY_NONE) ranks[(size_t)w * n + i] = rank;
-    }
-    if (live) keys[(size_t)w * n + i] = key;
+    keys[(size_t)w * n + i] = key;
   }
 }
 
@@ -203,21 +175,6 @@ static __global__ void __launch_bounds__(256) scan_apply(const u32* __restrict__
   }
 }
 
-// ---- K3: scatter point indices into bucket order ------------------------------------------------
-static __global__ void __launch_bounds__(256) msm_scatter_kernel(const u32* __restrict__ keys,
-                                                                 const u32* __restrict__ ranks, u32 n, int c,
-                                                                 const u32* __restrict__ offsets,
-                                                                 u32* __restrict__ sorted) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 w = blockIdx.y;
-  if (i >= n) return;
-  u32 key = keys[(size_t)w * n + i];
-  if (key == KEY_NONE) return;
-  size_t g = ((size_t)w << (c - 1)) + (key & 0x7fffffffu);
-  u32 pos = offsets[g] + ranks[(size_t)w * n + i];
-  sorted[pos] = i | (key & 0x80000000u);
-}
-
 // ---- K3b: bucket processing order, heaviest first -------------------------------------------------
 // Lanes of one wave should own buckets of (nearly) equal load, otherwise the wave runs for its
 // longest bucket (Poisson loads: ~30% of the lanes' time idle at mean 32).  Counting sort of bucket
@@ -225,7 +182,7 @@ static __global__ void __launch_bounds__(256) msm_scatter_kernel(const u32* __re
 // global atomics out of it.
 static constexpr int ORDER_TILE = 2048;
 static constexpr int ORDER_BINS = 256;
-static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* __restrict__ hist, size_t nb, int shift,
+static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* __restrict__ offsets, size_t nb, int shift,
                                                                     u32 nblocks, u32* __restrict__ block_hist) {
   __shared__ u32 sh[ORDER_BINS];
   sh[threadIdx.x] = 0;
@@ -234,7 +191,7 @@ static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* _
   for (int k = 0; k < ORDER_TILE / 256; k++) {
     size_t g = base + threadIdx.x + (size_t)k * 256;
     if (g < nb) {
-      u32 cls = hist[g] >> shift;
+      u32 cls = (offsets[g + 1] - offsets[g]) >> shift;
       if (cls > ORDER_BINS - 1) cls = ORDER_BINS - 1;
       atomicAdd(&sh[ORDER_BINS - 1 - cls], 1u);  // class 0 of the output = heaviest
     }
@@ -242,7 +199,7 @@ static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* _
   __syncthreads();
   block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = sh[threadIdx.x];  // bin-major
 }
-static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32* __restrict__ hist, size_t nb, int shift,
+static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32* __restrict__ offsets, size_t nb, int shift,
                                                                        u32 nblocks, const u32* __restrict__ block_off,
                                                                        u32* __restrict__ order) {
   __shared__ u32 sh[ORDER_BINS];
@@ -252,7 +209,7 @@ static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32
   for (int k = 0; k < ORDER_TILE / 256; k++) {
     size_t g = base + threadIdx.x + (size_t)k * 256;
     if (g < nb) {
-      u32 cls = hist[g] >> shift;
+      u32 cls = (offsets[g + 1] - offsets[g]) >> shift;
       if (cls > ORDER_BINS - 1) cls = ORDER_BINS - 1;
       u32 pos = atomicAdd(&sh[ORDER_BINS - 1 - cls], 1u);
       order[pos] = (u32)g;
@@ -555,13 +512,14 @@ struct DevBuf {
 };
 
 struct MsmWorkspace {
-  DevBuf hctr, hlist, hitems, hpart, lbases, keys, ranks, sorted, hist, offsets, sums, buckets, lvlS[2], lvlA[2], err, order, ohist, ooff;
+  DevBuf hctr, hlist, hitems, hpart, lbases, keys, part, thist, toff, sorted, offsets, sums, buckets, lvlS[2], lvlA[2], err, order, ohist, ooff;
   void* pinned = nullptr;  // host staging for the window sums
   size_t pinned_cap = 0;
   std::mutex mu;
   void release() {
     hctr.release(); hlist.release(); hitems.release(); hpart.release();
-    lbases.release(); keys.release(); ranks.release(); sorted.release(); hist.release(); offsets.release(); sums.release();
+    lbases.release(); keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
+    offsets.release(); sums.release();
     order.release(); ohist.release(); ooff.release();
     buckets.release(); err.release();
     for (int i = 0; i < 2; i++) { lvlS[i].release(); lvlA[i].release(); }
@@ -593,16 +551,23 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   const size_t nb = pl.nb;
   const size_t mwin = (size_t)1 << (c - 1);
 
+  // bucket-id split for the two-pass partition sort (msm_sort.cuh)
+  const int Bbits = c - 1;
+  const int LB = Bbits < PART_LO_BITS ? Bbits : PART_LO_BITS;
+  const int HB = Bbits - LB;
+  const u32 nsuper = (u32)W << HB;
+  const u32 ntiles = (u32)((n + PART_TILE - 1) / PART_TILE);
+  const size_t nthist = (size_t)nsuper * ntiles;
   if (ws.keys.ensure((size_t)W * n * 4)) return -3;
   if (ws.sorted.ensure((size_t)W * n * 4)) return -3;
-  if (ws.hist.ensure(nb * 4)) return -3;
+  if (ws.part.ensure((size_t)W * n * 8)) return -3;
+  if (ws.thist.ensure(nthist * 4) || ws.toff.ensure((nthist + 1) * 4)) return -3;
   if (ws.offsets.ensure((nb + 1) * 4)) return -3;
-  if (ws.ranks.ensure((size_t)W * n * 4)) return -3;
-  const u32 nscan = (u32)((nb + SCAN_TILE - 1) / SCAN_TILE);
+  const u32 ntscan = (u32)((nthist + SCAN_TILE - 1) / SCAN_TILE);
   const u32 noblk = (u32)((nb + ORDER_TILE - 1) / ORDER_TILE);
   const size_t nohist = (size_t)noblk * ORDER_BINS;
   const u32 noscan = (u32)((nohist + SCAN_TILE - 1) / SCAN_TILE);
-  if (ws.sums.ensure((size_t)(nscan > noscan ? nscan : noscan) * 4)) return -3;
+  if (ws.sums.ensure((size_t)(ntscan > noscan ? ntscan : noscan) * 4)) return -3;
   if (ws.order.ensure(nb * 4) || ws.ohist.ensure(nohist * 4) || ws.ooff.ensure((nohist + 1) * 4)) return -3;
   if (ws.buckets.ensure(nb * Pt::BYTES)) return -3;
   if (ws.pinned_cap < (size_t)W * Pt::BYTES + 64) {
@@ -621,9 +586,10 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
 
   u32* keys = (u32*)ws.keys.p;
   u32* sorted = (u32*)ws.sorted.p;
-  u32* hist = (u32*)ws.hist.p;
   u32* offsets = (u32*)ws.offsets.p;
-  u32* ranks = (u32*)ws.ranks.p;
+  u32* thist = (u32*)ws.thist.p;
+  u32* toff = (u32*)ws.toff.p;
+  uint2* part = (uint2*)ws.part.p;
   u32* order = (u32*)ws.order.p;
   u32* sums = (u32*)ws.sums.p;
 
@@ -638,30 +604,47 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
       ws.hpart.ensure(max_items * Pt::BYTES))
     return -3;
   ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 8, stream));
-  ARK_HIP_TRY(hipMemsetAsync(hist, 0, nb * 4, stream));
   ARK_HIP_TRY(hipMemsetAsync(ws.err.p, 0, 4, stream));
   const u32 nblk = (u32)((n + 255) / 256);
   hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
-                     (u32)n, scalars_mont, c, W, keys, ranks, hist, (u32*)ws.err.p);
+                     (u32)n, scalars_mont, c, W, keys, (u32*)ws.err.p);
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL(scan_block_sums, dim3(nscan), dim3(256), 0, stream, hist, nb, sums);
-  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, nscan);
-  hipLaunchKernelGGL(scan_apply, dim3(nscan), dim3(256), 0, stream, hist, nb, sums, offsets);
+  // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
+  hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
+                     ntiles, thist);
+  hipLaunchKernelGGL(scan_block_sums, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums);
+  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, ntscan);
+  hipLaunchKernelGGL(scan_apply, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums, toff);
+  if (tm) ARK_HIP_TRY(hipEventRecord(ev[2], stream));
   {
-    // load classes: width 2^shift so that the mean load falls around class 32..63
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
+    const size_t lds_a = ((size_t)8 << HB) + (size_t)PART_TILE * 8;
+    const size_t lds_b = ((size_t)(1 << PART_LO_BITS) + 1024 + PART_STAGE) * 4;
+    if (!attr_set) {
+      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 4096 - 64));
+      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 64));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, W), dim3(1024), lds_a, stream, keys, (u32)n, HB, LB, ntiles,
+                       toff, part);
+    hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper), dim3(1024), lds_b, stream, part, toff, ntiles, LB, nsuper,
+                       offsets, sorted);
+  }
+  {
+    // processing order, heaviest load class first; class width 2^shift so that the mean falls around class 32..63
     size_t mean = ((size_t)n * W) / nb;
     int shift = 0;
     while ((mean >> shift) >= 64) shift++;
     u32* ohist = (u32*)ws.ohist.p;
     u32* ooff = (u32*)ws.ooff.p;
-    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk), dim3(256), 0, stream, hist, nb, shift, noblk, ohist);
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nb, shift, noblk, ohist);
     hipLaunchKernelGGL(scan_block_sums, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums);
     hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, noscan);
     hipLaunchKernelGGL(scan_apply, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums, ooff);
-    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk), dim3(256), 0, stream, hist, nb, shift, noblk, ooff, order);
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nb, shift, noblk, ooff, order);
   }
-  if (tm) ARK_HIP_TRY(hipEventRecord(ev[2], stream));
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk, W), dim3(256), 0, stream, keys, ranks, (u32)n, c, offsets, sorted);
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[3], stream));
   if constexpr (C::LAZY) {
     typedef FpLazy<typename F::P> LZ;

@@ -22,7 +22,7 @@
 namespace arkhip {
 
 static constexpr int PART_LO_BITS = 10;        // buckets per super-bucket = 2^10
-static constexpr int PART_TILE = 16384;        // keys per workgroup in pass A (256 lanes x 64)
+static constexpr int PART_TILE = 8192;         // keys per workgroup in pass A (64 KiB of staged pairs)
 static constexpr u32 PART_KEY_NONE = 0xffffffffu;
 
 // A1: per-workgroup histogram over the high bits.  grid = (tiles, W); dynamic LDS = 4 << HB bytes.
@@ -46,55 +46,37 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
     tile_hist[((size_t)((w << HB) | b)) * ntiles + blockIdx.x] = part_lds[b];
 }
 
-// A2: same sweep; LDS cursors start at the scanned (super-bucket, tile) offsets.
-static __global__ void __launch_bounds__(256) msm_part_scatter_kernel(const u32* __restrict__ keys, u32 n, int HB, int LB,
-                                                                      u32 ntiles, const u32* __restrict__ tile_off,
-                                                                      uint2* __restrict__ part) {
+// A2: second sweep over the same tile.  Pairs are staged in LDS grouped by super-bucket and then written
+// out in order, so that each (super-bucket, tile) run leaves as contiguous 8-byte elements.
+// dynamic LDS: (2 << HB) counters + PART_TILE pairs.
+static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32* __restrict__ keys, u32 n, int HB,
+                                                                       int LB, u32 ntiles,
+                                                                       const u32* __restrict__ tile_off,
+                                                                       uint2* __restrict__ part) {
   extern __shared__ u32 part_lds[];
   const u32 nbins = 1u << HB;
+  u32* cnt = part_lds;                       // per-bin count, then local cursor
+  u32* lstart = part_lds + nbins;            // per-bin start inside the staging area
+  uint2* stage = (uint2*)(part_lds + 2 * nbins);
+  __shared__ u32 wsum[1024];
   const u32 w = blockIdx.y;
-  for (u32 b = threadIdx.x; b < nbins; b += blockDim.x)
-    part_lds[b] = tile_off[((size_t)((w << HB) | b)) * ntiles + blockIdx.x];
-  __syncthreads();
   const size_t base = (size_t)w * n;
   const u32 lo = blockIdx.x * PART_TILE;
   const u32 hi = lo + PART_TILE < n ? lo + PART_TILE : n;
   const u32 lmask = (1u << LB) - 1u;
+  for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) cnt[b] = 0;
+  __syncthreads();
   for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     u32 key = keys[base + i];
-    if (key != PART_KEY_NONE) {
-      u32 bkt = key & 0x7fffffffu;
-      u32 pos = atomicAdd(&part_lds[bkt >> LB], 1u);
-      part[pos] = make_uint2((bkt & lmask) | (key & 0x80000000u), i);
-    }
+    if (key != PART_KEY_NONE) atomicAdd(&cnt[(key & 0x7fffffffu) >> LB], 1u);
   }
-}
-
-// B: one workgroup per super-bucket sb = (w << HB | hb): buckets g = sb << LB | low.
-static __global__ void __launch_bounds__(256) msm_part_finish_kernel(const uint2* __restrict__ part,
-                                                                     const u32* __restrict__ tile_off, u32 ntiles,
-                                                                     int LB, u32 nsuper, u32* __restrict__ offsets,
-                                                                     u32* __restrict__ sorted) {
-  __shared__ u32 cnt[1 << PART_LO_BITS];
-  __shared__ u32 wsum[256];
-  const u32 sb = blockIdx.x;
-  const u32 nlow = 1u << LB;
-  const u32 start = tile_off[(size_t)sb * ntiles];
-  const u32 end = tile_off[(size_t)(sb + 1) * ntiles];  // tile_off has nsuper * ntiles + 1 entries
-  for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
-  const u32 lmask = nlow - 1u;
-  for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&cnt[part[j].x & lmask], 1u);
-  __syncthreads();
-  // exclusive scan of cnt[0..nlow) with 256 lanes: each lane owns nlow/256 consecutive bins (>= 1 when LB >= 8)
-  const u32 per = (nlow + blockDim.x - 1) / blockDim.x;
-  u32 local[4];  // per <= 4 for LB <= 10
+  // exclusive scan of cnt[0..nbins) -> lstart ; cnt becomes the cursor
+  const u32 per = (nbins + blockDim.x - 1) / blockDim.x;
   u32 s = 0;
   for (u32 k = 0; k < per; k++) {
     u32 b = threadIdx.x * per + k;
-    u32 v = b < nlow ? cnt[b] : 0;
-    local[k] = s;
-    s += v;
+    if (b < nbins) s += cnt[b];
   }
   wsum[threadIdx.x] = s;
   __syncthreads();
@@ -104,21 +86,89 @@ static __global__ void __launch_bounds__(256) msm_part_finish_kernel(const uint2
     wsum[threadIdx.x] += y;
     __syncthreads();
   }
-  const u32 lane_base = start + wsum[threadIdx.x] - s;
+  u32 run = wsum[threadIdx.x] - s;
   for (u32 k = 0; k < per; k++) {
     u32 b = threadIdx.x * per + k;
-    if (b < nlow) {
-      u32 off = lane_base + local[k];
-      cnt[b] = off;                                     // becomes the placement cursor
-      offsets[((size_t)sb << LB) + b] = off;
+    if (b < nbins) {
+      u32 v = cnt[b];
+      lstart[b] = run;
+      cnt[b] = run;
+      run += v;
     }
+  }
+  __syncthreads();
+  const u32 total = wsum[blockDim.x - 1];
+  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 key = keys[base + i];
+    if (key != PART_KEY_NONE) {
+      u32 bkt = key & 0x7fffffffu;
+      u32 pos = atomicAdd(&cnt[bkt >> LB], 1u);
+      stage[pos] = make_uint2(bkt | (key & 0x80000000u), i);   // full bucket id kept: the bin is re-derived below
+    }
+  }
+  __syncthreads();
+  for (u32 j = threadIdx.x; j < total; j += blockDim.x) {
+    uint2 e = stage[j];
+    u32 bkt = e.x & 0x7fffffffu;
+    u32 bin = bkt >> LB;
+    u32 dst = tile_off[((size_t)((w << HB) | bin)) * ntiles + blockIdx.x] + (j - lstart[bin]);
+    part[dst] = make_uint2((bkt & lmask) | (e.x & 0x80000000u), e.y);
+  }
+}
+
+// B: one workgroup per super-bucket sb = (w << HB | hb): buckets g = sb << LB | low.  The sorted indices
+// of the super-bucket are assembled in LDS and written out linearly; a super-bucket larger than the
+// staging area (skewed scalars) falls back to direct placement.
+static constexpr u32 PART_STAGE = 36864;  // u32 entries of staging: 144 KiB
+static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint2* __restrict__ part,
+                                                                      const u32* __restrict__ tile_off, u32 ntiles,
+                                                                      int LB, u32 nsuper, u32* __restrict__ offsets,
+                                                                      u32* __restrict__ sorted) {
+  extern __shared__ u32 part_lds[];
+  u32* cnt = part_lds;                         // [1 << PART_LO_BITS]
+  u32* wsum = part_lds + (1 << PART_LO_BITS);  // [1024]
+  u32* stage = wsum + 1024;                    // [PART_STAGE]
+  const u32 sb = blockIdx.x;
+  const u32 nlow = 1u << LB;
+  const u32 start = tile_off[(size_t)sb * ntiles];
+  const u32 end = tile_off[(size_t)(sb + 1) * ntiles];  // tile_off has nsuper * ntiles + 1 entries
+  for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
+  __syncthreads();
+  const u32 lmask = nlow - 1u;
+  for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&cnt[part[j].x & lmask], 1u);
+  __syncthreads();
+  // exclusive scan of cnt[0..nlow): lane t owns bin t (nlow <= 1024 = blockDim)
+  u32 v = threadIdx.x < nlow ? cnt[threadIdx.x] : 0;
+  wsum[threadIdx.x] = v;
+  __syncthreads();
+  for (u32 o = 1; o < blockDim.x; o <<= 1) {
+    u32 y = threadIdx.x >= o ? wsum[threadIdx.x - o] : 0;
+    __syncthreads();
+    wsum[threadIdx.x] += y;
+    __syncthreads();
+  }
+  const u32 excl = wsum[threadIdx.x] - v;
+  if (threadIdx.x < nlow) {
+    cnt[threadIdx.x] = excl;  // local placement cursor
+    offsets[((size_t)sb << LB) + threadIdx.x] = start + excl;
   }
   if (sb == nsuper - 1 && threadIdx.x == 0) offsets[(size_t)nsuper << LB] = end;
   __syncthreads();
-  for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) {
-    uint2 e = part[j];
-    u32 pos = atomicAdd(&cnt[e.x & lmask], 1u);
-    sorted[pos] = e.y | (e.x & 0x80000000u);
+  const u32 total = end - start;
+  if (total <= PART_STAGE) {
+    for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) {
+      uint2 e = part[j];
+      u32 pos = atomicAdd(&cnt[e.x & lmask], 1u);
+      stage[pos] = e.y | (e.x & 0x80000000u);
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < total; j += blockDim.x) sorted[start + j] = stage[j];
+  } else {
+    for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) {
+      uint2 e = part[j];
+      u32 pos = atomicAdd(&cnt[e.x & lmask], 1u);
+      sorted[start + pos] = e.y | (e.x & 0x80000000u);
+    }
   }
 }
 
