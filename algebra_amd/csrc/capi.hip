@@ -319,7 +319,7 @@ int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars,
   MsmTimings* tm = c->msm_timing ? &c->msm_tm : nullptr;
   rc = msm_dispatch(curve, c->msm, d_bases, d_scalars, n, mont, out_xyz, c->stream, tm);
   if (rc == 0 && tm) {
-    MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve));
+    MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve));
     c->msm_c = pl.c;
     c->msm_W = pl.W;
   }

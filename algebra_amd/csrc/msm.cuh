@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restr
                                                              const u32* __restrict__ sorted,
                                                              const u32* __restrict__ offsets,
                                                              const u32* __restrict__ order, u32 nbuckets,
-                                                             u32 heavy_thresh, char* __restrict__ buckets) {
+                                                             u32 heavy_thresh, int HB, int LB,
+                                                             char* __restrict__ buckets) {
   typedef typename C::F F;
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nbuckets) return;
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restr
       j++;
     }
   }
-  acc.store(buckets + (size_t)g * XYZZ<F>::BYTES);
+  acc.store(buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES);  // g is a slot (msm_sort.cuh)
 }
 
 // ---- K4h: heavy buckets --------------------------------------------------------------------------
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
 template <class C>
 __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __restrict__ ctr,
                                                                const HeavyEntry* __restrict__ list,
-                                                               const char* __restrict__ partials,
+                                                               const char* __restrict__ partials, int HB, int LB,
                                                                char* __restrict__ buckets) {
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __rest
     Pt x = Pt::load(partials + (size_t)(h.first_item + q) * Pt::BYTES);
     xyzz_add<F>(acc, x);
   }
-  acc.store(buckets + (size_t)h.bucket * Pt::BYTES);
+  acc.store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
 }
 
 // ---- K4 (lazy form): base conversion pre-pass + bucket accumulation in 28-bit limbs -------------------
@@ -374,7 +375,8 @@ __global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const u32* __r
                                                                   const u32* __restrict__ sorted,
                                                                   const u32* __restrict__ offsets,
                                                                   const u32* __restrict__ order, u32 nbuckets,
-                                                                  u32 heavy_thresh, char* __restrict__ buckets) {
+                                                                  u32 heavy_thresh, int HB, int LB,
+                                                                  char* __restrict__ buckets) {
   typedef typename C::F F;
   typedef typename F::P P;
   typedef FpLazy<P> LZ;
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const u32* __r
       j++;
     }
   }
-  xyzz_from_lazy<P>(acc).store(buckets + (size_t)g * XYZZ<F>::BYTES);
+  xyzz_from_lazy<P>(acc).store(buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES);
 }
 
 // ---- K5: one level of the bucket reduction ---------------------------------------------------------
@@ -456,6 +458,8 @@ struct MsmPlan {
   size_t nb;      // buckets over all windows = W << (c-1)
 };
 
+// relative cost of one base-field product (Fp384 = 1): Fp256 ~0.5, Fp2 over Fp384 ~3.3
+static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 3.3 : 1.0); }
 static inline int msm_scalar_bits(int curve_id) {
   switch (curve_id) {
     case 0: return BN254_FR::BITS;
@@ -464,19 +468,31 @@ static inline int msm_scalar_bits(int curve_id) {
   }
 }
 
-// window size: minimise  n*W*(mixed add) + W*2^(c-1)*(~2.3 full adds)   [muls: 10 vs 14 each]
-static inline MsmPlan msm_make_plan(size_t n, int bits) {
+// Window size.  Model (seconds) of the phases that depend on c, from this chip's measured rates
+// (profiles/): mixed additions stream at ~5.5e9/s (Fp384; scaled by `mul_cost` for other fields) but a
+// single bucket is a serial chain (~14 us per addition on a lightly loaded SIMD), the first reduction
+// level costs 2 full additions per bucket, every further level ~0.4 ms of latency.
+static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost = 1.0) {
   int best_c = 2;
   double best = 1e300;
   const char* env = getenv("ARK_HIP_MSM_C");
   if (env && atoi(env) >= 2 && atoi(env) <= 24) {
     best_c = atoi(env);
   } else {
-    for (int c = 2; c <= 22; c++) {
-      int W = (bits + 1 + c - 1) / c;
-      double cost = (double)n * W * 10.0 * 1.35 + (double)W * (double)(1u << (c - 1)) * 2.3 * 14.0;
-      // upper reduction levels are latency-bound: ~12 serial full additions per 2 bits of bucket index
-      cost += (double)(c - 1) * 6.0 * 14.0 * 65536.0;
+    for (int c = 2; c <= 23; c++) {
+      const int W = (bits + 1 + c - 1) / c;
+      const double nbk = (double)W * (double)(1u << (c - 1));
+      const double entries = (double)n * W;
+      const double madd = 1.0 / 5.5e9 * mul_cost, fadd = 1.4 / 5.5e9 * mul_cost;
+      double acc = entries * madd;
+      const double chain = (entries / nbk) * 14e-6 * mul_cost;  // one lane walks one bucket
+      if (chain > acc) acc = chain;
+      double red0 = nbk * 2.0 * fadd;
+      const double red0_lat = 2.0 * 8.0 * 21e-6 * mul_cost;     // >= 8 buckets per lane at level 0
+      if (red0_lat > red0) red0 = red0_lat;
+      const int upper = c - 1 > 5 ? (c - 1 - 5 + 1) / 2 : 0;    // levels of 4 after a level of 32
+      const double sort = entries * 2.0e-11 + nbk * 1.0e-10;
+      const double cost = acc + red0 + upper * 0.4e-3 * mul_cost + sort;
       if (cost < best) { best = cost; best_c = c; }
     }
   }
@@ -546,7 +562,7 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
     return 0;
   }
   if (n >= (1ull << 31)) return -2;
-  const MsmPlan pl = msm_make_plan(n, C::S::BITS);
+  const MsmPlan pl = msm_make_plan(n, C::S::BITS, msm_mul_cost(C::ID));
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;
   const size_t mwin = (size_t)1 << (c - 1);
@@ -597,7 +613,10 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   // heavy buckets: load above max(2048, 16 x mean)
   const size_t total_entries = (size_t)n * W;
   size_t mean_load = total_entries / nb;
-  const u32 heavy_thresh = (u32)(mean_load * 16 > 2048 ? mean_load * 16 : 2048);
+  u32 heavy_thresh = (u32)(mean_load * 16 > 2048 ? mean_load * 16 : 2048);
+  if (const char* hv = getenv("ARK_HIP_MSM_HEAVY")) {
+    if (atoi(hv) >= 64) heavy_thresh = (u32)atoi(hv);
+  }
   const size_t max_heavy = total_entries / heavy_thresh + 1;
   const size_t max_items = total_entries / HEAVY_CHUNK + max_heavy + 1;
   if (ws.hctr.ensure(16) || ws.hlist.ensure(max_heavy * sizeof(HeavyEntry)) || ws.hitems.ensure(max_items * 8) ||
@@ -652,10 +671,10 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
     hipLaunchKernelGGL((msm_bases_to_lazy_kernel<C>), dim3(nblk), dim3(256), 0, stream, (const char*)d_bases, (u32)n,
                        (u32*)ws.lbases.p);
     hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
-                       (const u32*)ws.lbases.p, sorted, offsets, order, (u32)nb, heavy_thresh, (char*)ws.buckets.p);
+                       (const u32*)ws.lbases.p, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
   } else {
     hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
-                       (const char*)d_bases, sorted, offsets, order, (u32)nb, heavy_thresh, (char*)ws.buckets.p);
+                       (const char*)d_bases, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
   }
   {
     u32* hctr = (u32*)ws.hctr.p;
@@ -665,7 +684,7 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
     hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), hthreads * Pt::BYTES, stream,
                        (const char*)d_bases, sorted, offsets, hctr, (const uint2*)ws.hitems.p, (char*)ws.hpart.p);
     hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3((u32)((max_heavy + 63) / 64)), dim3(64), 0, stream, hctr,
-                       (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, (char*)ws.buckets.p);
+                       (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, (char*)ws.buckets.p);
   }
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[4], stream));
 

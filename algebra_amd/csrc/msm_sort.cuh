@@ -10,8 +10,13 @@
 //           L2 resident): LDS histogram of the LOW bits, LDS scan -> bucket offsets, then places the
 //           point indices.  Wave-level work only, no cross-workgroup communication.
 //
-// Output is exactly what the accumulate kernels consume: `sorted` (point index, sign in bit 31, grouped
-// by global bucket id) and `offsets` (exclusive prefix sums of the bucket loads, nb + 1 entries).
+// The super-bucket is taken from the LOW bits of the bucket id and pass B sorts by the HIGH bits: signed
+// digits are uniform in their low bits even in the top window (whose high bits are mostly zero), so all
+// super-buckets carry the same load.  The price is that buckets come out in a permuted order, "slots":
+//     slot = (w << B) | (low HB bits << LB) | (high LB bits),   B = c-1 = HB + LB
+// `sorted` (point index, sign in bit 31) is grouped by slot and `offsets` (nb + 1 exclusive prefix sums)
+// is indexed by slot; msm_slot_to_bucket() gives the true bucket id where the weights matter (the store
+// of the accumulated bucket).
 // The order of the points inside a bucket is unspecified -- it only changes the Projective representative,
 // never the group element.  (Role in the reference: none -- the CPU walks scalars and adds into
 // `buckets[|digit|-1]` directly, ec/src/scalar_mul/variable_base/mod.rs:464-475.)
@@ -25,11 +30,22 @@ static constexpr int PART_LO_BITS = 10;        // buckets per super-bucket = 2^1
 static constexpr int PART_TILE = 8192;         // keys per workgroup in pass A (64 KiB of staged pairs)
 static constexpr u32 PART_KEY_NONE = 0xffffffffu;
 
+// slot index (sort order) -> bucket index (window-major, weight order)
+__host__ __device__ __forceinline__ u32 msm_slot_to_bucket(u32 slot, int HB, int LB) {
+  const u32 B = (u32)(HB + LB);
+  const u32 w = slot >> B;
+  const u32 in = slot & ((1u << B) - 1u);
+  const u32 low = in >> LB;                    // low HB bits of the bucket id
+  const u32 high = in & ((1u << LB) - 1u);     // high LB bits
+  return (w << B) | (high << HB) | low;
+}
+
 // A1: per-workgroup histogram over the high bits.  grid = (tiles, W); dynamic LDS = 4 << HB bytes.
 static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __restrict__ keys, u32 n, int HB, int LB,
                                                                    u32 ntiles, u32* __restrict__ tile_hist) {
   extern __shared__ u32 part_lds[];
   const u32 nbins = 1u << HB;
+  const u32 hmask = nbins - 1u;  // super-bucket = LOW HB bits of the bucket id (see header)
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) part_lds[b] = 0;
   __syncthreads();
   const u32 w = blockIdx.y;
@@ -38,7 +54,7 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
   const u32 hi = lo + PART_TILE < n ? lo + PART_TILE : n;
   for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     u32 key = keys[base + i];
-    if (key != PART_KEY_NONE) atomicAdd(&part_lds[(key & 0x7fffffffu) >> LB], 1u);
+    if (key != PART_KEY_NONE) atomicAdd(&part_lds[key & hmask], 1u);
   }
   __syncthreads();
   // bin-major: [(w << HB | bin)][tile]
@@ -63,12 +79,12 @@ static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32
   const size_t base = (size_t)w * n;
   const u32 lo = blockIdx.x * PART_TILE;
   const u32 hi = lo + PART_TILE < n ? lo + PART_TILE : n;
-  const u32 lmask = (1u << LB) - 1u;
+  const u32 hmask = nbins - 1u;
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
   for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     u32 key = keys[base + i];
-    if (key != PART_KEY_NONE) atomicAdd(&cnt[(key & 0x7fffffffu) >> LB], 1u);
+    if (key != PART_KEY_NONE) atomicAdd(&cnt[key & hmask], 1u);
   }
   __syncthreads();
   // exclusive scan of cnt[0..nbins) -> lstart ; cnt becomes the cursor
@@ -101,22 +117,21 @@ static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32
   for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     u32 key = keys[base + i];
     if (key != PART_KEY_NONE) {
-      u32 bkt = key & 0x7fffffffu;
-      u32 pos = atomicAdd(&cnt[bkt >> LB], 1u);
-      stage[pos] = make_uint2(bkt | (key & 0x80000000u), i);   // full bucket id kept: the bin is re-derived below
+      u32 pos = atomicAdd(&cnt[key & hmask], 1u);
+      stage[pos] = make_uint2(key, i);   // full key kept: the bin is re-derived below
     }
   }
   __syncthreads();
   for (u32 j = threadIdx.x; j < total; j += blockDim.x) {
     uint2 e = stage[j];
     u32 bkt = e.x & 0x7fffffffu;
-    u32 bin = bkt >> LB;
+    u32 bin = bkt & hmask;
     u32 dst = tile_off[((size_t)((w << HB) | bin)) * ntiles + blockIdx.x] + (j - lstart[bin]);
-    part[dst] = make_uint2((bkt & lmask) | (e.x & 0x80000000u), e.y);
+    part[dst] = make_uint2((bkt >> HB) | (e.x & 0x80000000u), e.y);   // remaining (high) bits, < 2^LB
   }
 }
 
-// B: one workgroup per super-bucket sb = (w << HB | hb): buckets g = sb << LB | low.  The sorted indices
+// B: one workgroup per super-bucket sb = (w << HB | low bits): bucket SLOTS sb << LB | high bits.  The sorted indices
 // of the super-bucket are assembled in LDS and written out linearly; a super-bucket larger than the
 // staging area (skewed scalars) falls back to direct placement.
 static constexpr u32 PART_STAGE = 36864;  // u32 entries of staging: 144 KiB

@@ -37,6 +37,22 @@ R_MOD = 524358751751261904794477405081859658376905525005276378226036586999385811
 A0 = 0xA11CE + (1 << 64) + (2 << 128)
 B0 = 0xB0B + (3 << 64)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+FP384_MUL_PEAK = 59.9e9  # measured ceiling of the Montgomery product sequence (ubench/mulbench.hip), products/s
+
+
+def pmc_traffic(kernel, log_n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json,
+    produced by tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE collected in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes).  None when no matching measurement is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            d = json.load(f)
+        e = d.get(kernel)
+        if e and e.get("log_n") == log_n:
+            return e.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def limbs4(v):
@@ -231,8 +247,10 @@ def main():
             "value": nf / (fft_ms * 1e-3), "unit": "elements/s", "ms_per_step": fft_ms,
             "device_ms": dev_ms, "passes": [ft[2 + i] for i in range(int(ft[1]))],
             "ifft_fft_roundtrip_exact": roundtrip_ok,
-            "roofline": {"bound": "hbm", "achieved": 64.0 * nf / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": 64.0 * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None},
+            "roofline": {"bound": "hbm", "kernel": "fft_pass_kernel (x%d passes)" % int(ft[1]),
+                         "achieved": 64.0 * nf / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": 64.0 * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic("fft_pass_kernel", kf)},
         }
 
     # ---- CPU baseline: the oracle's msm_bigint_wnaf restatement on the host cores, bounded sample ---
@@ -276,8 +294,13 @@ def main():
             "phases_ms": {"digits": phases[0], "scan": phases[1], "scatter": phases[2], "accumulate": phases[3],
                           "reduce": phases[4], "device_total": phases[5]},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "note": "MSM is integer-ALU bound: see DESIGN.md for the mul-throughput fraction"},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic("msm_accumulate_kernel", args.log_n),
+                         "alu": {"what": "Fp384 products/s in the accumulate kernel (10 per mixed addition) vs the "
+                                         "measured ceiling of the multiply sequence",
+                                 "achieved": 10.0 * n * phases[7] / (acc_avg_ms * 1e-3), "peak": FP384_MUL_PEAK,
+                                 "frac": 10.0 * n * phases[7] / (acc_avg_ms * 1e-3) / FP384_MUL_PEAK},
+                         "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
             "cpu_baseline": cpu,
             "fft": fft,
         }

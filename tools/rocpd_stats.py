@@ -24,12 +24,28 @@ def table(c, where, title):
     print()
 
 
+def pmc_table(c, min_ns):
+    """per-kernel sums of every collected hardware counter (rocprofv3 --pmc), launches >= min duration"""
+    rows = c.execute("select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration)/1e6 "
+                     "from counters_collection where duration >= %d group by kernel_name, counter_name "
+                     "order by 4 desc" % min_ns).fetchall()
+    print("## hardware counters per kernel (launches >= %.0f us)" % (min_ns / 1000))
+    print("%-64s %-14s %6s %16s %16s %10s" % ("kernel", "counter", "calls", "sum", "avg/launch", "avg_ms"))
+    for r in rows:
+        print("%-64s %-14s %6d %16.1f %16.1f %10.4f" % (r[0][:64], r[1], r[2], r[3], r[4], r[5]))
+    print()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
     ap.add_argument("--min-us", type=float, default=1000.0)
+    ap.add_argument("--pmc", action="store_true", help="database comes from a --pmc run: print counter sums")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
+    if a.pmc:
+        pmc_table(c, int(a.min_us * 1000))
+        return
     table(c, "", "all kernel launches")
     table(c, "where (end-start) >= %d" % int(a.min_us * 1000), "launches >= %.0f us (the timed full-size steps)" % a.min_us)
 
