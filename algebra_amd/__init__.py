@@ -11,5 +11,6 @@ include/ark_hip.h; this package holds no arithmetic and no CPU fallback.
 """
 from . import curves  # noqa: F401
 from ._lib import ArkHipError, LIB_PATH, lib  # noqa: F401
-from .msm import MsmLengthMismatch, into_affine, msm, msm_bigint, msm_unchecked, sum_projective  # noqa: F401
+from .msm import (ChunkedPippenger, MsmLengthMismatch, into_affine, msm, msm_bigint, msm_unchecked,  # noqa: F401
+                  sum_projective)
 from .domain import Radix2EvaluationDomain  # noqa: F401

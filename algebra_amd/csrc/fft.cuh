@@ -26,7 +26,7 @@
 
 namespace arkhip {
 
-static constexpr int FFT_LANE_BITS = 3;    // 8 adjacent elements = 256 B segments
+static constexpr int FFT_LANE_BITS = 2;    // 4 adjacent elements = 128 B segments (tile 2^(8+2) x 32 B = 32 KiB LDS: 4 workgroups per CU)
 static constexpr int FFT_MAX_KP = 8;       // stages per pass
 static constexpr int FFT_SINGLE_MAX = 10;  // whole transform in one workgroup up to 2^10
 static constexpr int PW_LO_BITS = 10;      // two-level power tables: h^i = hi[i >> 10] * lo[i & 1023]
@@ -391,6 +391,8 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     int base = k / P, rem = k % P;
     for (int i = 0; i < P; i++) kps[i] = base + (i < rem ? 1 : 0);
     t = FFT_LANE_BITS;
+    const char* envt = getenv("ARK_HIP_FFT_T");  // tuning knob: log2 of adjacent columns per tile (2 or 3)
+    if (envt && atoi(envt) >= 2 && atoi(envt) <= 3) t = atoi(envt);
   }
   u32* data = (u32*)d_data;
   u32* tmp = nullptr;

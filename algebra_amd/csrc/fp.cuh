@@ -33,6 +33,10 @@ struct Acc96 { u64 lo; u32 hi; };
 #define ARK_MAC2 ARK_MAC "\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
 #define ARK_MAC3 ARK_MAC2 "\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
 #define ARK_MAC4 ARK_MAC3 "\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+#define ARK_MAC5 ARK_MAC4 "\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+#define ARK_MAC6 ARK_MAC5 "\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+#define ARK_MAC7 ARK_MAC6 "\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+#define ARK_MAC8 ARK_MAC7 "\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
 
 ARK_DEV void mac_vv(Acc96& c, u32 a0, u32 b0) {
   asm(ARK_MAC : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "v"(b0) : "vcc");
@@ -42,6 +46,22 @@ ARK_DEV void mac_vv2(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1) {
 }
 ARK_DEV void mac_vv4(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3) {
   asm(ARK_MAC4 : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3) : "vcc");
+}
+// eight products per statement: hipcc pads every asm statement boundary with an s_nop, so longer
+// statements mean fewer wait states in the multiply (61 -> ~35 per Fp384 product)
+ARK_DEV void mac_vv8(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3, u32 a4, u32 b4, u32 a5,
+                     u32 b5, u32 a6, u32 b6, u32 a7, u32 b7) {
+  asm(ARK_MAC8 : "+v"(c.lo), "+v"(c.hi)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
+        "v"(a6), "v"(b6), "v"(a7), "v"(b7)
+      : "vcc");
+}
+ARK_DEV void mac_vs8(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3, u32 a4, u32 b4, u32 a5,
+                     u32 b5, u32 a6, u32 b6, u32 a7, u32 b7) {
+  asm(ARK_MAC8 : "+v"(c.lo), "+v"(c.hi)
+      : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5),
+        "v"(a6), "s"(b6), "v"(a7), "s"(b7)
+      : "vcc");
 }
 // second operand wave-uniform (modulus limb) -> SGPR
 ARK_DEV void mac_vs(Acc96& c, u32 a0, u32 b0) {
@@ -61,7 +81,11 @@ template <class P, int I> struct PL { static constexpr u32 v = P::P[I]; };
 // c += sum_{i=LO..HI} x[i] * y[K-i]   (both operands in VGPRs)
 template <int LO, int HI, int K>
 ARK_DEV void col_vv(Acc96& c, const u32* x, const u32* y) {
-  if constexpr (HI - LO + 1 >= 4) {
+  if constexpr (HI - LO + 1 >= 8) {
+    mac_vv8(c, x[LO], y[K - LO], x[LO + 1], y[K - LO - 1], x[LO + 2], y[K - LO - 2], x[LO + 3], y[K - LO - 3], x[LO + 4],
+            y[K - LO - 4], x[LO + 5], y[K - LO - 5], x[LO + 6], y[K - LO - 6], x[LO + 7], y[K - LO - 7]);
+    col_vv<LO + 8, HI, K>(c, x, y);
+  } else if constexpr (HI - LO + 1 >= 4) {
     mac_vv4(c, x[LO], y[K - LO], x[LO + 1], y[K - LO - 1], x[LO + 2], y[K - LO - 2], x[LO + 3], y[K - LO - 3]);
     col_vv<LO + 4, HI, K>(c, x, y);
   } else if constexpr (HI - LO + 1 >= 2) {
@@ -74,7 +98,12 @@ ARK_DEV void col_vv(Acc96& c, const u32* x, const u32* y) {
 // c += sum_{i=LO..HI} m[i] * p[K-i]   (p = modulus, SGPR operands)
 template <class P, int LO, int HI, int K>
 ARK_DEV void col_vp(Acc96& c, const u32* m) {
-  if constexpr (HI - LO + 1 >= 4) {
+  if constexpr (HI - LO + 1 >= 8) {
+    mac_vs8(c, m[LO], PL<P, K - LO>::v, m[LO + 1], PL<P, K - LO - 1>::v, m[LO + 2], PL<P, K - LO - 2>::v, m[LO + 3],
+            PL<P, K - LO - 3>::v, m[LO + 4], PL<P, K - LO - 4>::v, m[LO + 5], PL<P, K - LO - 5>::v, m[LO + 6],
+            PL<P, K - LO - 6>::v, m[LO + 7], PL<P, K - LO - 7>::v);
+    col_vp<P, LO + 8, HI, K>(c, m);
+  } else if constexpr (HI - LO + 1 >= 4) {
     mac_vs4(c, m[LO], PL<P, K - LO>::v, m[LO + 1], PL<P, K - LO - 1>::v, m[LO + 2], PL<P, K - LO - 2>::v, m[LO + 3],
             PL<P, K - LO - 3>::v);
     col_vp<P, LO + 4, HI, K>(c, m);

@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restr
 // A bucket far above the mean load (non-uniform scalars: the reference's bool / u8 / ... benches, or
 // many equal scalars) would pin one lane for its whole length.  Buckets above `thresh` are skipped by
 // the lane-per-bucket kernel, cut into chunks of HEAVY_CHUNK entries, each chunk summed by one
-// workgroup (256 lanes striding + LDS tree), and the chunk partials combined per bucket.
-static constexpr u32 HEAVY_CHUNK = 16384;
+// wave (64 lanes striding + LDS tree), and the chunk partials combined per bucket.
+static constexpr u32 HEAVY_CHUNK = 2048;
 struct HeavyEntry { u32 bucket, first_item, items; };
 
 static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* __restrict__ offsets, u32 nbuckets,
@@ -281,6 +281,8 @@ static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* _
   for (u32 q = 0; q < k; q++) items[first + q] = make_uint2(g, q);
 }
 
+// one WAVE per chunk: 64 lanes stride over the chunk's entries, then a 6-step LDS tree inside the wave's own
+// LDS region.  All waves of a workgroup run the same number of rounds so the barriers stay uniform.
 template <class C>
 __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __restrict__ bases,
                                                                 const u32* __restrict__ sorted,
@@ -291,34 +293,38 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
   extern __shared__ uint4 heavy_lds[];
-  char* sh = (char*)heavy_lds;
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  char* sh = (char*)heavy_lds + (size_t)wave * 64 * Pt::BYTES;
   const u32 nitems = ctr[0];
-  for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
-    uint2 it = items[item];
-    u32 lo = offsets[it.x] + it.y * HEAVY_CHUNK;
-    u32 hi = offsets[it.x + 1];
-    if (hi > lo + HEAVY_CHUNK) hi = lo + HEAVY_CHUNK;
+  for (u32 first = blockIdx.x * wpb; first < nitems; first += gridDim.x * wpb) {
+    const u32 item = first + wave;
+    const bool live = item < nitems;
     Pt acc = Pt::zero();
-    for (u32 j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-      u32 e = sorted[j];
-      Affine<F> p = Affine<F>::load(bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
-      if (!p.is_zero()) {
-        F y = F::cond_neg(p.y, (e >> 31) != 0);
-        xyzz_madd<F>(acc, p.x, y);
+    if (live) {
+      uint2 it = items[item];
+      u32 lo = offsets[it.x] + it.y * HEAVY_CHUNK;
+      u32 hi = offsets[it.x + 1];
+      if (hi > lo + HEAVY_CHUNK) hi = lo + HEAVY_CHUNK;
+      for (u32 j = lo + lane; j < hi; j += 64) {
+        u32 e = sorted[j];
+        Affine<F> p = Affine<F>::load(bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+        if (!p.is_zero()) {
+          F y = F::cond_neg(p.y, (e >> 31) != 0);
+          xyzz_madd<F>(acc, p.x, y);
+        }
       }
     }
-    // workgroup tree sum through LDS
-    acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
+    acc.store(sh + (size_t)lane * Pt::BYTES);
     __syncthreads();
-    for (u32 o = blockDim.x / 2; o > 0; o >>= 1) {
-      if (threadIdx.x < o) {
-        Pt other = Pt::load(sh + (size_t)(threadIdx.x + o) * Pt::BYTES);
+    for (u32 o = 32; o > 0; o >>= 1) {
+      if (lane < o) {
+        Pt other = Pt::load(sh + (size_t)(lane + o) * Pt::BYTES);
         xyzz_add<F>(acc, other);
-        acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
+        acc.store(sh + (size_t)lane * Pt::BYTES);
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) acc.store(partials + (size_t)item * Pt::BYTES);
+    if (live && lane == 0) acc.store(partials + (size_t)item * Pt::BYTES);
     __syncthreads();
   }
 }
@@ -451,6 +457,45 @@ __global__ void __launch_bounds__(128) msm_reduce_level_kernel(const char* __res
   acc.store(outA + (size_t)t * Pt::BYTES);
 }
 
+// ---- K5b: the rest of the reduction, bit-sliced -------------------------------------------------------
+// After level 0 every window holds m pairs (S_j, A_j) with  sum_k k B_k = sum_j A_j + L0 * sum_j j S_j.
+// Continuing with chunked running sums costs ~0.4 ms of pure latency per level (a handful of lanes, each a
+// serial chain).  Instead  sum_j j S_j = sum_b 2^b U_b  with  U_b = sum_{j : bit b of j set} S_j : log2(m)
+// masked plain sums plus the plain sum of the A_j -- all independent, each a strided partial sum + LDS tree.
+// grid = (chunks, log2(m) + 1, W): quantity q < nbits -> U_q, q == nbits -> sum A.  The host finishes with
+// a Horner over the bits (a few dozen point operations per window, same templated formulas).
+template <class C>
+__global__ void __launch_bounds__(256) msm_reduce_bits_kernel(const char* __restrict__ S, const char* __restrict__ A,
+                                                              u32 m, int nbits, u32 chunk, char* __restrict__ partial) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  extern __shared__ uint4 reduce_lds[];
+  char* sh = (char*)reduce_lds;
+  const u32 q = blockIdx.y, w = blockIdx.z, ch = blockIdx.x;
+  const bool plain = (int)q == nbits;
+  const char* src = plain ? A : S;
+  Pt acc = Pt::zero();
+  for (u32 e = threadIdx.x; e < chunk; e += blockDim.x) {
+    u32 j = ch * chunk + e;
+    if (j < m && (plain || ((j >> q) & 1u))) {
+      Pt x = Pt::load(src + ((size_t)w * m + j) * Pt::BYTES);
+      xyzz_add<F>(acc, x);
+    }
+  }
+  acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
+  __syncthreads();
+  for (u32 o = blockDim.x / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      Pt other = Pt::load(sh + (size_t)(threadIdx.x + o) * Pt::BYTES);
+      xyzz_add<F>(acc, other);
+      acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    acc.store(partial + (((size_t)w * gridDim.y + q) * gridDim.x + ch) * Pt::BYTES);
+}
+
 // ---- host-side plan / workspace -----------------------------------------------------------------
 struct MsmPlan {
   int c;          // window bits
@@ -471,7 +516,7 @@ static inline int msm_scalar_bits(int curve_id) {
 // Window size.  Model (seconds) of the phases that depend on c, from this chip's measured rates
 // (profiles/): mixed additions stream at ~5.5e9/s (Fp384; scaled by `mul_cost` for other fields) but a
 // single bucket is a serial chain (~14 us per addition on a lightly loaded SIMD), the first reduction
-// level costs 2 full additions per bucket, every further level ~0.4 ms of latency.
+// level costs 2 full additions per bucket, the bit-sliced remainder ~0.5 ms.
 static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost = 1.0) {
   int best_c = 2;
   double best = 1e300;
@@ -490,9 +535,13 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost = 1.0) {
       double red0 = nbk * 2.0 * fadd;
       const double red0_lat = 2.0 * 8.0 * 21e-6 * mul_cost;     // >= 8 buckets per lane at level 0
       if (red0_lat > red0) red0 = red0_lat;
-      const int upper = c - 1 > 5 ? (c - 1 - 5 + 1) / 2 : 0;    // levels of 4 after a level of 32
+      const double bits_stage = 0.5e-3 * mul_cost;              // bit-sliced stage + host tail
       const double sort = entries * 2.0e-11 + nbk * 1.0e-10;
-      const double cost = acc + red0 + upper * 0.4e-3 * mul_cost + sort;
+      double cost = acc + red0 + bits_stage + sort;
+      // A top window with only a few significant bits (after the s -> r-s fold the scalar has bits-1 of them)
+      // funnels n/2^tb points into each of 2^tb buckets: correct (heavy-bucket path) but measured ~1.4x slower.
+      const int tb = (bits - 1) - (W - 1) * c;
+      if (tb >= 1 && tb <= 5) cost *= 1.4;
       if (cost < best) { best = cost; best_c = c; }
     }
   }
@@ -610,10 +659,15 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   u32* sums = (u32*)ws.sums.p;
 
   if (ws.err.ensure(16)) return -3;
-  // heavy buckets: load above max(2048, 16 x mean)
+  // heavy buckets: a lane walks its bucket serially (~28 us per entry with two or three waves per SIMD) and
+  // the heaviest buckets start first; a bucket is "heavy" when its walk would outlast the kernel's
+  // throughput-bound duration (entries / 5.5e9 per s).  At 2^24 x 13 windows that is ~1400 entries, so the
+  // sparse top window (1024 per bucket) still rides along; skewed scalar distributions do not.
   const size_t total_entries = (size_t)n * W;
   size_t mean_load = total_entries / nb;
-  u32 heavy_thresh = (u32)(mean_load * 16 > 2048 ? mean_load * 16 : 2048);
+  u32 heavy_thresh = (u32)(total_entries / 154000);
+  if (heavy_thresh < 64) heavy_thresh = 64;
+  if (heavy_thresh < 4 * mean_load) heavy_thresh = (u32)(4 * mean_load);
   if (const char* hv = getenv("ARK_HIP_MSM_HEAVY")) {
     if (atoi(hv) >= 64) heavy_thresh = (u32)atoi(hv);
   }
@@ -680,7 +734,7 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
     u32* hctr = (u32*)ws.hctr.p;
     hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
                        heavy_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
-    const u32 hthreads = Pt::BYTES > 192 ? 128 : 256;  // keep the LDS tree within 48 KiB
+    const u32 hthreads = Pt::BYTES > 192 ? 128 : 256;  // one 64-lane LDS tree per wave, 48 KiB per workgroup
     hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), hthreads * Pt::BYTES, stream,
                        (const char*)d_bases, sorted, offsets, hctr, (const uint2*)ws.hitems.p, (char*)ws.hpart.p);
     hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3((u32)((max_heavy + 63) / 64)), dim3(64), 0, stream, hctr,
@@ -688,55 +742,75 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   }
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[4], stream));
 
-  // bucket reduction levels
-  const char* inS = (const char*)ws.buckets.p;
-  const char* inA = nullptr;
-  size_t m = mwin;  // inputs per window
-  int log2M = 0;    // log2 of the cumulative chunk size
-  int lvl = 0;
-  int pp = 0;
-  while (m > 1 || lvl == 0) {
-    u32 L;
-    if (lvl == 0) {
-      L = 32;
-      while (L > m) L >>= 1;
-      // keep enough lanes in flight on small problems
-      while (L > 4 && (m / L) * (size_t)W < 4096) L >>= 1;
-    } else {
-      L = 4;
-      while (L > m) L >>= 1;
-    }
-    if (L < 1) L = 1;
-    size_t mout = m / L;
-    size_t total_out = mout * W;
-    if (ws.lvlS[pp].ensure(total_out * Pt::BYTES)) return -3;
-    if (ws.lvlA[pp].ensure(total_out * Pt::BYTES)) return -3;
-    hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((total_out + 127) / 128)), dim3(128), 0, stream, inS,
-                       inA, L, log2M, (u32)total_out, (char*)ws.lvlS[pp].p, (char*)ws.lvlA[pp].p);
-    inS = (const char*)ws.lvlS[pp].p;
-    inA = (const char*)ws.lvlA[pp].p;
-    pp ^= 1;
-    m = mout;
-    int lg = 0;
-    while ((1u << lg) < L) lg++;
-    log2M += lg;
-    lvl++;
+  // bucket reduction: level 0 (chunked running sums over L0 buckets per lane), then the bit-sliced sums
+  u32 L0 = 32;
+  {
+    size_t want = (mwin * (size_t)W) >> 17;  // keep ~1e5 (S, A) pairs for the bit-sliced stage
+    u32 p2 = 1;
+    while (p2 < want) p2 <<= 1;
+    if (p2 < 8) p2 = 8;
+    if (p2 < L0) L0 = p2;
+    while (L0 > mwin) L0 >>= 1;
   }
-  ARK_HIP_TRY(hipMemcpyAsync(ws.pinned, inA, (size_t)W * Pt::BYTES, hipMemcpyDeviceToHost, stream));
-  u32* h_err = (u32*)((char*)ws.pinned + (size_t)W * Pt::BYTES);
+  const size_t m = mwin / L0;  // pairs per window after level 0
+  int log2L0 = 0;
+  while ((1u << log2L0) < L0) log2L0++;
+  int nbits = 0;
+  while (((size_t)1 << nbits) < m) nbits++;
+  const u32 Q = (u32)nbits + 1;
+  u32 chunk = 4096;
+  if (chunk > m) chunk = (u32)m;
+  const u32 nchunks = (u32)((m + chunk - 1) / chunk);
+  const size_t npart = (size_t)W * Q * nchunks;
+  if (ws.lvlS[0].ensure(m * W * Pt::BYTES) || ws.lvlA[0].ensure(m * W * Pt::BYTES)) return -3;
+  if (ws.lvlS[1].ensure(npart * Pt::BYTES)) return -3;
+  if (ws.pinned_cap < npart * Pt::BYTES + 64) {
+    if (ws.pinned) (void)hipHostFree(ws.pinned);
+    ws.pinned = nullptr;
+    ws.pinned_cap = 0;
+    ARK_HIP_TRY(hipHostMalloc(&ws.pinned, npart * Pt::BYTES + 64));
+    ws.pinned_cap = npart * Pt::BYTES + 64;
+  }
+  hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * W + 127) / 128)), dim3(128), 0, stream,
+                     (const char*)ws.buckets.p, (const char*)nullptr, L0, 0, (u32)(m * W), (char*)ws.lvlS[0].p,
+                     (char*)ws.lvlA[0].p);
+  {
+    const u32 rthreads = Pt::BYTES > 192 ? 128 : 256;  // LDS tree within 48 KiB
+    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, W), dim3(rthreads), rthreads * Pt::BYTES, stream,
+                       (const char*)ws.lvlS[0].p, (const char*)ws.lvlA[0].p, (u32)m, nbits, chunk, (char*)ws.lvlS[1].p);
+  }
+  ARK_HIP_TRY(hipMemcpyAsync(ws.pinned, ws.lvlS[1].p, npart * Pt::BYTES, hipMemcpyDeviceToHost, stream));
+  u32* h_err = (u32*)((char*)ws.pinned + npart * Pt::BYTES);
   ARK_HIP_TRY(hipMemcpyAsync(h_err, ws.err.p, 4, hipMemcpyDeviceToHost, stream));
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[5], stream));
   ARK_HIP_TRY(hipStreamSynchronize(stream));
   ARK_HIP_TRY(hipGetLastError());
   if (*h_err) return -4;  // scalar out of range
 
-  // window combine (mod.rs:489-502): total = sum_w 2^(c*w) * T_w, high to low
+  // host tail (serial chains, ~0.2 ms):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(c w) T_w
+  // (window combine of mod.rs:489-502, high to low)
+  auto part_at = [&](int w, u32 q) {
+    Pt s = Pt::zero();
+    for (u32 ch = 0; ch < nchunks; ch++) {
+      Pt x = Pt::load((const char*)ws.pinned + (((size_t)w * Q + q) * nchunks + ch) * Pt::BYTES);
+      xyzz_add<F>(s, x);
+    }
+    return s;
+  };
   Pt total = Pt::zero();
   for (int w = W - 1; w >= 0; w--) {
     if (w != W - 1)
       for (int k = 0; k < c; k++) total = xyzz_dbl<F>(total);
-    Pt tw = Pt::load((const char*)ws.pinned + (size_t)w * Pt::BYTES);
-    xyzz_add<F>(total, tw);
+    Pt u = Pt::zero();
+    for (int b2 = nbits - 1; b2 >= 0; b2--) {
+      u = xyzz_dbl<F>(u);
+      Pt ub = part_at(w, (u32)b2);
+      xyzz_add<F>(u, ub);
+    }
+    for (int k = 0; k < log2L0; k++) u = xyzz_dbl<F>(u);
+    Pt asum = part_at(w, (u32)nbits);
+    xyzz_add<F>(u, asum);
+    xyzz_add<F>(total, u);
   }
   xyzz_to_jac<F>(total).store(out_xyz);
 

@@ -97,3 +97,40 @@ def into_affine(curve, points):
     out = np.zeros((n, cv.affine_words(cid)), dtype=np.uint64)
     check(lib().ark_hip_sw_into_affine(cid, pp, n, out.ctypes.data_as(C.c_void_p)), "ark_hip_sw_into_affine")
     return out[0] if p.ndim == 1 else out
+
+
+class ChunkedPippenger:
+    """Host mirror of ark_ec's streaming accumulator (ec/src/scalar_mul/variable_base/stream_pippenger.rs:10-66):
+    buffers (base, bigint) pairs and runs an MSM whenever `max_msm_buffer` pairs are pending; `finalize`
+    flushes and returns the total.  Each flush is one device MSM; partial results are summed on the host."""
+
+    def __init__(self, curve, max_msm_buffer):
+        self.curve = cv.curve_id(curve)
+        self.buf_size = int(max_msm_buffer)
+        self._bases = []
+        self._scalars = []
+        self._result = None
+
+    @classmethod
+    def with_size(cls, curve, max_msm_buffer):
+        return cls(curve, max_msm_buffer)
+
+    def add(self, base, scalar):
+        self._bases.append(np.asarray(base, dtype=np.uint64).reshape(-1))
+        self._scalars.append(np.asarray(scalar, dtype=np.uint64).reshape(-1))
+        if len(self._bases) == self.buf_size:
+            self._flush()
+
+    def _flush(self):
+        if not self._bases:
+            return
+        part = msm_bigint(self.curve, np.stack(self._bases), np.stack(self._scalars))
+        self._result = part if self._result is None else sum_projective(self.curve, np.stack([self._result, part]))
+        self._bases, self._scalars = [], []
+
+    def finalize(self):
+        self._flush()
+        if self._result is None:
+            return msm_bigint(self.curve, np.zeros((0, cv.affine_words(self.curve)), dtype=np.uint64),
+                              np.zeros((0, 4), dtype=np.uint64))
+        return self._result

@@ -204,3 +204,35 @@ def test_msm_skewed_scalars_heavy_buckets(cname):
         got = A.msm_bigint(cid, d, torch.from_numpy(scalars.view(np.int64)).cuda())
         exp = O.msm(cid, bases, scalars, O.SIGNED, 8)
         assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp)), (cname, name)
+
+
+def test_msm_known_answer_table_bls12_381_g2():
+    # reference KAT for the Fp2 path: k*G2 for k = 0..999 (g2_uncompressed_valid_test_vectors.dat, tests/mod.rs:113-123)
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bls12_381_g2_multiples.npz"))
+    xy = g["xy"]  # canonical limbs [1000, 2 (x,y), 2 (c0,c1), 6]
+    fq = O.FID["BLS12_381_FQ"]
+    mont = O.field_op(fq, "from_bigint", xy.reshape(-1, 6)).reshape(1000, 24)
+    cid = O.CID["BLS12_381_G2"]
+    sc10 = np.zeros((10, 4), dtype=np.uint64)
+    sc10[:, 0] = np.arange(10, 0, -1)          # sum_{k=1..10} k (11-k) = 220
+    got = A.into_affine(cid, A.msm_bigint(cid, mont[1:11], sc10))
+    assert np.array_equal(got, mont[220])
+    ones = np.zeros((44, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, mont[1:45], ones)), mont[990])
+
+
+def test_chunked_pippenger_matches_msm_bigint():
+    # test_chunked_pippenger (test-templates/src/msm.rs:112-133): streaming wrapper == msm_bigint
+    cid = O.CID["BLS12_381_G1"]
+    n = 1 << 10
+    bases = O.gen_bases(cid, A4, B4, n)
+    scalars = O.gen_scalars(sf(cid), 31337, n)
+    whole = A.msm_bigint(cid, bases, scalars)
+    p = A.ChunkedPippenger.with_size(cid, 1 << 8)
+    for b, s in zip(bases, scalars):
+        p.add(b, s)
+    assert np.array_equal(A.into_affine(cid, p.finalize()), A.into_affine(cid, whole))
+    assert np.array_equal(A.into_affine(cid, A.ChunkedPippenger(cid, 4).finalize()),
+                          np.zeros(2 * O.fe_words(cid), dtype=np.uint64))

@@ -45,9 +45,13 @@ def main():
         d = np.ascontiguousarray(mul_gen(m * b0))
         check(L.ark_hip_sw_add_affine_device(cid, bases.data_ptr(), bases.data_ptr() + m * ab, cnt, d.ctypes.data_as(C.c_void_p)), "ext")
         m += cnt
-    rng = np.random.default_rng(5)
-    sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    sc[:, 3] &= np.uint64((1 << 60) - 1)  # < 2^252 < r for all three scalar fields
+    if cv.scalar_field(cid) == "BLS12_381_FR":
+        import bench
+        sc = bench.gen_scalars(n, 5)          # uniform in [0, r)
+    else:
+        rng = np.random.default_rng(5)
+        sc = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+        sc[:, 3] &= np.uint64((1 << 60) - 1)  # < 2^252 < r for the other two scalar fields
     scalars = torch.from_numpy(sc.view(np.int64)).cuda()
     torch.cuda.synchronize()
     res = A.msm_bigint(cid, bases, scalars)
