@@ -299,6 +299,10 @@ struct Fp {
 #endif
   }
   ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }  // montgomery_backend.rs:250-317
+  // Out-of-line copy for the extension-field formulas: an XYZZ addition over Fp2 would otherwise inline ~40 copies
+  // of this 700-instruction sequence (minutes of compile time per kernel, scratch spills).  Operands travel by value
+  // so the AMDGPU calling convention keeps them in VGPRs.
+  __host__ __device__ __attribute__((noinline)) static Fp mul_call(Fp a, Fp b) { return mul(a, b); }
   // Montgomery -> canonical integer (montgomery_backend.rs:396-412): multiply by 1
   ARK_HD static Fp from_mont(const Fp& a) {
     Fp o = zero();
@@ -393,9 +397,9 @@ struct Fp2 {
     else { static_assert(NEG_BETA == 1 || NEG_BETA == 5, "unsupported nonresidue"); return x; }
   }
   ARK_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
-    B v0 = B::mul(a.c0, b.c0);
-    B v1 = B::mul(a.c1, b.c1);
-    B s = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+    B v0 = B::mul_call(a.c0, b.c0);
+    B v1 = B::mul_call(a.c1, b.c1);
+    B s = B::mul_call(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
     Fp2 r;
     r.c1 = B::sub(B::sub(s, v0), v1);
     r.c0 = B::sub(v0, mul_neg_beta(v1));  // v0 + beta*v1
@@ -404,8 +408,8 @@ struct Fp2 {
   ARK_HD static Fp2 sqr(const Fp2& a) {
     // (a0 + a1 u)^2 = (a0^2 + beta a1^2) + 2 a0 a1 u ; with t = a0*a1:
     // a0^2 + beta a1^2 = (a0 + a1)(a0 + beta a1) - (1 + beta) t
-    B t = B::mul(a.c0, a.c1);
-    B s = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, mul_neg_beta(a.c1)));
+    B t = B::mul_call(a.c0, a.c1);
+    B s = B::mul_call(B::add(a.c0, a.c1), B::sub(a.c0, mul_neg_beta(a.c1)));
     Fp2 r;
     r.c1 = B::dbl(t);
     // -(1+beta) t = (NEG_BETA - 1) t
