@@ -68,6 +68,16 @@ def main():
     if vals is not None:
         k = (int(np.sum(vals)) * a0 + int(np.dot(vals, np.arange(n, dtype=object))) * b0) % r
         ok = bool(np.array_equal(A.into_affine(cid, res), mul_gen(k)))
+    if os.environ.get("MSM_BENCH_HOST"):
+        hb = bases.cpu().numpy().view(np.uint64).reshape(n, -1)
+        A.msm_bigint(cid, hb, sc)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            rh = A.msm_bigint(cid, hb, sc)
+        dth = (time.perf_counter() - t0) / 2
+        print("%s 2^%d host-pointer entry (pageable numpy buffers, H2D of %.2f GiB included): %.1f ms/MSM  %.3e scalar-muls/s  same result: %s"
+              % (curve, logn, (hb.nbytes + sc.nbytes) / 2**30, dth * 1e3, n / dth, bool(np.array_equal(rh, res)) or
+                 bool(np.array_equal(A.into_affine(cid, rh), A.into_affine(cid, res)))))
     print("%s 2^%d c=%d W=%d: %.2f ms/MSM  %.3e scalar-muls/s  [digits %.2f sortA %.2f sortB %.2f accumulate %.2f reduce %.2f]  exact=%s"
           % (curve, logn, int(tm[6]), int(tm[7]), dt * 1e3, n / dt, tm[0], tm[1], tm[2], tm[3], tm[4], ok))
 
