@@ -14,3 +14,4 @@ from ._lib import ArkHipError, LIB_PATH, lib  # noqa: F401
 from .msm import (ChunkedPippenger, MsmLengthMismatch, into_affine, msm, msm_bigint, msm_unchecked,  # noqa: F401
                   sum_projective)
 from .domain import Radix2EvaluationDomain  # noqa: F401
+from .poly import poly_mul  # noqa: F401

@@ -379,6 +379,23 @@ int ark_hip_ifft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t*
 int ark_hip_fft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d) { return fft_any(field, dom, d, 0); }
 int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d) { return fft_any(field, dom, d, 1); }
 
+// r[i] = a[i] * b[i] over n Fr elements in device memory (Evaluations *= Evaluations,
+// poly/src/evaluations/univariate/mod.rs MulAssign; the middle step of DensePolynomial multiplication,
+// poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous on the context stream.
+int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n) {
+  if (n && (!d_a || !d_b || !d_r)) return ARK_HIP_ERR_ARG;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  switch (field) {
+#ifndef ARK_HIP_DEV
+    case ARK_HIP_BN254_FR: return test_field_op_BN254_FR(2, d_a, d_b, d_r, n, g_ctx->stream);
+    case ARK_HIP_BLS12_377_FR: return test_field_op_BLS12_377_FR(2, d_a, d_b, d_r, n, g_ctx->stream);
+#endif
+    case ARK_HIP_BLS12_381_FR: return test_field_op_BLS12_381_FR(2, d_a, d_b, d_r, n, g_ctx->stream);
+  }
+  return ARK_HIP_ERR_ARG;
+}
+
 int ark_hip_fft_set_timing(int enable) {
   int rc = ensure_ctx();
   if (rc) return rc;

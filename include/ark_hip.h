@@ -109,6 +109,10 @@ int ark_hip_ifft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t*
 /* Same on device memory; asynchronous on the context stream (ark_hip_synchronize() to wait). */
 int ark_hip_fft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d_data);
 int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d_data);
+/* r[i] = a[i] * b[i] over n Fr elements in device memory: `Evaluations *= &Evaluations`
+ * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
+ * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */
+int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
 int ark_hip_fft_set_timing(int enable);
 /* [total_ms, npass, pass0_ms, pass1_ms, ...] of the last timed device transform */
 int ark_hip_fft_last_timing(double out[10]);

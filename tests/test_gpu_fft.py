@@ -96,3 +96,20 @@ def test_fft_2_22_bls12_381_device_resident():
     yb = d.fft(b).reshape(n, 4)
     yab = d.fft(ab).reshape(n, 4)
     assert np.array_equal(O.field_op(fid, "add", ya, yb).reshape(n, 4), yab)
+
+
+@pytest.mark.parametrize("fname", FR)
+def test_polynomial_multiplication_on_device(fname):
+    # &DensePolynomial * &DensePolynomial (dense.rs:641-656): FFT, pointwise product, IFFT without leaving the GPU;
+    # checked against the schoolbook product computed with the oracle's field arithmetic
+    fid = O.FID[fname]
+    for la, lb in [(1, 1), (3, 5), (17, 16), (100, 29)]:
+        a = rand_fr(fid, la, 71 + la)
+        b = rand_fr(fid, lb, 93 + lb)
+        got = A.poly_mul(fname, a, b)
+        exp = np.zeros((la + lb - 1, 4), dtype=np.uint64)
+        for i in range(la):
+            prod = O.field_op(fid, "mul", np.tile(a[i], (lb, 1)), b).reshape(lb, 4)
+            exp[i:i + lb] = O.field_op(fid, "add", exp[i:i + lb], prod).reshape(lb, 4)
+        assert np.array_equal(got, exp), (fname, la, lb)
+    assert A.poly_mul(fname, np.zeros((0, 4), dtype=np.uint64), rand_fr(fid, 3, 1)).shape == (0, 4)
