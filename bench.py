@@ -131,12 +131,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # one process per GPU.  (ARK_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs
+    # than ranks -- ranks then share devices; never used for reported numbers.)
+    backend = os.environ.get("ARK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     L = lib()
-    check(L.ark_hip_init(local_rank), "ark_hip_init")
+    check(L.ark_hip_init(dev_index), "ark_hip_init")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     cid = cv.curve_id(CURVE)
     n = 1 << args.log_n
@@ -195,7 +202,7 @@ def main():
     elapsed = time.perf_counter() - t0
     check(L.ark_hip_msm_set_timing(0), "set_timing")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     phases /= max(args.steps, 1)
@@ -291,8 +298,8 @@ def main():
                        "curve": CURVE, "window_bits": int(phases[6]), "windows": int(phases[7]),
                        "sharding": "base-range, %d rank(s)" % world},
             "bit_exact_vs_kG": exact,
-            "phases_ms": {"digits": phases[0], "scan": phases[1], "scatter": phases[2], "accumulate": phases[3],
-                          "reduce": phases[4], "device_total": phases[5]},
+            "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
+                          "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic("msm_accumulate_kernel", args.log_n),

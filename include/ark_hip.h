@@ -63,7 +63,8 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalars_are_montgomery,
                           uint64_t* out_xyz);
 /* Per-phase device times of the last ark_hip_msm_sw_device call made with timing enabled (ms):
- * [digits, scan, scatter, accumulate, reduce, total, window_bits, windows] */
+ * [digits, partition histogram + scan, partition scatter + finish + bucket order, accumulate (incl. heavy
+ *  buckets), reduce, total, window_bits, windows] */
 int ark_hip_msm_set_timing(int enable);
 int ark_hip_msm_last_timing(double out[8]);
 
