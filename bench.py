@@ -292,9 +292,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 limbs (Fp384/Fp256 Montgomery, integer)",
+            "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "BLS12-381 G1 MSM, 2^%d random bases/scalars per GPU, device resident" % args.log_n,
+                       "arithmetic": "Montgomery Fp384 on 32-bit limbs (v_mad_u64_u32), exact integers",
                        "curve": CURVE, "window_bits": int(phases[6]), "windows": int(phases[7]),
                        "sharding": "base-range, %d rank(s)" % world},
             "bit_exact_vs_kG": exact,
