@@ -173,6 +173,9 @@ def main():
     torch.cuda.synchronize()
 
     from algebra_amd import dist as D
+    if world > 1:
+        # bring the communicator up outside the timed region (RCCL initialises lazily on the first collective)
+        D.combine_partials(cid, np.zeros(cv.projective_words(cid), dtype=np.uint64))
 
     def step():
         # local MSM on this rank's base range, then (N > 1) RCCL all-gather of the 144-byte partials + EC sum
