@@ -9,30 +9,35 @@
 namespace arkhip {
 
 struct BN254_G1 {
+  static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 0;
   typedef Fp<BN254_FQ> F;
   typedef BN254_FR S;
 };
 struct BLS12_381_G1 {
+  static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 1;
   typedef Fp<BLS12_381_FQ> F;
   typedef BLS12_381_FR S;
 };
 struct BLS12_377_G1 {
+  static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 2;
   typedef Fp<BLS12_377_FQ> F;
   typedef BLS12_377_FR S;
 };
 struct BLS12_377_G2 {
+  static constexpr bool RELAXED = false;
   static constexpr bool LAZY = false;  // lazy form not defined over Fp2
   static constexpr int ID = 3;
   typedef Fp2<BLS12_377_FQ, 5> F;
   typedef BLS12_377_FR S;
 };
 struct BLS12_381_G2 {
+  static constexpr bool RELAXED = false;
   static constexpr bool LAZY = false;  // lazy form not defined over Fp2
   static constexpr int ID = 4;
   typedef Fp2<BLS12_381_FQ, 1> F;

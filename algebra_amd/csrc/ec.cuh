@@ -133,6 +133,37 @@ ARK_HD void xyzz_madd(XYZZ<F>& acc, const F& x2, const F& y2) {
   acc.zzz = F::mul(acc.zzz, ppp);
 }
 
+// The same mixed addition on relaxed residues (Fp::mul_r & co., values in [0, 2p)): the bucket-accumulation loop
+// of the MSM.  (x2, y2) canonical; acc's coordinates relaxed, except that infinity is the exact (1, 1, 0, 0).
+template <class F>
+ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
+  if (acc.is_zero()) {
+    acc.x = x2; acc.y = y2; acc.zz = F::one(); acc.zzz = F::one();
+    return;
+  }
+  F p = F::sub_r(F::mul_r(x2, acc.zz), acc.x);
+  F r = F::sub_r(F::mul_r(y2, acc.zzz), acc.y);
+  if (p.is_zero_mod_p()) {
+    if (r.is_zero_mod_p()) acc = xyzz_mdbl<F>(x2, y2);   // canonical arithmetic; rare
+    else acc = XYZZ<F>::zero();
+    return;
+  }
+  F pp = F::mul_r(p, p);
+  F ppp = F::mul_r(p, pp);
+  F q = F::mul_r(acc.x, pp);
+  F x3 = F::sub_r(F::sub_r(F::mul_r(r, r), ppp), F::dbl_r(q));
+  F y3 = F::sub_r(F::mul_r(r, F::sub_r(q, x3)), F::mul_r(acc.y, ppp));
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = F::mul_r(acc.zz, pp);
+  acc.zzz = F::mul_r(acc.zzz, ppp);
+}
+template <class F>
+ARK_HD XYZZ<F> xyzz_canonical(const XYZZ<F>& a) {
+  if (a.is_zero()) return XYZZ<F>::zero();
+  return XYZZ<F>{a.x.canonical(), a.y.canonical(), a.zz.canonical(), a.zzz.canonical()};
+}
+
 // acc += b (both XYZZ)                                        bucket.rs:256-337 (add-2008-s)
 template <class F>
 ARK_HD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {

@@ -299,6 +299,92 @@ struct Fp {
 #endif
   }
   ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }  // montgomery_backend.rs:250-317
+
+  // ---- "relaxed" residues in [0, 2p) for the MSM inner loop -------------------------------------------
+  // Every modulus served here satisfies 4p <= 2^(32N) (p/R = 0.10, 0.007, 0.19 for the three base fields), so a
+  // Montgomery product of operands < 2p is itself < 2p without the final conditional subtraction:
+  // (a b + m p)/R < p (4p/R + 1) <= 2p.  Sums and differences are brought back below 2p with one
+  // conditional +-2p.  Saves the 2N-instruction tail of every product in the bucket accumulation; values are
+  // made canonical again (one conditional subtraction) before they are stored.
+  ARK_HD static Fp mul_r(const Fp& a, const Fp& b) {
+    static_assert((P::P[N - 1] >> 30) == 0, "relaxed arithmetic needs 4p <= R");
+#if defined(__HIP_DEVICE_COMPILE__)
+    Acc96 c{0, 0};
+    u32 m[N];
+    Fp r;
+    mont_cols_lo<P, 0>(c, a.l, b.l, m);
+    mont_cols_hi<P, N>(c, a.l, b.l, m, r.l);
+    r.l[N - 1] = (u32)c.lo;
+    return r;
+#else
+    return mul(a, b);  // canonical is a valid relaxed representative
+#endif
+  }
+  // t (< 4p) -> t or t - 2p, whichever lies in [0, 2p)
+  ARK_HD static Fp reduce_2p(const u32* t) {
+    u32 d[N];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const u32 p2 = (i == 0) ? ((u32)P::P[0] << 1) : (((u32)P::P[i] << 1) | ((u32)P::P[i - 1] >> 31));
+      u32 bo;
+      d[i] = __builtin_subc(t[i], p2, borrow, &bo);
+      borrow = bo;
+    }
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = borrow ? t[i] : d[i];
+    return r;
+  }
+  ARK_HD static Fp add_r(const Fp& a, const Fp& b) {
+    u32 t[N];
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      u32 co;
+      t[i] = __builtin_addc(a.l[i], b.l[i], c, &co);
+      c = co;
+    }
+    return reduce_2p(t);
+  }
+  ARK_HD static Fp dbl_r(const Fp& a) {
+    u32 t[N];
+#pragma unroll
+    for (int i = N - 1; i > 0; i--) t[i] = (a.l[i] << 1) | (a.l[i - 1] >> 31);
+    t[0] = a.l[0] << 1;
+    return reduce_2p(t);
+  }
+  ARK_HD static Fp sub_r(const Fp& a, const Fp& b) {  // a - b (+ 2p if negative)
+    u32 d[N];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      u32 bo;
+      d[i] = __builtin_subc(a.l[i], b.l[i], borrow, &bo);
+      borrow = bo;
+    }
+    const u32 mask = 0u - borrow;
+    Fp r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const u32 p2 = (i == 0) ? ((u32)P::P[0] << 1) : (((u32)P::P[i] << 1) | ((u32)P::P[i - 1] >> 31));
+      u32 co;
+      r.l[i] = __builtin_addc(d[i], p2 & mask, c, &co);
+      c = co;
+    }
+    return r;
+  }
+  ARK_HD bool is_zero_mod_p() const {  // relaxed value: 0 or p
+    u32 o = 0, q = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      o |= l[i];
+      q |= l[i] ^ (u32)P::P[i];
+    }
+    return o == 0 || q == 0;
+  }
+  ARK_HD Fp canonical() const { return reduce_once(l); }
   // Out-of-line copy for the extension-field formulas: an XYZZ addition over Fp2 would otherwise inline ~40 copies
   // of this 700-instruction sequence (minutes of compile time per kernel, scratch spills).  Operands travel by value
   // so the AMDGPU calling convention keeps them in VGPRs.

@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restr
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
         F y = F::cond_neg(p.y, (e >> 31) != 0);
-        xyzz_madd<F>(acc, p.x, y);
+        if constexpr (C::RELAXED) xyzz_madd_relaxed<F>(acc, p.x, y);
+        else xyzz_madd<F>(acc, p.x, y);
       }
       if (!more) break;
       e = e_next;
@@ -255,6 +256,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restr
       j++;
     }
   }
+  if constexpr (C::RELAXED) acc = xyzz_canonical<F>(acc);
   acc.store(buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES);  // g is a slot (msm_sort.cuh)
 }
 
@@ -614,6 +616,7 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   const MsmPlan pl = msm_make_plan(n, C::S::BITS, msm_mul_cost(C::ID));
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;
+  if ((size_t)n * (size_t)W >= (1ull << 32)) return -2;  // sort positions are 32-bit
   const size_t mwin = (size_t)1 << (c - 1);
 
   // bucket-id split for the two-pass partition sort (msm_sort.cuh)
