@@ -9,6 +9,7 @@
 namespace arkhip {
 
 struct BN254_G1 {
+  static constexpr int ACC_MIN_WAVES = 1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 0;
@@ -16,6 +17,7 @@ struct BN254_G1 {
   typedef BN254_FR S;
 };
 struct BLS12_381_G1 {
+  static constexpr int ACC_MIN_WAVES = 1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 1;
@@ -23,6 +25,7 @@ struct BLS12_381_G1 {
   typedef BLS12_381_FR S;
 };
 struct BLS12_377_G1 {
+  static constexpr int ACC_MIN_WAVES = 1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 2;
@@ -30,6 +33,7 @@ struct BLS12_377_G1 {
   typedef BLS12_377_FR S;
 };
 struct BLS12_377_G2 {
+  static constexpr int ACC_MIN_WAVES = 1;   // (2 = cap at 256 registers: measured slower, the extra spills cost more than the second wave hides)
   static constexpr bool RELAXED = false;
   static constexpr bool LAZY = false;  // lazy form not defined over Fp2
   static constexpr int ID = 3;
@@ -37,6 +41,7 @@ struct BLS12_377_G2 {
   typedef BLS12_377_FR S;
 };
 struct BLS12_381_G2 {
+  static constexpr int ACC_MIN_WAVES = 1;   // (2 = cap at 256 registers: measured slower, the extra spills cost more than the second wave hides)
   static constexpr bool RELAXED = false;
   static constexpr bool LAZY = false;  // lazy form not defined over Fp2
   static constexpr int ID = 4;

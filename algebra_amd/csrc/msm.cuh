@@ -221,7 +221,7 @@ static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32
 // One lane per bucket.  `order` (optional) maps lane -> bucket id so that lanes of one wave own
 // buckets of similar load.
 template <class C>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const char* __restrict__ bases,
+__global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(const char* __restrict__ bases,
                                                              const u32* __restrict__ sorted,
                                                              const u32* __restrict__ offsets,
                                                              const u32* __restrict__ order, u32 nbuckets,
