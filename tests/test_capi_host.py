@@ -106,3 +106,21 @@ def test_length_mismatch_is_reported_like_the_reference():
     with pytest.raises(A.MsmLengthMismatch) as e:
         A.msm("BLS12_381_G1", bases, scalars)
     assert e.value.min_len == 2
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_fallback():
+    # The product has no CPU compute path: without a visible GPU every compute entry point returns
+    # ARK_HIP_ERR_NO_DEVICE (-5) and the Python mirror raises.  (Skipped where a GPU is present.)
+    L = _lib.lib()
+    if L.ark_hip_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    cid = O.CID["BLS12_381_G1"]
+    bases = O.gen_bases(cid, A4, B4, 4)
+    scalars = O.gen_scalars(O.curve_info(cid)[1], 1, 4)
+    with pytest.raises(A.ArkHipError) as e:
+        A.msm_bigint(cid, bases, scalars)
+    assert e.value.code == -5
+    d = A.Radix2EvaluationDomain.new("BLS12_381_FR", 8)      # domain constants are host arithmetic: fine
+    with pytest.raises(A.ArkHipError) as e:
+        d.fft(np.zeros((8, 4), dtype=np.uint64))
+    assert e.value.code == -5
