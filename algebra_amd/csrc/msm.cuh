@@ -7,19 +7,21 @@
 //   ec/src/models/short_weierstrass/bucket.rs (XYZZ bucket arithmetic, see ec.cuh).
 // It is a different algorithm organisation, chosen for the GPU, producing the same group element:
 //
-//   K1 msm_digits      one lane per scalar: (optional Montgomery->canonical), fold s -> r-s when
-//                      that is smaller (negating the base instead; the GPU analogue of the
-//                      reference's negative-small-scalar classes, mod.rs:251-285), signed base-2^c
-//                      recoding exactly as make_digits, one key per (window, scalar) and a global
-//                      histogram of bucket loads (atomics).
-//   K2 scan            exclusive prefix sum of the histogram -> bucket offsets.
-//   K3 msm_scatter     counting-sort scatter: point indices grouped by (window, bucket).
-//   K4 msm_accumulate  one lane per bucket: gathers its bases (96 B random gathers run at
-//                      ~3.5 TB/s on this chip) and sums them with XYZZ mixed additions.
-//   K5 msm_reduce_level  sum_k k*B_k per window as a hierarchy of chunked running sums
-//                      (parallel form of mod.rs:478-484).
-//   host               Horner over the <= 64 window sums: (W-1)*c serial doublings -- a chain with no
-//                      parallelism, run on the host in the same templated formulas (0.1 ms).
+//   K1  msm_digits        one lane per scalar: (optional Montgomery->canonical), fold s -> r-s when that is
+//                         smaller (negating the base instead; the GPU analogue of the reference's
+//                         negative-small-scalar classes, mod.rs:251-285), signed base-2^c recoding exactly as
+//                         make_digits: one key (sign | bucket) per (window, scalar).
+//   K2  msm_part_*        (msm_sort.cuh) two-pass partition sort of the keys with LDS counters -> `sorted`
+//                         point indices grouped by bucket slot, `offsets` = prefix sums of the bucket loads.
+//   K3  msm_order_*       bucket slots ordered heaviest load class first (lanes of a wave get equal loads).
+//   K4  msm_accumulate    one lane per bucket: gathers its bases (96 B random gathers run at ~3.5 TB/s on this
+//                         chip) and sums them with XYZZ mixed additions on relaxed residues ([0, 2p)).
+//   K4h msm_heavy_*       buckets too long for one lane (skewed scalars): one wave per 2048-entry chunk.
+//   K5a msm_reduce_level  sum_k k*B_k per window, level 0: chunked running sums over <= 32 buckets per lane
+//                         (parallel form of mod.rs:478-484).
+//   K5b msm_reduce_bits   the rest, bit-sliced: log2(m)+1 independent masked sums per window.
+//   host                  Horner over the bit sums and the <= 64 window sums: ~(W-1)*c serial doublings -- a
+//                         chain with no parallelism, run on the host in the same templated formulas (~0.3 ms).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
