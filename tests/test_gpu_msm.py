@@ -236,3 +236,18 @@ def test_chunked_pippenger_matches_msm_bigint():
     assert np.array_equal(A.into_affine(cid, p.finalize()), A.into_affine(cid, whole))
     assert np.array_equal(A.into_affine(cid, A.ChunkedPippenger(cid, 4).finalize()),
                           np.zeros(2 * O.fe_words(cid), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("cname", ["BLS12_381_G1", "BN254_G1"])
+def test_msm_random_sizes_fuzz(cname):
+    # sizes that straddle the internal tiles (8192-key sort tiles, 2048-bucket order tiles, window-size changes)
+    cid = O.CID[cname]
+    rng = np.random.default_rng(2024)
+    sizes = [8191, 8192, 8193, 16385, 3, 5, 100, 257, 4097, 12345] + [int(x) for x in rng.integers(1, 20000, size=8)]
+    bases_all = O.gen_bases(cid, A4, B4, max(sizes))
+    for k, n in enumerate(sizes):
+        scalars = O.gen_scalars(sf(cid), 1000 + k, n)
+        off = int(rng.integers(0, max(sizes) - n + 1))
+        got = A.msm_bigint(cid, bases_all[off:off + n], scalars)
+        exp = O.msm(cid, bases_all[off:off + n], scalars, O.WNAF, 8)
+        assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp)), (cname, n)
