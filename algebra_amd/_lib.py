@@ -43,6 +43,10 @@ SYMBOLS = {
     "ark_hip_synchronize": (C.c_int, []),
     "ark_hip_version": (C.c_char_p, []),
     "ark_hip_curve_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
+    "ark_hip_malloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ark_hip_free": (C.c_int, [C.c_void_p]),
+    "ark_hip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_curve_generator": (C.c_int, [C.c_int, C.c_void_p]),
     "ark_hip_msm_sw": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ark_hip_msm_sw_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),

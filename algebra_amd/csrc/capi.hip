@@ -296,6 +296,41 @@ int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_fi
   return 0;
 }
 
+// ---- device memory for hosts without their own HIP binding (the Rust shim keeps an SRS resident this way) ----
+int ark_hip_malloc(size_t bytes, void** out_dptr) {
+  if (!out_dptr) return ARK_HIP_ERR_ARG;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  *out_dptr = nullptr;
+  if (bytes == 0) return 0;
+  if (hipMalloc(out_dptr, bytes) != hipSuccess) return ARK_HIP_ERR_NOMEM;
+  return 0;
+}
+int ark_hip_free(void* dptr) {
+  if (!dptr) return 0;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  ARK_HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+  ARK_HIP_TRY(hipFree(dptr));
+  return 0;
+}
+int ark_hip_memcpy_h2d(void* dst_dptr, const void* src_host, size_t bytes) {
+  if (bytes && (!dst_dptr || !src_host)) return ARK_HIP_ERR_ARG;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  ARK_HIP_TRY(hipMemcpyAsync(dst_dptr, src_host, bytes, hipMemcpyHostToDevice, g_ctx->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+  return 0;
+}
+int ark_hip_memcpy_d2h(void* dst_host, const void* src_dptr, size_t bytes) {
+  if (bytes && (!dst_host || !src_dptr)) return ARK_HIP_ERR_ARG;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  ARK_HIP_TRY(hipMemcpyAsync(dst_host, src_dptr, bytes, hipMemcpyDeviceToHost, g_ctx->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+  return 0;
+}
+
 int ark_hip_curve_generator(int curve, uint64_t* out_xy) {
   if (!out_xy) return ARK_HIP_ERR_ARG;
   const uint64_t* g = nullptr;

@@ -46,6 +46,13 @@ const char* ark_hip_version(void);
 /* u64 words per base-field element (4, 6 or 12), scalar field id, base field id, extension degree */
 int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_field, int* ext_degree);
 
+/* Device memory for hosts that have no HIP binding of their own: upload a fixed base set (an SRS) once with
+ * ark_hip_malloc + ark_hip_memcpy_h2d and pass the device pointer to ark_hip_msm_sw_device for every proof. */
+int ark_hip_malloc(size_t bytes, void** out_dptr);
+int ark_hip_free(void* dptr);
+int ark_hip_memcpy_h2d(void* dst_dptr, const void* src_host, size_t bytes);
+int ark_hip_memcpy_d2h(void* dst_host, const void* src_dptr, size_t bytes);
+
 /* SWCurveConfig::GENERATOR (e.g. curves/bls12_381/src/curves/g1.rs:199-205) as Affine limbs */
 int ark_hip_curve_generator(int curve, uint64_t* out_xy);
 

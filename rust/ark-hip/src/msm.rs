@@ -112,3 +112,49 @@ hip_sw_config!(HipBls12_377G2Config, ark_bls12_377::g2::Config, crate::sys::BLS1
 // So that `ark_ec::...` paths used above resolve without the user importing them.
 #[allow(unused_imports)]
 use {CurveConfig as _, VariableBaseMSM as _};
+
+/// A base set (an SRS) kept in GPU memory across MSMs: uploaded once, then every `msm_bigint` call moves only the
+/// scalars (what `ChunkedPippenger` / a prover's commit loop wants).
+pub struct ResidentBases<P: HipCurve> {
+    d_bases: *mut core::ffi::c_void,
+    d_scalars: *mut core::ffi::c_void,
+    n: usize,
+    _p: core::marker::PhantomData<P>,
+}
+impl<P: HipCurve> ResidentBases<P> {
+    pub fn upload(bases: &[Affine<P>]) -> Option<Self> {
+        if !layout_ok::<P>() {
+            return None;
+        }
+        let (mut db, mut ds) = (core::ptr::null_mut(), core::ptr::null_mut());
+        let bytes = core::mem::size_of_val(bases);
+        unsafe {
+            if sys::ark_hip_malloc(bytes, &mut db) != 0 || sys::ark_hip_malloc(bases.len() * 32, &mut ds) != 0 {
+                return None;
+            }
+            if sys::ark_hip_memcpy_h2d(db, bases.as_ptr() as *const _, bytes) != 0 {
+                return None;
+            }
+        }
+        Some(Self { d_bases: db, d_scalars: ds, n: bases.len(), _p: core::marker::PhantomData })
+    }
+    pub fn msm_bigint(&self, bigints: &[BigInt<4>]) -> Option<Projective<P>> {
+        let n = self.n.min(bigints.len());
+        let mut out = core::mem::MaybeUninit::<Projective<P>>::uninit();
+        let rc = unsafe {
+            if sys::ark_hip_memcpy_h2d(self.d_scalars, bigints.as_ptr() as *const _, n * 32) != 0 {
+                return None;
+            }
+            sys::ark_hip_msm_sw_device(P::CURVE_ID, self.d_bases, self.d_scalars, n, 0, out.as_mut_ptr() as *mut u64)
+        };
+        (rc == 0).then(|| unsafe { out.assume_init() })
+    }
+}
+impl<P: HipCurve> Drop for ResidentBases<P> {
+    fn drop(&mut self) {
+        unsafe {
+            sys::ark_hip_free(self.d_bases);
+            sys::ark_hip_free(self.d_scalars);
+        }
+    }
+}

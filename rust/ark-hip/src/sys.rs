@@ -38,6 +38,10 @@ extern "C" {
                           scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_msm_sw_device(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,
                                  scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_malloc(bytes: usize, out_dptr: *mut *mut c_void) -> c_int;
+    pub fn ark_hip_free(dptr: *mut c_void) -> c_int;
+    pub fn ark_hip_memcpy_h2d(dst_dptr: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
+    pub fn ark_hip_memcpy_d2h(dst_host: *mut c_void, src_dptr: *const c_void, bytes: usize) -> c_int;
     pub fn ark_hip_sw_sum(curve: c_int, jac_points: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_fft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;
     pub fn ark_hip_ifft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;

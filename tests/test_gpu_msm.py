@@ -251,3 +251,29 @@ def test_msm_random_sizes_fuzz(cname):
         got = A.msm_bigint(cid, bases_all[off:off + n], scalars)
         exp = O.msm(cid, bases_all[off:off + n], scalars, O.WNAF, 8)
         assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp)), (cname, n)
+
+
+def test_resident_bases_through_the_c_abi_only():
+    # what the Rust shim does for a fixed SRS: ark_hip_malloc + ark_hip_memcpy_h2d once, then
+    # ark_hip_msm_sw_device with raw device pointers for every scalar vector (no torch involved)
+    import ctypes as C
+    from algebra_amd._lib import check, lib
+    L = lib()
+    cid = O.CID["BLS12_381_G1"]
+    n = 3000
+    bases = O.gen_bases(cid, A4, B4, n)
+    d_bases, d_scalars = C.c_void_p(), C.c_void_p()
+    check(L.ark_hip_malloc(bases.nbytes, C.byref(d_bases)), "malloc")
+    check(L.ark_hip_malloc(n * 32, C.byref(d_scalars)), "malloc")
+    check(L.ark_hip_memcpy_h2d(d_bases, bases.ctypes.data_as(C.c_void_p), bases.nbytes), "h2d")
+    back = np.zeros_like(bases)
+    check(L.ark_hip_memcpy_d2h(back.ctypes.data_as(C.c_void_p), d_bases, bases.nbytes), "d2h")
+    assert np.array_equal(back, bases)
+    for seed in (1, 2):
+        scalars = O.gen_scalars(sf(cid), seed, n)
+        check(L.ark_hip_memcpy_h2d(d_scalars, scalars.ctypes.data_as(C.c_void_p), scalars.nbytes), "h2d")
+        out = np.zeros(18, dtype=np.uint64)
+        check(L.ark_hip_msm_sw_device(cid, d_bases, d_scalars, n, 0, out.ctypes.data_as(C.c_void_p)), "msm")
+        assert np.array_equal(A.into_affine(cid, out), O.to_affine(cid, O.msm(cid, bases, scalars, O.SIGNED, 4)))
+    check(L.ark_hip_free(d_bases), "free")
+    check(L.ark_hip_free(d_scalars), "free")
