@@ -44,10 +44,17 @@ namespace arkhip {
 
 static constexpr u32 KEY_NONE = 0xffffffffu;
 
+// Window widths: W windows of c bits, except that the top `narrow` windows are c-1 bits wide, so that the widths
+// add up to the scalar's bit length exactly and no window is left with only a few significant bits.
+__host__ __device__ __forceinline__ int msm_window_width(int w, int c, int W, int narrow) {
+  return w >= W - narrow ? c - 1 : c;
+}
+
 // ---- K1: signed-digit recoding -------------------------------------------------------------------
 template <class SP>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__ scalars, u32 n, int mont, int c,
-                                                         int W, u32* __restrict__ keys, u32* __restrict__ err) {
+                                                         int W, int narrow, u32* __restrict__ keys,
+                                                         u32* __restrict__ err) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   typedef Fp<SP> S;
@@ -74,21 +81,22 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
   for (int k = 0; k < S::N; k++) v[k] = lt ? t[k] : s.l[k];
   v[S::N] = 0;
   const u32 flip = lt ? 0x80000000u : 0u;
-  const u32 mask = (1u << c) - 1u;
-  const u32 half = 1u << (c - 1);
   u32 carry = 0;
   for (int w = 0; w < W; w++) {
+    const int cw = msm_window_width(w, c, W, narrow);  // this window's width
+    const u32 mask = (1u << cw) - 1u;
+    const u32 half = 1u << (cw - 1);
     u32 raw = (v[0] & mask) + carry;
-    // shift the 256-bit register right by c (c < 32)
+    // shift the 256-bit register right by cw (cw < 32)
 #pragma unroll
-    for (int k = 0; k < S::N; k++) v[k] = (v[k] >> c) | (v[k + 1] << (32 - c));
+    for (int k = 0; k < S::N; k++) v[k] = (v[k] >> cw) | (v[k + 1] << (32 - cw));
     u32 key = KEY_NONE;
     if (w < W - 1) {
       carry = raw >= half ? 1u : 0u;  // mod.rs:783-786: carry = (digit + radix/2) >> c
     } else {
       carry = 0;
     }
-    int d = (int)raw - (int)(carry << c);
+    int d = (int)raw - (int)(carry << cw);
     if (d != 0) {
       u32 mag = d < 0 ? (u32)(-d) : (u32)d;
       if (mag > half) {  // only reachable for a scalar >= 2^BITS, which the reference does not accept either
@@ -502,10 +510,13 @@ __global__ void __launch_bounds__(256) msm_reduce_bits_kernel(const char* __rest
 
 // ---- host-side plan / workspace -----------------------------------------------------------------
 struct MsmPlan {
-  int c;          // window bits
+  int c;          // window bits (widest windows)
   int W;          // windows
-  size_t nb;      // buckets over all windows = W << (c-1)
+  int narrow;     // the top `narrow` windows are c-1 bits wide, so that the widths sum to bits exactly and no
+                  // window is left with only a few significant bits (0: uniform widths)
+  size_t nb;      // bucket slots over all windows = W << (c-1)
 };
+
 
 // relative cost of one base-field product (Fp384 = 1): Fp256 ~0.5, Fp2 over Fp384 ~3.3
 static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 3.3 : 1.0); }
@@ -521,16 +532,31 @@ static inline int msm_scalar_bits(int curve_id) {
 // (profiles/): mixed additions stream at ~5.5e9/s (Fp384; scaled by `mul_cost` for other fields) but a
 // single bucket is a serial chain (~14 us per addition on a lightly loaded SIMD), the first reduction
 // level costs 2 full additions per bucket, the bit-sliced remainder ~0.5 ms.
+static inline void msm_window_layout(int c, int bits, int* W, int* narrow) {
+  // signed digits of a (bits-1)-bit value (after the s -> r-s fold) need bits significant positions in total
+  // (the top window is not recoded and must keep one spare bit).  W windows of c bits, the top `narrow` of them
+  // one bit narrower so that the widths add up exactly.
+  int w = (bits + c - 1) / c;
+  int deficit = w * c - bits;
+  if (deficit > w || c < 3) {  // cannot be spread one bit per window: uniform widths, sparse top window
+    *W = (bits + 1 + c - 1) / c;
+    *narrow = 0;
+    return;
+  }
+  *W = w;
+  *narrow = deficit;
+}
 static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost = 1.0) {
-  int best_c = 2;
+  int best_c = 3;
   double best = 1e300;
   const char* env = getenv("ARK_HIP_MSM_C");
-  if (env && atoi(env) >= 2 && atoi(env) <= 24) {
+  if (env && atoi(env) >= 3 && atoi(env) <= 24) {
     best_c = atoi(env);
   } else {
-    for (int c = 2; c <= 23; c++) {
-      const int W = (bits + 1 + c - 1) / c;
-      const double nbk = (double)W * (double)(1u << (c - 1));
+    for (int c = 3; c <= 23; c++) {
+      int W, narrow;
+      msm_window_layout(c, bits, &W, &narrow);
+      const double nbk = (double)(W - narrow) * (double)(1u << (c - 1)) + (double)narrow * (double)(1u << (c - 2));
       const double entries = (double)n * W;
       const double madd = 1.0 / 5.5e9 * mul_cost, fadd = 1.4 / 5.5e9 * mul_cost;
       double acc = entries * madd;
@@ -542,16 +568,22 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost = 1.0) {
       const double bits_stage = 0.5e-3 * mul_cost;              // bit-sliced stage + host tail
       const double sort = entries * 2.0e-11 + nbk * 1.0e-10;
       double cost = acc + red0 + bits_stage + sort;
-      // A top window with only a few significant bits (after the s -> r-s fold the scalar has bits-1 of them)
-      // funnels n/2^tb points into each of 2^tb buckets: correct (heavy-bucket path) but measured ~1.4x slower.
-      const int tb = (bits - 1) - (W - 1) * c;
-      if (tb >= 1 && tb <= 5) cost *= 1.4;
+      if (narrow == 0) {
+        // uniform widths: a top window with only a few significant bits funnels n/2^tb points into each of 2^tb
+        // buckets: correct (heavy-bucket path) but measured ~1.4x slower.
+        const int tb = (bits - 1) - (W - 1) * c;
+        if (tb >= 1 && tb <= 5) cost *= 1.4;
+      }
       if (cost < best) { best = cost; best_c = c; }
     }
   }
   MsmPlan p;
   p.c = best_c;
-  p.W = (bits + 1 + best_c - 1) / best_c;
+  msm_window_layout(best_c, bits, &p.W, &p.narrow);
+  if (getenv("ARK_HIP_MSM_UNIFORM")) {  // A/B knob: the older uniform-width layout
+    p.W = (bits + 1 + best_c - 1) / best_c;
+    p.narrow = 0;
+  }
   p.nb = (size_t)p.W << (best_c - 1);
   return p;
 }
@@ -685,7 +717,7 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   ARK_HIP_TRY(hipMemsetAsync(ws.err.p, 0, 4, stream));
   const u32 nblk = (u32)((n + 255) / 256);
   hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
-                     (u32)n, scalars_mont, c, W, keys, (u32*)ws.err.p);
+                     (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.err.p);
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[1], stream));
   // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
   hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
@@ -804,8 +836,10 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   };
   Pt total = Pt::zero();
   for (int w = W - 1; w >= 0; w--) {
-    if (w != W - 1)
-      for (int k = 0; k < c; k++) total = xyzz_dbl<F>(total);
+    if (w != W - 1) {
+      const int cw = msm_window_width(w, c, W, pl.narrow);  // weight of window w+1 over window w
+      for (int k = 0; k < cw; k++) total = xyzz_dbl<F>(total);
+    }
     Pt u = Pt::zero();
     for (int b2 = nbits - 1; b2 >= 0; b2--) {
       u = xyzz_dbl<F>(u);
