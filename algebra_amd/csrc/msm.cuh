@@ -508,6 +508,22 @@ __global__ void __launch_bounds__(256) msm_reduce_bits_kernel(const char* __rest
     acc.store(partial + (((size_t)w * gridDim.y + q) * gridDim.x + ch) * Pt::BYTES);
 }
 
+// sums the `nchunks` chunk partials of every (window, quantity) pair: one lane each (nchunks <= 16)
+template <class C>
+__global__ void __launch_bounds__(64) msm_sum_chunks_kernel(const char* __restrict__ partial, u32 npairs, u32 nchunks,
+                                                            char* __restrict__ out) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npairs) return;
+  Pt acc = Pt::load(partial + (size_t)t * nchunks * Pt::BYTES);
+  for (u32 k = 1; k < nchunks; k++) {
+    Pt x = Pt::load(partial + ((size_t)t * nchunks + k) * Pt::BYTES);
+    xyzz_add<F>(acc, x);
+  }
+  acc.store(out + (size_t)t * Pt::BYTES);
+}
+
 // ---- host-side plan / workspace -----------------------------------------------------------------
 struct MsmPlan {
   int c;          // window bits (widest windows)
@@ -816,7 +832,15 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
     hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, W), dim3(rthreads), rthreads * Pt::BYTES, stream,
                        (const char*)ws.lvlS[0].p, (const char*)ws.lvlA[0].p, (u32)m, nbits, chunk, (char*)ws.lvlS[1].p);
   }
-  ARK_HIP_TRY(hipMemcpyAsync(ws.pinned, ws.lvlS[1].p, npart * Pt::BYTES, hipMemcpyDeviceToHost, stream));
+  const size_t npairs = (size_t)W * Q;
+  const char* d_sums = (const char*)ws.lvlS[1].p;
+  if (nchunks > 1) {
+    if (ws.lvlA[1].ensure(npairs * Pt::BYTES)) return -3;
+    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)((npairs + 63) / 64)), dim3(64), 0, stream,
+                       (const char*)ws.lvlS[1].p, (u32)npairs, nchunks, (char*)ws.lvlA[1].p);
+    d_sums = (const char*)ws.lvlA[1].p;
+  }
+  ARK_HIP_TRY(hipMemcpyAsync(ws.pinned, d_sums, npairs * Pt::BYTES, hipMemcpyDeviceToHost, stream));
   u32* h_err = (u32*)((char*)ws.pinned + npart * Pt::BYTES);
   ARK_HIP_TRY(hipMemcpyAsync(h_err, ws.err.p, 4, hipMemcpyDeviceToHost, stream));
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[5], stream));
@@ -824,16 +848,9 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   ARK_HIP_TRY(hipGetLastError());
   if (*h_err) return -4;  // scalar out of range
 
-  // host tail (serial chains, ~0.2 ms):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(c w) T_w
+  // host tail (serial chains, ~0.3 ms):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(width) T_w
   // (window combine of mod.rs:489-502, high to low)
-  auto part_at = [&](int w, u32 q) {
-    Pt s = Pt::zero();
-    for (u32 ch = 0; ch < nchunks; ch++) {
-      Pt x = Pt::load((const char*)ws.pinned + (((size_t)w * Q + q) * nchunks + ch) * Pt::BYTES);
-      xyzz_add<F>(s, x);
-    }
-    return s;
-  };
+  auto part_at = [&](int w, u32 q) { return Pt::load((const char*)ws.pinned + ((size_t)w * Q + q) * Pt::BYTES); };
   Pt total = Pt::zero();
   for (int w = W - 1; w >= 0; w--) {
     if (w != W - 1) {
