@@ -803,6 +803,10 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
     while (p2 < want) p2 <<= 1;
     if (p2 < 8) p2 = 8;
     if (p2 < L0) L0 = p2;
+    if (const char* e0 = getenv("ARK_HIP_MSM_L0")) {  // tuning knob
+      int v = atoi(e0);
+      if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L0 = (u32)v;
+    }
     while (L0 > mwin) L0 >>= 1;
   }
   const size_t m = mwin / L0;  // pairs per window after level 0
