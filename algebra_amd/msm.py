@@ -134,3 +134,41 @@ class ChunkedPippenger:
             return msm_bigint(self.curve, np.zeros((0, cv.affine_words(self.curve)), dtype=np.uint64),
                               np.zeros((0, 4), dtype=np.uint64))
         return self._result
+
+
+def _small_to_bigint(values, signed_ok=False):
+    v = np.asarray(values)
+    if v.dtype == np.bool_:
+        v = v.astype(np.uint64)
+    if not np.issubdtype(v.dtype, np.unsignedinteger):
+        raise TypeError("msm_u*: unsigned integer (or bool) scalars expected")
+    out = np.zeros((v.size, 4), dtype=np.uint64)
+    out[:, 0] = v.astype(np.uint64).reshape(-1)
+    return out
+
+
+def msm_u1(curve, bases, scalars):
+    """VariableBaseMSM::msm_u1 (variable_base/mod.rs:89-93): boolean scalars.  On the device these are ordinary
+    1-bit scalars: every point with a set bit lands in bucket 0 of window 0 (heavy-bucket path), the other
+    windows are empty."""
+    return msm_bigint(curve, bases, _small_to_bigint(scalars))
+
+
+def msm_u8(curve, bases, scalars):
+    """VariableBaseMSM::msm_u8 (mod.rs:95-99)."""
+    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint8)))
+
+
+def msm_u16(curve, bases, scalars):
+    """VariableBaseMSM::msm_u16 (mod.rs:101-105)."""
+    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint16)))
+
+
+def msm_u32(curve, bases, scalars):
+    """VariableBaseMSM::msm_u32 (mod.rs:107-111)."""
+    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint32)))
+
+
+def msm_u64(curve, bases, scalars):
+    """VariableBaseMSM::msm_u64 (mod.rs:113-117)."""
+    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint64)))

@@ -277,3 +277,21 @@ def test_resident_bases_through_the_c_abi_only():
         assert np.array_equal(A.into_affine(cid, out), O.to_affine(cid, O.msm(cid, bases, scalars, O.SIGNED, 4)))
     check(L.ark_hip_free(d_bases), "free")
     check(L.ark_hip_free(d_scalars), "free")
+
+
+def test_msm_specialized_small_scalar_entry_points():
+    # test_var_base_msm_specialized (test-templates/src/msm.rs:74-110): msm_u1/u8/u16/u32/u64 vs the naive sum
+    cid = O.CID["BLS12_381_G1"]
+    n = 5 << 10
+    bases = O.gen_bases(cid, A4, B4, n)
+    rng = np.random.default_rng(77)
+    cases = [(A.msm_u1, rng.integers(0, 2, size=n).astype(bool)),
+             (A.msm_u8, rng.integers(0, 1 << 8, size=n, dtype=np.uint64).astype(np.uint8)),
+             (A.msm_u16, rng.integers(0, 1 << 16, size=n, dtype=np.uint64).astype(np.uint16)),
+             (A.msm_u32, rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)),
+             (A.msm_u64, rng.integers(0, 1 << 63, size=n, dtype=np.uint64))]
+    for fn, sc in cases:
+        big = np.zeros((n, 4), dtype=np.uint64)
+        big[:, 0] = sc.astype(np.uint64)
+        exp = O.msm(cid, bases, big, O.SIGNED, 8)
+        assert np.array_equal(A.into_affine(cid, fn(cid, bases, sc)), O.to_affine(cid, exp)), fn.__name__
