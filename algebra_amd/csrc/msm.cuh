@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
   }
 }
 
+// one wave per heavy bucket: lanes stride over its chunk partials, then a 6-step LDS tree
 template <class C>
 __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __restrict__ ctr,
                                                                const HeavyEntry* __restrict__ list,
@@ -348,15 +349,27 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __rest
                                                                char* __restrict__ buckets) {
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
-  u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= ctr[1]) return;
+  extern __shared__ uint4 heavy_lds[];
+  char* sh = (char*)heavy_lds;
+  const u32 slot = blockIdx.x, lane = threadIdx.x;
+  if (slot >= ctr[1]) return;  // uniform for the whole workgroup
   HeavyEntry h = list[slot];
   Pt acc = Pt::zero();
-  for (u32 q = 0; q < h.items; q++) {
+  for (u32 q = lane; q < h.items; q += 64) {
     Pt x = Pt::load(partials + (size_t)(h.first_item + q) * Pt::BYTES);
     xyzz_add<F>(acc, x);
   }
-  acc.store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
+  acc.store(sh + (size_t)lane * Pt::BYTES);
+  __syncthreads();
+  for (u32 o = 32; o > 0; o >>= 1) {
+    if (lane < o) {
+      Pt other = Pt::load(sh + (size_t)(lane + o) * Pt::BYTES);
+      xyzz_add<F>(acc, other);
+      acc.store(sh + (size_t)lane * Pt::BYTES);
+    }
+    __syncthreads();
+  }
+  if (lane == 0) acc.store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
 }
 
 // ---- K4 (lazy form): base conversion pre-pass + bucket accumulation in 28-bit limbs -------------------
@@ -790,7 +803,7 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
     const u32 hthreads = Pt::BYTES > 192 ? 128 : 256;  // one 64-lane LDS tree per wave, 48 KiB per workgroup
     hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), hthreads * Pt::BYTES, stream,
                        (const char*)d_bases, sorted, offsets, hctr, (const uint2*)ws.hitems.p, (char*)ws.hpart.p);
-    hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3((u32)((max_heavy + 63) / 64)), dim3(64), 0, stream, hctr,
+    hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3((u32)max_heavy), dim3(64), 64 * Pt::BYTES, stream, hctr,
                        (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, (char*)ws.buckets.p);
   }
   if (tm) ARK_HIP_TRY(hipEventRecord(ev[4], stream));
