@@ -431,6 +431,34 @@ int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r
   return ARK_HIP_ERR_ARG;
 }
 
+// out = base^exp in Fr (host arithmetic): domain elements / twiddles for hosts without field code of their own
+int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out) {
+  if (!base || !out) return ARK_HIP_ERR_ARG;
+  uint64_t e[1] = {exp};
+  switch (field) {
+    case ARK_HIP_BN254_FR: host_pow<BN254_FR>(Fp<BN254_FR>::load(base), e, 1).store(out); return 0;
+    case ARK_HIP_BLS12_381_FR: host_pow<BLS12_381_FR>(Fp<BLS12_381_FR>::load(base), e, 1).store(out); return 0;
+    case ARK_HIP_BLS12_377_FR: host_pow<BLS12_377_FR>(Fp<BLS12_377_FR>::load(base), e, 1).store(out); return 0;
+  }
+  return ARK_HIP_ERR_ARG;
+}
+
+// G-point transform along the slow axis of a [G][cols] array in device memory: the cross-GPU stage of a
+// sharded FFT (algebra_amd/dist.py).  root = primitive G-th root of unity to use (w_n^(n/G) or its inverse).
+int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, const uint64_t* root) {
+  if (!d_data || !root) return ARK_HIP_ERR_ARG;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  switch (field) {
+#ifndef ARK_HIP_DEV
+    case ARK_HIP_BN254_FR: return fft_axis_BN254_FR(g_ctx->fft, d_data, G, cols, root, g_ctx->stream);
+    case ARK_HIP_BLS12_377_FR: return fft_axis_BLS12_377_FR(g_ctx->fft, d_data, G, cols, root, g_ctx->stream);
+#endif
+    case ARK_HIP_BLS12_381_FR: return fft_axis_BLS12_381_FR(g_ctx->fft, d_data, G, cols, root, g_ctx->stream);
+  }
+  return ARK_HIP_ERR_ARG;
+}
+
 int ark_hip_fft_set_timing(int enable) {
   int rc = ensure_ctx();
   if (rc) return rc;

@@ -257,6 +257,43 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
   }
 }
 
+// ---- G-point transform along the slow axis of a [G][cols] array (multi-GPU exchange step) ----------------
+// out[j][c] = sum_i root^(i j) in[i][c], natural order in and out, G in {2,4,8,16}.  One lane per column: the G
+// values travel through registers (radix-2 decimation in frequency, then a bit-reversed write-back).
+// `pw` holds root^k for k < G/2.
+template <class FP, int G>
+__global__ void __launch_bounds__(256) fft_axis_kernel(u32* __restrict__ data, size_t cols, const u32* __restrict__ pw) {
+  typedef Fp<FP> F;
+  size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  F v[G];
+#pragma unroll
+  for (int i = 0; i < G; i++) v[i] = F::load(data + ((size_t)i * cols + c) * F::N);
+#pragma unroll
+  for (int gap = G / 2; gap >= 1; gap >>= 1) {
+#pragma unroll
+    for (int base = 0; base < G; base += 2 * gap) {
+#pragma unroll
+      for (int j = 0; j < gap; j++) {
+        F lo = v[base + j], hi = v[base + j + gap];
+        v[base + j] = F::add(lo, hi);
+        F d = F::sub(lo, hi);
+        const int tw = j * (G / (2 * gap));  // root^(j * G/(2 gap))
+        if (tw != 0) d = F::mul(d, F::load(pw + (size_t)tw * F::N));
+        v[base + j + gap] = d;
+      }
+    }
+  }
+  constexpr int LG = G == 2 ? 1 : (G == 4 ? 2 : (G == 8 ? 3 : 4));
+#pragma unroll
+  for (int i = 0; i < G; i++) {
+    int r = 0;
+#pragma unroll
+    for (int b = 0; b < LG; b++) r |= ((i >> b) & 1) << (LG - 1 - b);
+    v[i].store(data + ((size_t)r * cols + c) * F::N);  // position i holds X[bitrev(i)]
+  }
+}
+
 // ---- host side: cached twiddle tables + pass plan ------------------------------------------------
 struct FftTables {
   DevBuf roots;   // n/2 entries
@@ -284,6 +321,30 @@ struct FftWorkspace {
   }
 };
 struct FftTimings { float total = 0; float pass[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int npass = 0; };
+
+template <class FP>
+int fft_axis_run(FftWorkspace& ws, void* d_data, unsigned G, size_t cols, const uint64_t* root4, hipStream_t stream) {
+  typedef Fp<FP> F;
+  std::lock_guard<std::mutex> lock(ws.mu);
+  if (G == 1 || cols == 0) return 0;
+  if (G != 2 && G != 4 && G != 8 && G != 16) return -2;
+  if (ws.pw.ensure((2 * (((size_t)1 << PW_LO_BITS) + 1) + 3 + 16) * F::BYTES)) return -3;
+  u32* d_root = (u32*)ws.pw.p;
+  u32* d_pw = d_root + F::N;
+  ARK_HIP_TRY(hipMemcpyAsync(d_root, root4, F::BYTES, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3(1), dim3(256), 0, stream, d_root, (u64)1, (u32)(G / 2),
+                     (const u32*)nullptr, d_pw);
+  const unsigned blocks = (unsigned)((cols + 255) / 256);
+  switch (G) {
+    case 2: hipLaunchKernelGGL((fft_axis_kernel<FP, 2>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
+    case 4: hipLaunchKernelGGL((fft_axis_kernel<FP, 4>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
+    case 8: hipLaunchKernelGGL((fft_axis_kernel<FP, 8>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
+    default: hipLaunchKernelGGL((fft_axis_kernel<FP, 16>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
+  }
+  ARK_HIP_TRY(hipStreamSynchronize(stream));  // root4 is caller memory; pw is shared scratch
+  return 0;
+}
+
 
 template <class FP>
 int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t stream, const u32** out) {

@@ -10,4 +10,7 @@ int fft_run_BLS12_381_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* 
 int test_field_op_BLS12_381_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<Fp<BLS12_381_FR>, true>(op, a, b, r, n, s);
 }
+int fft_axis_BLS12_381_FR(FftWorkspace& ws, void* d_data, unsigned G, size_t cols, const uint64_t* root4, hipStream_t s) {
+  return fft_axis_run<BLS12_381_FR>(ws, d_data, G, cols, root4, s);
+}
 }  // namespace arkhip

@@ -27,7 +27,8 @@ ARK_DECL_CURVE(BLS12_381_G2)
 #define ARK_DECL_FIELD(NAME)                                                                                    \
   int fft_run_##NAME(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4,         \
                      const uint64_t* post4, const uint64_t* postc4, hipStream_t stream, FftTimings* tm);          \
-  int test_field_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);
+  int test_field_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);          \
+  int fft_axis_##NAME(FftWorkspace& ws, void* d_data, unsigned G, size_t cols, const uint64_t* root4, hipStream_t s);
 ARK_DECL_FIELD(BN254_FR)
 ARK_DECL_FIELD(BLS12_381_FR)
 ARK_DECL_FIELD(BLS12_377_FR)

@@ -121,6 +121,11 @@ int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, vo
  * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
  * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */
 int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
+/* ---- multi-GPU FFT building blocks (the exchange itself is the host's: RCCL all-to-all, algebra_amd/dist.py) ----
+ * base^exp in Fr on the host (twiddle w_n^j for the per-rank coset), and the G-point transform along the slow
+ * axis of a [G][cols] device array (G = 2, 4, 8 or 16): out[j][c] = sum_i root^(i j) in[i][c]. */
+int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out);
+int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, const uint64_t* root);
 int ark_hip_fft_set_timing(int enable);
 /* [total_ms, npass, pass0_ms, pass1_ms, ...] of the last timed device transform */
 int ark_hip_fft_last_timing(double out[10]);
