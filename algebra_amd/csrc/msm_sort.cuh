@@ -26,7 +26,7 @@
 
 namespace arkhip {
 
-static constexpr int PART_LO_BITS = 10;        // buckets per super-bucket = 2^10
+static constexpr int PART_LO_BITS = 10;        // buckets per super-bucket = 2^10 (2^9 measured no better)
 static constexpr int PART_TILE = 8192;         // keys per workgroup in pass A (64 KiB of staged pairs)
 static constexpr u32 PART_KEY_NONE = 0xffffffffu;
 
