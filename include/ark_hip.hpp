@@ -1,0 +1,189 @@
+// ark_hip.hpp -- C++17 host-side mirror of the two reference interfaces that libark_hip.so replaces, written over
+// the C ABI of ark_hip.h (header only).  The reference is Rust; this image has no Rust toolchain, so this header is
+// the compiled-language host side (the same surface exists as Rust source in rust/ark-hip/ and as a Python mirror
+// in algebra_amd/).  Names, argument meaning and error behaviour follow the reference:
+//
+//   ark_hip::VariableBaseMSM<Curve>      <- ark_ec::VariableBaseMSM for Projective<P>
+//        msm(bases, scalars)   -> Result: Err(min_len) when the lengths differ   (ec/src/scalar_mul/variable_base/mod.rs:67-78,
+//                                                                                  short_weierstrass/mod.rs:112-119)
+//        msm_unchecked(...)    -> truncates to the shorter input                   (mod.rs:59-64)
+//        msm_bigint(...)       -> scalars are canonical BigInt<4>                  (mod.rs:80-85)
+//   ark_hip::Radix2EvaluationDomain<F>   <- ark_poly::Radix2EvaluationDomain<F> / EvaluationDomain<F>
+//        new_(num_coeffs) -> optional (None when log2(size) > TWO_ADICITY)         (poly/src/domain/radix2/mod.rs:55-83)
+//        get_coset, size, log_size_of_group, size_inv, group_gen, group_gen_inv, coset_offset, coset_offset_inv,
+//        coset_offset_pow_size, fft, fft_in_place, ifft, ifft_in_place             (radix2/mod.rs:85-153, domain/mod.rs:92-112)
+//
+// Element types are plain limb arrays in the reference's in-memory layout (Montgomery, little-endian u64 limbs).
+#pragma once
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <vector>
+#include "ark_hip.h"
+
+namespace ark_hip {
+
+// ---- element types ------------------------------------------------------------------------------------------------
+template <int WORDS>
+struct FieldElement {  // Fp (WORDS = 4 or 6) or Fp2 (WORDS = 12): c0 | c1
+  std::array<uint64_t, WORDS> limbs{};
+  bool operator==(const FieldElement& o) const { return limbs == o.limbs; }
+  bool is_zero() const {
+    for (auto l : limbs)
+      if (l) return false;
+    return true;
+  }
+};
+using Fr = FieldElement<4>;      // scalar-field element (Montgomery)
+using BigInt4 = FieldElement<4>; // canonical 256-bit integer (PrimeField::BigInt)
+
+template <int WORDS>
+struct Affine {  // short_weierstrass::Affine with ZeroFlag = (): identity is (0, 0)
+  FieldElement<WORDS> x, y;
+  bool is_zero() const { return x.is_zero() && y.is_zero(); }
+  bool operator==(const Affine& o) const { return x == o.x && y == o.y; }
+};
+template <int WORDS>
+struct Projective {  // Jacobian (x, y, z)
+  FieldElement<WORDS> x, y, z;
+};
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const char* what) : std::runtime_error(what), code(c) {}
+};
+inline void check(int rc, const char* what) {
+  if (rc != 0) throw Error(rc, what);
+}
+
+// ---- curve tags -----------------------------------------------------------------------------------------------------
+template <int CURVE_ID, int FE_WORDS, int SCALAR_FIELD_ID>
+struct CurveTag {
+  static constexpr int ID = CURVE_ID;
+  static constexpr int WORDS = FE_WORDS;
+  static constexpr int SCALAR_FIELD = SCALAR_FIELD_ID;
+  using AffineT = Affine<FE_WORDS>;
+  using ProjectiveT = Projective<FE_WORDS>;
+};
+using Bn254G1 = CurveTag<ARK_HIP_BN254_G1, 4, ARK_HIP_BN254_FR>;
+using Bls12_381G1 = CurveTag<ARK_HIP_BLS12_381_G1, 6, ARK_HIP_BLS12_381_FR>;
+using Bls12_377G1 = CurveTag<ARK_HIP_BLS12_377_G1, 6, ARK_HIP_BLS12_377_FR>;
+using Bls12_377G2 = CurveTag<ARK_HIP_BLS12_377_G2, 12, ARK_HIP_BLS12_377_FR>;
+using Bls12_381G2 = CurveTag<ARK_HIP_BLS12_381_G2, 12, ARK_HIP_BLS12_381_FR>;
+
+// Result<Projective, usize> of VariableBaseMSM::msm
+template <class T>
+struct MsmResult {
+  bool ok;
+  T value;         // valid when ok
+  size_t min_len;  // the reference's Err payload when !ok
+};
+
+template <class Curve>
+struct VariableBaseMSM {
+  using A = typename Curve::AffineT;
+  using P = typename Curve::ProjectiveT;
+  static_assert(sizeof(A) == 2 * Curve::WORDS * 8 && sizeof(P) == 3 * Curve::WORDS * 8, "layout must be packed limbs");
+
+  // msm: length check, then msm_unchecked (scalars are Fr elements in Montgomery form)
+  static MsmResult<P> msm(const std::vector<A>& bases, const std::vector<Fr>& scalars) {
+    if (bases.size() != scalars.size()) return {false, P{}, bases.size() < scalars.size() ? bases.size() : scalars.size()};
+    return {true, msm_unchecked(bases, scalars), 0};
+  }
+  static P msm_unchecked(const std::vector<A>& bases, const std::vector<Fr>& scalars) {
+    return run(bases.data(), reinterpret_cast<const uint64_t*>(scalars.data()),
+               bases.size() < scalars.size() ? bases.size() : scalars.size(), 1);
+  }
+  static P msm_bigint(const std::vector<A>& bases, const std::vector<BigInt4>& bigints) {
+    return run(bases.data(), reinterpret_cast<const uint64_t*>(bigints.data()),
+               bases.size() < bigints.size() ? bases.size() : bigints.size(), 0);
+  }
+  // CurveGroup::into_affine
+  static A into_affine(const P& p) {
+    A out;
+    check(ark_hip_sw_into_affine(Curve::ID, reinterpret_cast<const uint64_t*>(&p), 1, reinterpret_cast<uint64_t*>(&out)),
+          "ark_hip_sw_into_affine");
+    return out;
+  }
+
+ private:
+  static P run(const A* bases, const uint64_t* scalars, size_t n, int montgomery) {
+    P out;
+    check(ark_hip_msm_sw(Curve::ID, reinterpret_cast<const uint64_t*>(bases), scalars, n, montgomery,
+                         reinterpret_cast<uint64_t*>(&out)),
+          "ark_hip_msm_sw");
+    return out;
+  }
+};
+
+// ---- Radix2EvaluationDomain ------------------------------------------------------------------------------------------
+template <int FIELD_ID>
+class Radix2EvaluationDomain {
+ public:
+  // EvaluationDomain::new
+  static std::optional<Radix2EvaluationDomain> new_(size_t num_coeffs) {
+    Radix2EvaluationDomain d;
+    int rc = ark_hip_radix2_domain_new(FIELD_ID, num_coeffs, &d.s_);
+    if (rc == ARK_HIP_ERR_SIZE) return std::nullopt;
+    check(rc, "ark_hip_radix2_domain_new");
+    return d;
+  }
+  std::optional<Radix2EvaluationDomain> get_coset(const Fr& offset) const {
+    Radix2EvaluationDomain d;
+    int rc = ark_hip_radix2_domain_get_coset(FIELD_ID, &s_, offset.limbs.data(), &d.s_);
+    if (rc == ARK_HIP_ERR_ARG) return std::nullopt;
+    check(rc, "ark_hip_radix2_domain_get_coset");
+    return d;
+  }
+  static std::optional<size_t> compute_size_of_domain(size_t num_coeffs) {
+    auto d = new_(num_coeffs);
+    if (!d) return std::nullopt;
+    return d->size();
+  }
+  size_t size() const { return (size_t)s_.size; }
+  uint64_t log_size_of_group() const { return s_.log_size_of_group; }
+  Fr size_as_field_element() const { return fe(s_.size_as_field_element); }
+  Fr size_inv() const { return fe(s_.size_inv); }
+  Fr group_gen() const { return fe(s_.group_gen); }
+  Fr group_gen_inv() const { return fe(s_.group_gen_inv); }
+  Fr coset_offset() const { return fe(s_.offset); }
+  Fr coset_offset_inv() const { return fe(s_.offset_inv); }
+  Fr coset_offset_pow_size() const { return fe(s_.offset_pow_size); }
+
+  // fft_in_place / ifft_in_place: the Vec is resized to the domain size (zero-extended) first, as in radix2/mod.rs:140-153
+  void fft_in_place(std::vector<Fr>& coeffs) const {
+    resize(coeffs);
+    check(ark_hip_fft_in_place(FIELD_ID, &s_, reinterpret_cast<uint64_t*>(coeffs.data())), "ark_hip_fft_in_place");
+  }
+  void ifft_in_place(std::vector<Fr>& evals) const {
+    resize(evals);
+    check(ark_hip_ifft_in_place(FIELD_ID, &s_, reinterpret_cast<uint64_t*>(evals.data())), "ark_hip_ifft_in_place");
+  }
+  std::vector<Fr> fft(const std::vector<Fr>& coeffs) const {
+    std::vector<Fr> v(coeffs);
+    fft_in_place(v);
+    return v;
+  }
+  std::vector<Fr> ifft(const std::vector<Fr>& evals) const {
+    std::vector<Fr> v(evals);
+    ifft_in_place(v);
+    return v;
+  }
+  const ark_hip_radix2_domain& raw() const { return s_; }
+
+ private:
+  ark_hip_radix2_domain s_{};
+  static Fr fe(const uint64_t* p) {
+    Fr r;
+    for (int i = 0; i < 4; i++) r.limbs[i] = p[i];
+    return r;
+  }
+  void resize(std::vector<Fr>& v) const {
+    if (v.size() > size()) throw Error(ARK_HIP_ERR_ARG, "more coefficients than the domain size");
+    v.resize(size());
+  }
+};
+
+}  // namespace ark_hip

@@ -1,0 +1,92 @@
+// Exercises include/ark_hip.hpp (the C++ mirror of VariableBaseMSM / Radix2EvaluationDomain) on the GPU and checks
+// it against the oracle.  Mirrors the reference's own tests: test_var_base_msm (test-templates/src/msm.rs:17-32),
+// the Err(min_len) contract, test_fft_correctness / round trips (poly/src/domain/radix2/mod.rs:351-391).
+// Built and run by tests/test_gpu_cpp_mirror.py (g++, links libark_hip.so and the oracle).
+#include <cstdio>
+#include <cstring>
+#include "ark_hip.hpp"
+extern "C" {
+#include "ark_oracle.h"
+}
+using namespace ark_hip;
+
+static int fails = 0;
+#define EXPECT(c, msg) do { if (!(c)) { std::printf("FAIL: %s\n", msg); fails++; } } while (0)
+
+template <class Curve>
+void check_msm(const char* name, size_t n) {
+  using M = VariableBaseMSM<Curve>;
+  const uint64_t a4[4] = {0xA11CE, 1, 2, 0}, b4[4] = {0xB0B, 3, 0, 0};
+  std::vector<typename Curve::AffineT> bases(n);
+  ark_oracle_gen_bases(Curve::ID, a4, b4, n, reinterpret_cast<uint64_t*>(bases.data()));
+  std::vector<BigInt4> big(n);
+  std::vector<Fr> mont(n);
+  ark_oracle_gen_scalars(Curve::SCALAR_FIELD, 17, n, 0, reinterpret_cast<uint64_t*>(big.data()));
+  ark_oracle_field_op(Curve::SCALAR_FIELD, 8, reinterpret_cast<const uint64_t*>(big.data()), nullptr,
+                      reinterpret_cast<uint64_t*>(mont.data()), n);  // from_bigint
+  typename Curve::ProjectiveT ref;
+  ark_oracle_msm(Curve::ID, reinterpret_cast<const uint64_t*>(bases.data()), reinterpret_cast<const uint64_t*>(big.data()),
+                 n, 2, 4, reinterpret_cast<uint64_t*>(&ref));
+  typename Curve::AffineT ref_aff;
+  ark_oracle_to_affine(Curve::ID, reinterpret_cast<const uint64_t*>(&ref), reinterpret_cast<uint64_t*>(&ref_aff), 1);
+
+  auto r1 = M::msm(bases, mont);
+  EXPECT(r1.ok && M::into_affine(r1.value) == ref_aff, name);
+  EXPECT(M::into_affine(M::msm_bigint(bases, big)) == ref_aff, name);
+  // length mismatch -> Err(min_len), nothing computed
+  std::vector<Fr> shorter(mont.begin(), mont.begin() + n / 2);
+  auto r2 = M::msm(bases, shorter);
+  EXPECT(!r2.ok && r2.min_len == n / 2, "Err(min_len)");
+  // msm_unchecked truncates
+  typename Curve::ProjectiveT ref2;
+  ark_oracle_msm(Curve::ID, reinterpret_cast<const uint64_t*>(bases.data()), reinterpret_cast<const uint64_t*>(big.data()),
+                 n / 2, 2, 4, reinterpret_cast<uint64_t*>(&ref2));
+  typename Curve::AffineT ref2_aff;
+  ark_oracle_to_affine(Curve::ID, reinterpret_cast<const uint64_t*>(&ref2), reinterpret_cast<uint64_t*>(&ref2_aff), 1);
+  EXPECT(M::into_affine(M::msm_unchecked(bases, shorter)) == ref2_aff, "msm_unchecked truncation");
+  // empty -> identity
+  EXPECT(M::into_affine(M::msm_bigint({}, {})).is_zero(), "empty msm");
+  std::printf("%s msm n=%zu checked\n", name, n);
+}
+
+template <int FIELD>
+void check_fft(const char* name, unsigned log_n) {
+  using D = Radix2EvaluationDomain<FIELD>;
+  size_t n = (size_t)1 << log_n;
+  auto dom = D::new_(n - 3);  // next power of two
+  EXPECT(dom && dom->size() == n && dom->log_size_of_group() == log_n, "domain size");
+  std::vector<Fr> x(n - 3);
+  ark_oracle_gen_scalars(FIELD, 5, n - 3, 1, reinterpret_cast<uint64_t*>(x.data()));
+  std::vector<Fr> padded(x);
+  padded.resize(n);
+  std::vector<Fr> ref(padded);
+  ark_oracle_fft(FIELD, reinterpret_cast<uint64_t*>(ref.data()), log_n, nullptr, 0, 4);
+  auto y = dom->fft(x);  // zero-extended like the reference
+  EXPECT(y.size() == n && std::memcmp(y.data(), ref.data(), n * 32) == 0, name);
+  auto back = dom->ifft(y);
+  EXPECT(std::memcmp(back.data(), padded.data(), n * 32) == 0, "ifft(fft(x)) == x");
+  // coset with offset = GENERATOR (poly/benches/fft.rs:107)
+  Fr gen;
+  ark_oracle_field_const(FIELD, 3, gen.limbs.data());
+  auto coset = dom->get_coset(gen);
+  EXPECT(coset.has_value(), "get_coset");
+  std::vector<Fr> cref(padded);
+  ark_oracle_fft(FIELD, reinterpret_cast<uint64_t*>(cref.data()), log_n, gen.limbs.data(), 0, 4);
+  auto cy = coset->fft(x);
+  EXPECT(std::memcmp(cy.data(), cref.data(), n * 32) == 0, "coset fft");
+  Fr zero;
+  EXPECT(!dom->get_coset(zero).has_value(), "zero offset -> None");
+  std::printf("%s fft 2^%u checked\n", name, log_n);
+}
+
+int main() {
+  if (ark_hip_device_count() <= 0) { std::printf("no GPU\n"); return 2; }
+  check_msm<Bls12_381G1>("BLS12_381_G1", 2000);
+  check_msm<Bn254G1>("BN254_G1", 1024);
+  check_msm<Bls12_377G2>("BLS12_377_G2", 300);
+  check_fft<ARK_HIP_BLS12_381_FR>("BLS12_381_FR", 12);
+  check_fft<ARK_HIP_BN254_FR>("BN254_FR", 9);
+  EXPECT(!Radix2EvaluationDomain<ARK_HIP_BN254_FR>::new_(((size_t)1 << 28) + 1).has_value(), "too large -> None");
+  std::printf(fails ? "FAILED (%d)\n" : "all ok\n", fails);
+  return fails ? 1 : 0;
+}
