@@ -124,3 +124,20 @@ def test_no_gpu_means_loud_failure_not_a_cpu_fallback():
     with pytest.raises(A.ArkHipError) as e:
         d.fft(np.zeros((8, 4), dtype=np.uint64))
     assert e.value.code == -5
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    # include/ark_hip.hpp is plain C++17 over the C ABI: g++ alone must build a program against it (run on the GPU by
+    # tests/test_gpu_cpp_mirror.py; here, without a GPU, the program must refuse to compute: exit code 2)
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "hmc")
+    subprocess.check_call(["g++", "-std=c++17", "-O0", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"),
+                           os.path.join(ROOT, "tests", "cpp", "host_mirror_check.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "algebra_amd"), "-lark_hip", "-L", os.path.join(ROOT, "oracle"),
+                           "-lark_oracle", "-Wl,-rpath," + os.path.join(ROOT, "algebra_amd"),
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle")], timeout=300)
+    if _lib.lib().ark_hip_device_count() == 0:
+        assert subprocess.run([exe], capture_output=True, timeout=120).returncode == 2
