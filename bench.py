@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--fft-log-n", type=int, default=22)
     ap.add_argument("--fft-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=22)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=24)
     args = ap.parse_args()
 
     import torch
@@ -303,8 +303,9 @@ def main():
         same = bool(np.array_equal(O.to_affine(O.CID[CURVE], ref),
                                    A.into_affine(cid, A.msm_bigint(cid, bases[: ns * ab], scalars[:ns]))))
         cpu = {"value": ns / cpu_s, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
-               "sample": "first 2^%d of the same bases/scalars, msm_bigint_wnaf restatement (oracle/), %.1f s; "
-                         "GPU result on the sample bit-exact: %s" % (int(np.log2(ns)), cpu_s, same)}
+               "sample": "%s 2^%d of the same bases/scalars, msm_bigint_wnaf restatement (oracle/), %.1f s; "
+                         "GPU result on the sample bit-exact: %s"
+                         % ("all" if ns == n else "first", int(np.log2(ns)), cpu_s, same)}
 
     if rank == 0:
         total_pairs = n * world * args.steps
