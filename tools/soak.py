@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""One-off soak: many MSMs / FFTs of random sizes and seeds against the oracle (looks for rare, timing-dependent
+failures in the LDS-staged kernels).  usage: python tools/soak.py [iterations]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import algebra_amd as A
+import oracle_lib as O
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(12345)
+A4 = np.array([0xA11CE, 1, 2, 0], dtype=np.uint64)
+B4 = np.array([0xB0B, 3, 0, 0], dtype=np.uint64)
+bases = {c: O.gen_bases(O.CID[c], A4, B4, 1 << 15) for c in ("BLS12_381_G1", "BN254_G1")}
+bad = 0
+for it in range(iters):
+    cname = ("BLS12_381_G1", "BN254_G1")[it % 2]
+    cid = O.CID[cname]
+    n = int(rng.integers(1, 1 << 15))
+    off = int(rng.integers(0, (1 << 15) - n + 1))
+    sc = O.gen_scalars(O.curve_info(cid)[1], 5000 + it, n)
+    kind = it % 5
+    if kind == 3:  # skewed: many small scalars
+        sc[:, 1:] = 0
+        sc[:, 0] &= np.uint64(0xFF)
+    if kind == 4:  # many equal
+        sc[::2] = sc[0]
+    got = A.into_affine(cid, A.msm_bigint(cid, bases[cname][off:off + n], sc))
+    exp = O.to_affine(cid, O.msm(cid, bases[cname][off:off + n], sc, O.SIGNED, 8))
+    if not np.array_equal(got, exp):
+        bad += 1
+        print("MSM MISMATCH", cname, n, it)
+    log_n = int(rng.integers(1, 17))
+    fname = ("BLS12_381_FR", "BN254_FR", "BLS12_377_FR")[it % 3]
+    fid = O.FID[fname]
+    x = O.gen_scalars(fid, 9000 + it, 1 << log_n, montgomery=True)
+    d = A.Radix2EvaluationDomain.new(fname, 1 << log_n)
+    if it % 2:
+        d = d.get_coset(O.field_const(fid, 3))
+    inv = bool(it % 4 >= 2)
+    got = (d.ifft(x) if inv else d.fft(x)).reshape(-1)
+    exp = O.fft(fid, x, log_n, O.field_const(fid, 3) if it % 2 else None, inv, 8)
+    if not np.array_equal(got, exp):
+        bad += 1
+        print("FFT MISMATCH", fname, log_n, it)
+print("soak: %d iterations, %d mismatches" % (iters, bad))
+sys.exit(1 if bad else 0)
