@@ -55,6 +55,7 @@ SYMBOLS = {
     "ark_hip_sw_sum": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ark_hip_sw_into_affine": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ark_hip_sw_add_affine_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ark_hip_sw_normalize_batch_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_radix2_domain_new": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(Radix2DomainStruct)]),
     "ark_hip_radix2_domain_get_coset": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p,
                                                   C.POINTER(Radix2DomainStruct)]),

@@ -526,6 +526,27 @@ int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_
   return 0;
 }
 
+// CurveGroup::normalize_batch for n Projective points in device memory -> n Affine points (device memory)
+int ark_hip_sw_normalize_batch_device(int curve, const void* d_jac, void* d_out_xy, size_t n) {
+  if (curve < 0 || curve > 4 || (n && (!d_jac || !d_out_xy))) return ARK_HIP_ERR_ARG;
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Context* c = g_ctx;
+  switch (curve) {
+#ifndef ARK_HIP_DEV
+    case 0: rc = sw_normalize_batch_BN254_G1(d_jac, d_out_xy, n, c->stream); break;
+    case 2: rc = sw_normalize_batch_BLS12_377_G1(d_jac, d_out_xy, n, c->stream); break;
+    case 3: rc = sw_normalize_batch_BLS12_377_G2(d_jac, d_out_xy, n, c->stream); break;
+    case 4: rc = sw_normalize_batch_BLS12_381_G2(d_jac, d_out_xy, n, c->stream); break;
+#endif
+    case 1: rc = sw_normalize_batch_BLS12_381_G1(d_jac, d_out_xy, n, c->stream); break;
+    default: return ARK_HIP_ERR_ARG;
+  }
+  if (rc) return rc;
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ---- test hooks ----
 static int run_elementwise(size_t abytes, size_t bbytes, size_t rbytes, const void* a, const void* b, void* r,
                            int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t), int op, size_t n) {

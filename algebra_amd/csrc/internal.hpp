@@ -16,7 +16,8 @@ struct FftTimings;
                      uint64_t* out_xyz, hipStream_t stream, MsmTimings* tm);                                      \
   int test_basefield_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);    \
   int test_point_op_##NAME(int kind, const void* d_acc, const void* d_other, void* d_out, size_t n, hipStream_t s); \
-  int sw_add_affine_##NAME(const void* d_in, void* d_out, size_t n, const void* d_delta, hipStream_t s);
+  int sw_add_affine_##NAME(const void* d_in, void* d_out, size_t n, const void* d_delta, hipStream_t s);        \
+  int sw_normalize_batch_##NAME(const void* d_in, void* d_out, size_t n, hipStream_t s);
 ARK_DECL_CURVE(BN254_G1)
 ARK_DECL_CURVE(BLS12_381_G1)
 ARK_DECL_CURVE(BLS12_377_G1)

@@ -17,4 +17,7 @@ int test_point_op_BLS12_381_G2(int kind, const void* acc, const void* other, voi
 int sw_add_affine_BLS12_381_G2(const void* in, void* out, size_t n, const void* d_delta, hipStream_t s) {
   return sw_add_affine_launch<BLS12_381_G2>(in, out, n, d_delta, s);
 }
+int sw_normalize_batch_BLS12_381_G2(const void* in, void* out, size_t n, hipStream_t s) {
+  return sw_normalize_batch_launch<BLS12_381_G2>(in, out, n, s);
+}
 }  // namespace arkhip

@@ -17,4 +17,7 @@ int test_point_op_BN254_G1(int kind, const void* acc, const void* other, void* o
 int sw_add_affine_BN254_G1(const void* in, void* out, size_t n, const void* d_delta, hipStream_t s) {
   return sw_add_affine_launch<BN254_G1>(in, out, n, d_delta, s);
 }
+int sw_normalize_batch_BN254_G1(const void* in, void* out, size_t n, hipStream_t s) {
+  return sw_normalize_batch_launch<BN254_G1>(in, out, n, s);
+}
 }  // namespace arkhip

@@ -103,6 +103,35 @@ int sw_add_affine_launch(const void* in, void* out, size_t n, const void* d_delt
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// CurveGroup::normalize_batch on the device (group.rs:302-319): Jacobian (x, y, z) -> affine (x/z^2, y/z^3), identity
+// -> (0, 0).  One Fermat inversion per point (the reference amortises one inversion over the batch with
+// Montgomery's trick on the CPU; per-lane exponentiation is the data-parallel equivalent).
+template <class C>
+__global__ void __launch_bounds__(128) sw_normalize_batch_kernel(const char* __restrict__ in, char* __restrict__ out,
+                                                                 size_t n) {
+  typedef typename C::F F;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const char* p = in + i * 3 * F::BYTES;
+  F x = F::load(p), y = F::load(p + F::BYTES), z = F::load(p + 2 * F::BYTES);
+  F ax = F::zero(), ay = F::zero();
+  if (!z.is_zero()) {
+    F zi = F::inverse(z);
+    F zi2 = F::sqr(zi);
+    ax = F::mul(x, zi2);
+    ay = F::mul(y, F::mul(zi2, zi));
+  }
+  ax.store(out + i * 2 * F::BYTES);
+  ay.store(out + i * 2 * F::BYTES + F::BYTES);
+}
+template <class C>
+int sw_normalize_batch_launch(const void* in, void* out, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((sw_normalize_batch_kernel<C>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s,
+                     (const char*)in, (char*)out, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 template <class C>
 int test_point_op_launch(int kind, const void* acc, const void* other, void* out, size_t n, hipStream_t s) {
   if (n == 0) return 0;

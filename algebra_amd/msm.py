@@ -172,3 +172,16 @@ def msm_u32(curve, bases, scalars):
 def msm_u64(curve, bases, scalars):
     """VariableBaseMSM::msm_u64 (mod.rs:113-117)."""
     return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint64)))
+
+
+def normalize_batch(curve, points):
+    """CurveGroup::normalize_batch (group.rs:302-319) on the device: Projective points (CUDA tensor, 3*fe_words u64
+    per point) -> Affine points (CUDA tensor of the same dtype)."""
+    import torch
+    cid = cv.curve_id(curve)
+    assert points.is_cuda and points.is_contiguous()
+    n = points.numel() * points.element_size() // (8 * cv.projective_words(cid))
+    out = torch.empty(n * cv.affine_words(cid) * 8 // points.element_size(), dtype=points.dtype, device=points.device)
+    torch.cuda.current_stream().synchronize()
+    check(lib().ark_hip_sw_normalize_batch_device(cid, points.data_ptr(), out.data_ptr(), n), "normalize_batch")
+    return out

@@ -89,6 +89,10 @@ int ark_hip_sw_into_affine(int curve, const uint64_t* jac_points, size_t n, uint
  * (bench.py / tests); mathematically Affine + Affine -> into_affine (group.rs:332-413, affine.rs:374-396). */
 int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_t n, const uint64_t* delta_xy);
 
+/* CurveGroup::normalize_batch (ec/src/models/short_weierstrass/group.rs:302-319) for n Projective points in
+ * device memory -> n Affine points in device memory; identity -> (0, 0). */
+int ark_hip_sw_normalize_batch_device(int curve, const void* d_jac, void* d_out_xy, size_t n);
+
 /* ---- Radix-2 evaluation domain ----
  * Mirror of Radix2EvaluationDomain<F>'s public fields (poly/src/domain/radix2/mod.rs:22-42). */
 typedef struct {

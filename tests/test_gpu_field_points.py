@@ -118,3 +118,19 @@ def test_point_ops_match_oracle(cname):
     got = H.point_op(cid, "bkt_to_jac", bk)
     for i in range(n):
         assert np.array_equal(O.to_affine(cid, got[i]), _norm(cid, bk[i:i + 1])[0])
+
+
+@pytest.mark.parametrize("cname", O.CURVES)
+def test_normalize_batch_on_device(cname):
+    # CurveGroup::normalize_batch == per-point into_affine (test-templates/src/groups.rs batch normalisation check)
+    import torch
+    import algebra_amd as A
+    cid = O.CID[cname]
+    n = 40
+    bases = O.gen_bases(cid, A4, B4, n)
+    sc = O.gen_scalars(O.curve_info(cid)[1], 3, n)
+    pts = np.stack([O.scalar_mul(cid, bases[i], sc[i]) for i in range(n)])
+    pts[7] = O.msm(cid, bases[:0], sc[:0], O.NAIVE)            # an identity in the batch
+    d = torch.from_numpy(pts.view(np.int64)).cuda()
+    got = A.normalize_batch(cid, d).cpu().numpy().view(np.uint64).reshape(n, -1)
+    assert np.array_equal(got, O.to_affine(cid, pts))
