@@ -464,7 +464,16 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
   int s0 = 0;
   for (int i = 0; i < P; i++) {
     FftPassArgs a;
-    a.k = k; a.s0 = s0; a.kp = kps[i]; a.t = t; a.last = (i == P - 1) ? 1 : 0;
+    // columns per tile: keep every tile at 1024 elements (32 KiB of LDS, 4 elements per lane) -- passes with
+    // fewer stages take more adjacent columns, i.e. longer contiguous segments
+    int ti = t;
+    if (P > 1 && !getenv("ARK_HIP_FFT_T")) {
+      ti = 10 - kps[i];
+      if (ti < FFT_LANE_BITS) ti = FFT_LANE_BITS;
+      const int room = (i == P - 1) ? (k - kps[i]) : (k - s0 - kps[i]);  // bits available for columns
+      if (ti > room) ti = room;
+    }
+    a.k = k; a.s0 = s0; a.kp = kps[i]; a.t = ti; a.last = (i == P - 1) ? 1 : 0;
     a.roots = roots;
     a.pre_lo = (i == 0) ? pre_lo : nullptr;
     a.pre_hi = (i == 0) ? pre_hi : nullptr;
@@ -477,8 +486,8 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     else if (i == 0) { src = data; dst = tmp; }
     else if (i == P - 1) { src = tmp; dst = data; }
     else { src = tmp; dst = tmp; }
-    u32 tiles = (u32)(n >> (kps[i] + t));
-    size_t lds_bytes = ((size_t)2 << (kps[i] + t)) * sizeof(uint4);
+    u32 tiles = (u32)(n >> (kps[i] + ti));
+    size_t lds_bytes = ((size_t)2 << (kps[i] + ti)) * sizeof(uint4);
     hipLaunchKernelGGL((fft_pass_kernel<FP>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, a);
     if (tm) ARK_HIP_TRY(hipEventRecord(ev[nev++], stream));
     s0 += kps[i];
