@@ -39,6 +39,27 @@ class Radix2DomainStruct(C.Structure):
 SYMBOLS = {
     "ark_hip_device_count": (C.c_int, []),
     "ark_hip_init": (C.c_int, [C.c_int]),
+    "ark_hip_set_device": (C.c_int, [C.c_int]),
+    "ark_hip_get_device": (C.c_int, []),
+    "ark_hip_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ark_hip_host_free": (C.c_int, [C.c_void_p]),
+    "ark_hip_msm_sw_device_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "ark_hip_msm_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ark_hip_msm_bases_prepare": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ark_hip_msm_bases_prepare_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ark_hip_msm_bases_free": (C.c_int, [C.c_void_p]),
+    "ark_hip_msm_bases_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_size_t)]),
+    "ark_hip_msm_prepared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ark_hip_msm_prepared_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ark_hip_msm_prepared_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "ark_hip_msm_prepared_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "ark_hip_msm_sw_chunks": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "ark_hip_msm_sw_multi": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ark_hip_msm_sw_multi_device": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
+    "ark_hip_fft_in_place_degree_aware": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_size_t]),
+    "ark_hip_fft_in_place_degree_aware_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_size_t]),
     "ark_hip_shutdown": (None, []),
     "ark_hip_synchronize": (C.c_int, []),
     "ark_hip_version": (C.c_char_p, []),

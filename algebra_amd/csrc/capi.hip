@@ -2,6 +2,8 @@
 #include "../../include/ark_hip.h"
 #include <string.h>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include "msm.cuh"
 #include "fft.cuh"
 #include "internal.hpp"
@@ -11,42 +13,87 @@ using namespace arkhip;
 
 namespace {
 
+// One context per (logical) device: stream, workspaces, staging.  Every entry point runs on the calling thread's
+// current device (ark_hip_set_device / ark_hip_init; default: the first device initialised) and holds that
+// context's lock for its whole body, so the library can be called from any number of host threads (rayon workers,
+// Python threads): calls on one device serialise, calls on different devices run concurrently.
 struct Context {
-  int device = -1;
-  hipStream_t stream = nullptr;
+  int logical = -1, physical = -1;
+  hipStream_t stream = nullptr;        // compute
+  hipStream_t copy_stream = nullptr;   // uploads overlapped with compute (streaming MSM)
   MsmWorkspace msm;
   FftWorkspace fft;
-  DevBuf stage_a, stage_b, stage_c;  // host-pointer entry points: device copies
+  DevBuf stage_a, stage_b, stage_c;    // host-pointer entry points: device copies
+  DevBuf ring_s[2], ring_b[2];         // double-buffered scalar / base uploads of the streaming entry points
+  hipEvent_t ring_free[2] = {nullptr, nullptr}, ring_up[2] = {nullptr, nullptr};
+  int ring_next = 0;
   bool msm_timing = false, fft_timing = false;
   MsmTimings msm_tm;
-  int msm_c = 0, msm_W = 0;
   FftTimings fft_tm;
+  std::recursive_mutex mu;
 };
-Context* g_ctx = nullptr;
+constexpr int MAX_DEV = 64;
+Context* g_ctxs[MAX_DEV] = {};
 std::mutex g_mu;
+int g_default = -1;              // device of threads that never chose one
+thread_local int t_dev = -1;
 
-int ensure_ctx() {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_ctx) {
-    // HIP's current device is per host thread: re-select ours on every entry
-    return hipSetDevice(g_ctx->device) == hipSuccess ? 0 : ARK_HIP_ERR_NO_DEVICE;
-  }
+int device_count_raw() {
   int cnt = 0;
-  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+// logical -> physical device.  ARK_HIP_OVERSUBSCRIBE=1 lets logical ids beyond the physical count wrap around (separate
+// contexts, streams and workspaces on a shared GPU): how the multi-device code paths are tested on a one-GPU box.
+int physical_of(int logical, int cnt) {
+  if (logical < 0 || logical >= MAX_DEV || cnt <= 0) return -1;
+  if (logical < cnt) return logical;
+  const char* e = getenv("ARK_HIP_OVERSUBSCRIBE");
+  return (e && atoi(e) > 0) ? logical % cnt : -1;
+}
+
+int get_ctx(int logical, Context** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int cnt = device_count_raw();
+  if (cnt <= 0) {
     fprintf(stderr, "ark_hip: no HIP device visible -- this library has no CPU fallback\n");
     return ARK_HIP_ERR_NO_DEVICE;
   }
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return ARK_HIP_ERR_NO_DEVICE;
-  Context* c = new Context();
-  c->device = dev;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete c;
-    return ARK_HIP_ERR_NO_DEVICE;
+  if (logical < 0) logical = g_default >= 0 ? g_default : 0;
+  const int phys = physical_of(logical, cnt);
+  if (phys < 0) return ARK_HIP_ERR_ARG;
+  if (hipSetDevice(phys) != hipSuccess) return ARK_HIP_ERR_NO_DEVICE;  // HIP's current device is per host thread
+  if (!g_ctxs[logical]) {
+    Context* c = new Context();
+    c->logical = logical;
+    c->physical = phys;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return ARK_HIP_ERR_NO_DEVICE;
+    }
+    g_ctxs[logical] = c;
+    if (g_default < 0) g_default = logical;
   }
-  g_ctx = c;
+  *out = g_ctxs[logical];
   return 0;
 }
+
+// RAII: the calling thread's context, locked
+struct Scope {
+  Context* c = nullptr;
+  std::unique_lock<std::recursive_mutex> lk;
+  int enter(int logical = -2) {
+    int rc = get_ctx(logical == -2 ? t_dev : logical, &c);
+    if (rc) return rc;
+    lk = std::unique_lock<std::recursive_mutex>(c->mu);
+    if (hipSetDevice(c->physical) != hipSuccess) return ARK_HIP_ERR_NO_DEVICE;
+    return 0;
+  }
+};
+#define ARK_SCOPE(S)               \
+  Scope S;                         \
+  if (int _rc = S.enter()) return _rc
 
 struct CurveInfo { int fe_words, scalar_field, base_field, ext; };
 const CurveInfo CURVES[5] = {
@@ -54,38 +101,116 @@ const CurveInfo CURVES[5] = {
     {6, ARK_HIP_BLS12_377_FR, ARK_HIP_BLS12_377_FQ, 1}, {12, ARK_HIP_BLS12_377_FR, ARK_HIP_BLS12_377_FQ, 2},
     {12, ARK_HIP_BLS12_381_FR, ARK_HIP_BLS12_381_FQ, 2}};
 
-int msm_dispatch(int curve, MsmWorkspace& ws, const void* b, const void* s, size_t n, int mont, uint64_t* out,
-                 hipStream_t st, MsmTimings* tm) {
-  switch (curve) {
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BN254_G1: return msm_run_BN254_G1(ws, b, s, n, mont, out, st, tm);
+// per-curve dispatch (one translation unit per curve, internal.hpp)
+#ifdef ARK_HIP_DEV
+#define ARK_CURVE_SWITCH(curve, CALL)                         \
+  switch (curve) {                                            \
+    case ARK_HIP_BLS12_381_G1: return CALL(BLS12_381_G1);     \
+  }                                                           \
+  return ARK_HIP_ERR_ARG
+#define ARK_FIELD_SWITCH(field, CALL)                         \
+  switch (field) {                                            \
+    case ARK_HIP_BLS12_381_FR: return CALL(BLS12_381_FR);     \
+  }                                                           \
+  return ARK_HIP_ERR_ARG
+#else
+#define ARK_CURVE_SWITCH(curve, CALL)                         \
+  switch (curve) {                                            \
+    case ARK_HIP_BN254_G1: return CALL(BN254_G1);             \
+    case ARK_HIP_BLS12_381_G1: return CALL(BLS12_381_G1);     \
+    case ARK_HIP_BLS12_377_G1: return CALL(BLS12_377_G1);     \
+    case ARK_HIP_BLS12_377_G2: return CALL(BLS12_377_G2);     \
+    case ARK_HIP_BLS12_381_G2: return CALL(BLS12_381_G2);     \
+  }                                                           \
+  return ARK_HIP_ERR_ARG
+#define ARK_FIELD_SWITCH(field, CALL)                         \
+  switch (field) {                                            \
+    case ARK_HIP_BN254_FR: return CALL(BN254_FR);             \
+    case ARK_HIP_BLS12_381_FR: return CALL(BLS12_381_FR);     \
+    case ARK_HIP_BLS12_377_FR: return CALL(BLS12_377_FR);     \
+  }                                                           \
+  return ARK_HIP_ERR_ARG
 #endif
-    case ARK_HIP_BLS12_381_G1: return msm_run_BLS12_381_G1(ws, b, s, n, mont, out, st, tm);
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BLS12_377_G1: return msm_run_BLS12_377_G1(ws, b, s, n, mont, out, st, tm);
-#endif
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BLS12_377_G2: return msm_run_BLS12_377_G2(ws, b, s, n, mont, out, st, tm);
-#endif
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BLS12_381_G2: return msm_run_BLS12_381_G2(ws, b, s, n, mont, out, st, tm);
-#endif
-  }
-  return ARK_HIP_ERR_ARG;
-}
 
+int msm_enqueue_dispatch(int curve, MsmWorkspace& ws, const void* pts, size_t wstride, const MsmPlan* prep, const void* s,
+                         size_t n, int mont, hipStream_t st, bool timing) {
+#define X(NAME) msm_enqueue_##NAME(ws, pts, wstride, prep, s, n, mont, st, timing)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int msm_finish_dispatch(int curve, MsmWorkspace& ws, int slot, uint64_t* out, MsmTimings* tm) {
+#define X(NAME) msm_finish_##NAME(ws, slot, out, tm)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int msm_prepare_dispatch(int curve, const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, hipStream_t st) {
+#define X(NAME) msm_prepare_##NAME(d_bases, n, pl, d_table, st)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
 int fft_dispatch(int field, FftWorkspace& ws, void* d, int k, const uint64_t* root, const uint64_t* pre,
-                 const uint64_t* post, const uint64_t* postc, hipStream_t st, FftTimings* tm) {
+                 const uint64_t* post, const uint64_t* postc, int zlog, hipStream_t st, FftTimings* tm) {
+#define X(NAME) fft_run_##NAME(ws, d, k, root, pre, post, postc, zlog, st, tm)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+typedef int (*elementwise_fn)(int, const void*, const void*, void*, size_t, hipStream_t);
+int add_affine_dispatch(int curve, const void* in, void* out, size_t n, const void* d_delta, hipStream_t st) {
+#define X(NAME) sw_add_affine_##NAME(in, out, n, d_delta, st)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int normalize_dispatch(int curve, const void* in, void* out, size_t n, hipStream_t st) {
+#define X(NAME) sw_normalize_batch_##NAME(in, out, n, st)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int fr_mul_dispatch(int field, const void* a, const void* b, void* r, size_t n, hipStream_t st) {
+#define X(NAME) test_field_op_##NAME(2, a, b, r, n, st)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+int fft_axis_dispatch(int field, FftWorkspace& ws, void* d, unsigned G, size_t cols, const uint64_t* root, hipStream_t st) {
+#define X(NAME) fft_axis_##NAME(ws, d, G, cols, root, st)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+elementwise_fn field_op_fn(int field) {
   switch (field) {
 #ifndef ARK_HIP_DEV
-    case ARK_HIP_BN254_FR: return fft_run_BN254_FR(ws, d, k, root, pre, post, postc, st, tm);
+    case ARK_HIP_BN254_FR: return test_field_op_BN254_FR;
+    case ARK_HIP_BLS12_377_FR: return test_field_op_BLS12_377_FR;
+    case ARK_HIP_BN254_FQ: return test_basefield_op_BN254_G1;  // base fields: through the G1 curve over them
+    case ARK_HIP_BLS12_377_FQ: return test_basefield_op_BLS12_377_G1;
 #endif
-    case ARK_HIP_BLS12_381_FR: return fft_run_BLS12_381_FR(ws, d, k, root, pre, post, postc, st, tm);
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BLS12_377_FR: return fft_run_BLS12_377_FR(ws, d, k, root, pre, post, postc, st, tm);
-#endif
+    case ARK_HIP_BLS12_381_FR: return test_field_op_BLS12_381_FR;
+    case ARK_HIP_BLS12_381_FQ: return test_basefield_op_BLS12_381_G1;
   }
-  return ARK_HIP_ERR_ARG;
+  return nullptr;
+}
+elementwise_fn basefield_op_fn(int curve) {
+  switch (curve) {
+#ifndef ARK_HIP_DEV
+    case 0: return test_basefield_op_BN254_G1;
+    case 2: return test_basefield_op_BLS12_377_G1;
+    case 3: return test_basefield_op_BLS12_377_G2;
+    case 4: return test_basefield_op_BLS12_381_G2;
+#endif
+    case 1: return test_basefield_op_BLS12_381_G1;
+  }
+  return nullptr;
+}
+elementwise_fn point_op_fn(int curve) {
+  switch (curve) {
+#ifndef ARK_HIP_DEV
+    case 0: return test_point_op_BN254_G1;
+    case 2: return test_point_op_BLS12_377_G1;
+    case 3: return test_point_op_BLS12_377_G2;
+    case 4: return test_point_op_BLS12_381_G2;
+#endif
+    case 1: return test_point_op_BLS12_381_G1;
+  }
+  return nullptr;
 }
 
 // ---- host-side scalar-field arithmetic for the domain constants (same templates as the device) ----
@@ -195,97 +320,146 @@ int domain_coset(const ark_hip_radix2_domain* dom, const uint64_t* offset, ark_h
   return 0;
 }
 
+
 template <class FP>
-int fft_entry(Context* c, const ark_hip_radix2_domain* dom, void* d_data, int inverse) {
+int fft_entry(Context* c, const ark_hip_radix2_domain* dom, void* d_data, int inverse, int zlog) {
   const bool coset = !host_is_one<FP>(dom->offset);
   FftTimings* tm = c->fft_timing ? &c->fft_tm : nullptr;
   int k = (int)dom->log_size_of_group;
   if (dom->size != ((uint64_t)1 << k)) return ARK_HIP_ERR_ARG;
   if (!inverse) {
     // fft.rs:74-79: distribute_powers(offset) then DIF + derange
-    return fft_dispatch(FP::ID, c->fft, d_data, k, dom->group_gen, coset ? dom->offset : nullptr, nullptr, nullptr,
+    return fft_dispatch(FP::ID, c->fft, d_data, k, dom->group_gen, coset ? dom->offset : nullptr, nullptr, nullptr, zlog,
                         c->stream, tm);
   }
   // fft.rs:81-88: transform with group_gen_inv, then x[i] *= size_inv * offset_inv^i
   return fft_dispatch(FP::ID, c->fft, d_data, k, dom->group_gen_inv, nullptr, coset ? dom->offset_inv : nullptr,
-                      dom->size_inv, c->stream, tm);
+                      dom->size_inv, 0, c->stream, tm);
 }
 
-int fft_any(int field, const ark_hip_radix2_domain* dom, void* d_data, int inverse) {
-  if (!dom || !d_data) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
+int fft_any(Context* c, int field, const ark_hip_radix2_domain* dom, void* d_data, int inverse, int zlog) {
   switch (field) {
-    case ARK_HIP_BN254_FR: return fft_entry<BN254_FR>(g_ctx, dom, d_data, inverse);
-    case ARK_HIP_BLS12_381_FR: return fft_entry<BLS12_381_FR>(g_ctx, dom, d_data, inverse);
-    case ARK_HIP_BLS12_377_FR: return fft_entry<BLS12_377_FR>(g_ctx, dom, d_data, inverse);
+    case ARK_HIP_BN254_FR: return fft_entry<BN254_FR>(c, dom, d_data, inverse, zlog);
+    case ARK_HIP_BLS12_381_FR: return fft_entry<BLS12_381_FR>(c, dom, d_data, inverse, zlog);
+    case ARK_HIP_BLS12_377_FR: return fft_entry<BLS12_377_FR>(c, dom, d_data, inverse, zlog);
   }
   return ARK_HIP_ERR_ARG;
 }
 
-int fft_host(int field, const ark_hip_radix2_domain* dom, uint64_t* data, int inverse) {
-  if (!dom || !data) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  Context* c = g_ctx;
-  size_t bytes = (size_t)dom->size * 32;
-  if (c->stage_a.ensure(bytes)) return ARK_HIP_ERR_NOMEM;
-  ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, data, bytes, hipMemcpyHostToDevice, c->stream));
-  rc = fft_any(field, dom, c->stage_a.p, inverse);
-  if (rc) return rc;
-  ARK_HIP_TRY(hipMemcpyAsync(data, c->stage_a.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
-  return 0;
+// Stage skipping of the degree-aware path (radix2/mod.rs:141, fft.rs:29-71): with num_coeffs * 4 <= size the first
+// log2(size / next_pow2(num_coeffs)) stages only copy; returns that count (0: plain transform).
+int degree_aware_zlog(const ark_hip_radix2_domain* dom, size_t num_coeffs, size_t* d_pow2) {
+  size_t d = 1;
+  while (d < num_coeffs) d <<= 1;
+  *d_pow2 = d;
+  if (num_coeffs == 0 || num_coeffs * 4 > dom->size) return 0;
+  int z = 0;
+  while ((d << z) < dom->size) z++;
+  return z;
 }
 
 size_t field_bytes(int field) { return (field == ARK_HIP_BLS12_381_FQ || field == ARK_HIP_BLS12_377_FQ) ? 48 : 32; }
+
+// ---- MSM plumbing shared by the entry points ----------------------------------------------------------
+struct PreparedBases {   // ark_hip_msm_bases: a fixed base set with its table of per-window multiples
+  int curve = -1;
+  int logical = -1;      // device it lives on
+  size_t n = 0;
+  MsmPlan plan{};
+  DevBuf table;          // [plan.W][n] affine points
+};
+struct MsmJobHandle {    // ark_hip_msm_job
+  int logical;
+  int curve;
+  int slot;
+};
+
+int msm_enqueue_ctx(Context* c, int curve, const void* pts, size_t wstride, const MsmPlan* prep, const void* d_scalars,
+                    size_t n, int mont) {
+  return msm_enqueue_dispatch(curve, c->msm, pts, wstride, prep, d_scalars, n, mont, c->stream, c->msm_timing);
+}
+int msm_finish_ctx(Context* c, int curve, int slot, uint64_t* out) {
+  return msm_finish_dispatch(curve, c->msm, slot, out, c->msm_timing ? &c->msm_tm : nullptr);
+}
+
+// next slot of the upload ring: the copy stream waits until the MSM that last read this slot has finished
+int ring_acquire(Context* c, int* k) {
+  const int i = c->ring_next;
+  c->ring_next ^= 1;
+  for (int j = 0; j < 2; j++) {
+    if (!c->ring_free[j]) ARK_HIP_TRY(hipEventCreateWithFlags(&c->ring_free[j], hipEventDisableTiming));
+    if (!c->ring_up[j]) ARK_HIP_TRY(hipEventCreateWithFlags(&c->ring_up[j], hipEventDisableTiming));
+  }
+  ARK_HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ring_free[i], 0));  // never-recorded event: no wait
+  *k = i;
+  return 0;
+}
+// uploads done -> compute may start; after the MSM is enqueued the slot is marked free again
+int ring_publish(Context* c, int k) {
+  ARK_HIP_TRY(hipEventRecord(c->ring_up[k], c->copy_stream));
+  ARK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ring_up[k], 0));
+  return 0;
+}
+int ring_release(Context* c, int k) {
+  ARK_HIP_TRY(hipEventRecord(c->ring_free[k], c->stream));
+  return 0;
+}
 
 }  // namespace
 
 extern "C" {
 
-int ark_hip_device_count(void) {
-  int cnt = 0;
-  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
-  return cnt;
-}
+int ark_hip_device_count(void) { return device_count_raw(); }
 
 int ark_hip_init(int device) {
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ctx) return g_ctx->device == device ? 0 : ARK_HIP_ERR_ARG;
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
-      fprintf(stderr, "ark_hip: no HIP device visible -- this library has no CPU fallback\n");
-      return ARK_HIP_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= cnt) return ARK_HIP_ERR_ARG;
-    if (hipSetDevice(device) != hipSuccess) return ARK_HIP_ERR_NO_DEVICE;
-  }
-  return ensure_ctx();
+  Context* c = nullptr;
+  if (device < 0) return ARK_HIP_ERR_ARG;
+  int rc = get_ctx(device, &c);
+  if (rc) return rc;
+  t_dev = device;
+  return 0;
 }
+int ark_hip_set_device(int device) { return ark_hip_init(device); }
+int ark_hip_get_device(void) { return t_dev >= 0 ? t_dev : (g_default >= 0 ? g_default : 0); }
 
 void ark_hip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ctx) return;
-  (void)hipStreamSynchronize(g_ctx->stream);
-  g_ctx->msm.release();
-  g_ctx->fft.release();
-  g_ctx->stage_a.release();
-  g_ctx->stage_b.release();
-  g_ctx->stage_c.release();
-  (void)hipStreamDestroy(g_ctx->stream);
-  delete g_ctx;
-  g_ctx = nullptr;
+  for (int i = 0; i < MAX_DEV; i++) {
+    Context* c = g_ctxs[i];
+    if (!c) continue;
+    {
+      std::lock_guard<std::recursive_mutex> cl(c->mu);  // waits for calls in flight on this device
+      (void)hipSetDevice(c->physical);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipStreamSynchronize(c->copy_stream);
+      c->msm.release();
+      c->fft.release();
+      c->stage_a.release();
+      c->stage_b.release();
+      c->stage_c.release();
+      for (int j = 0; j < 2; j++) {
+        c->ring_s[j].release();
+        c->ring_b[j].release();
+        if (c->ring_free[j]) (void)hipEventDestroy(c->ring_free[j]);
+        if (c->ring_up[j]) (void)hipEventDestroy(c->ring_up[j]);
+      }
+      (void)hipStreamDestroy(c->stream);
+      (void)hipStreamDestroy(c->copy_stream);
+    }
+    delete c;
+    g_ctxs[i] = nullptr;
+  }
+  g_default = -1;
 }
 
 int ark_hip_synchronize(void) {
-  if (!g_ctx) return 0;
-  ARK_HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+  ARK_SCOPE(sc);
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->copy_stream));
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
   return 0;
 }
 
-const char* ark_hip_version(void) { return "ark_hip 0.1 (gfx950)"; }
+const char* ark_hip_version(void) { return "ark_hip 0.2 (gfx950)"; }
 
 int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_field, int* ext_degree) {
   if (curve < 0 || curve > 4) return ARK_HIP_ERR_ARG;
@@ -296,11 +470,10 @@ int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_fi
   return 0;
 }
 
-// ---- device memory for hosts without their own HIP binding (the Rust shim keeps an SRS resident this way) ----
+// ---- device / pinned memory for hosts without their own HIP binding ----
 int ark_hip_malloc(size_t bytes, void** out_dptr) {
   if (!out_dptr) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
+  ARK_SCOPE(sc);
   *out_dptr = nullptr;
   if (bytes == 0) return 0;
   if (hipMalloc(out_dptr, bytes) != hipSuccess) return ARK_HIP_ERR_NOMEM;
@@ -308,26 +481,37 @@ int ark_hip_malloc(size_t bytes, void** out_dptr) {
 }
 int ark_hip_free(void* dptr) {
   if (!dptr) return 0;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  ARK_HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+  ARK_SCOPE(sc);
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
   ARK_HIP_TRY(hipFree(dptr));
   return 0;
 }
 int ark_hip_memcpy_h2d(void* dst_dptr, const void* src_host, size_t bytes) {
   if (bytes && (!dst_dptr || !src_host)) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  ARK_HIP_TRY(hipMemcpyAsync(dst_dptr, src_host, bytes, hipMemcpyHostToDevice, g_ctx->stream));
-  ARK_HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+  ARK_SCOPE(sc);
+  ARK_HIP_TRY(hipMemcpyAsync(dst_dptr, src_host, bytes, hipMemcpyHostToDevice, sc.c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
   return 0;
 }
 int ark_hip_memcpy_d2h(void* dst_host, const void* src_dptr, size_t bytes) {
   if (bytes && (!dst_host || !src_dptr)) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  ARK_HIP_TRY(hipMemcpyAsync(dst_host, src_dptr, bytes, hipMemcpyDeviceToHost, g_ctx->stream));
-  ARK_HIP_TRY(hipStreamSynchronize(g_ctx->stream));
+  ARK_SCOPE(sc);
+  ARK_HIP_TRY(hipMemcpyAsync(dst_host, src_dptr, bytes, hipMemcpyDeviceToHost, sc.c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
+  return 0;
+}
+int ark_hip_host_alloc(size_t bytes, void** out_ptr) {
+  if (!out_ptr) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  *out_ptr = nullptr;
+  if (bytes == 0) return 0;
+  if (hipHostMalloc(out_ptr, bytes) != hipSuccess) return ARK_HIP_ERR_NOMEM;
+  return 0;
+}
+int ark_hip_host_free(void* ptr) {
+  if (!ptr) return 0;
+  ARK_SCOPE(sc);
+  ARK_HIP_TRY(hipHostFree(ptr));
   return 0;
 }
 
@@ -346,49 +530,284 @@ int ark_hip_curve_generator(int curve, uint64_t* out_xy) {
   return 0;
 }
 
-int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont, uint64_t* out_xyz) {
-  if (curve < 0 || curve > 4 || !out_xyz || (n && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  Context* c = g_ctx;
-  MsmTimings* tm = c->msm_timing ? &c->msm_tm : nullptr;
-  rc = msm_dispatch(curve, c->msm, d_bases, d_scalars, n, mont, out_xyz, c->stream, tm);
-  if (rc == 0 && tm) {
-    MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve));
-    c->msm_c = pl.c;
-    c->msm_W = pl.W;
+// ---- MSM ------------------------------------------------------------------------------------------------
+int ark_hip_msm_sw_device_async(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont,
+                                ark_hip_msm_job** out_job) {
+  if (curve < 0 || curve > 4 || !out_job || (n && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  int slot = msm_enqueue_ctx(sc.c, curve, d_bases, 0, nullptr, d_scalars, n, mont);
+  if (slot < 0) return slot;
+  *out_job = (ark_hip_msm_job*)new MsmJobHandle{sc.c->logical, curve, slot};
+  return 0;
+}
+
+int ark_hip_msm_wait(ark_hip_msm_job* job, uint64_t* out_xyz) {
+  if (!job) return ARK_HIP_ERR_ARG;
+  MsmJobHandle* h = (MsmJobHandle*)job;
+  int rc;
+  {
+    Scope sc;
+    rc = sc.enter(h->logical);
+    if (rc == 0) {
+      // the event wait and the host tail run WITHOUT the context lock: other threads may enqueue meanwhile
+      Context* c = sc.c;
+      sc.lk.unlock();
+      uint64_t scratch[36];
+      rc = msm_finish_ctx(c, h->curve, h->slot, out_xyz ? out_xyz : scratch);
+    }
   }
+  delete h;
   return rc;
+}
+
+int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont, uint64_t* out_xyz) {
+  if (!out_xyz) return ARK_HIP_ERR_ARG;
+  ark_hip_msm_job* job = nullptr;
+  int rc = ark_hip_msm_sw_device_async(curve, d_bases, d_scalars, n, mont, &job);
+  if (rc) return rc;
+  return ark_hip_msm_wait(job, out_xyz);
 }
 
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xyz) {
   if (curve < 0 || curve > 4 || !out_xyz || (n && (!bases || !scalars))) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  Context* c = g_ctx;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
   size_t bb = n * (size_t)CURVES[curve].fe_words * 2 * 8, sb = n * 32;
   if (n) {
     if (c->stage_a.ensure(bb) || c->stage_b.ensure(sb)) return ARK_HIP_ERR_NOMEM;
     ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, bases, bb, hipMemcpyHostToDevice, c->stream));
     ARK_HIP_TRY(hipMemcpyAsync(c->stage_b.p, scalars, sb, hipMemcpyHostToDevice, c->stream));
   }
-  return ark_hip_msm_sw_device(curve, c->stage_a.p, c->stage_b.p, n, mont, out_xyz);
+  // the staging buffers stay locked with the context until the result is back
+  int slot = msm_enqueue_ctx(c, curve, c->stage_a.p, 0, nullptr, c->stage_b.p, n, mont);
+  if (slot < 0) return slot;
+  return msm_finish_ctx(c, curve, slot, out_xyz);
 }
 
 int ark_hip_msm_set_timing(int enable) {
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  g_ctx->msm_timing = enable != 0;
+  ARK_SCOPE(sc);
+  sc.c->msm_timing = enable != 0;
   return 0;
 }
 int ark_hip_msm_last_timing(double out[8]) {
-  if (!g_ctx || !out) return ARK_HIP_ERR_ARG;
-  const MsmTimings& t = g_ctx->msm_tm;
+  if (!out) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  const MsmTimings& t = sc.c->msm_tm;
   out[0] = t.digits; out[1] = t.scan; out[2] = t.scatter; out[3] = t.accumulate; out[4] = t.reduce; out[5] = t.total;
-  out[6] = g_ctx->msm_c; out[7] = g_ctx->msm_W;
+  out[6] = t.c; out[7] = t.W;
   return 0;
 }
 
+// ---- prepared base sets (fixed SRS) ----
+int ark_hip_msm_bases_prepare_device(int curve, const void* d_bases, size_t n, ark_hip_msm_bases** out) {
+  if (curve < 0 || curve > 4 || !out || (n && !d_bases)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  PreparedBases* pb = new PreparedBases();
+  pb->curve = curve;
+  pb->logical = c->logical;
+  pb->n = n;
+  pb->plan = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve), true);
+  const size_t row = n * (size_t)CURVES[curve].fe_words * 16;
+  if (n) {
+    if ((size_t)pb->plan.W * n >= (1ull << 31) || pb->table.ensure((size_t)pb->plan.W * row)) {
+      delete pb;
+      return ARK_HIP_ERR_NOMEM;
+    }
+    int rc = msm_prepare_dispatch(curve, d_bases, n, pb->plan, pb->table.p, c->stream);
+    if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = -1000;
+    if (rc) {
+      pb->table.release();
+      delete pb;
+      return rc;
+    }
+  }
+  *out = (ark_hip_msm_bases*)pb;
+  return 0;
+}
+int ark_hip_msm_bases_prepare(int curve, const uint64_t* bases, size_t n, ark_hip_msm_bases** out) {
+  if (curve < 0 || curve > 4 || !out || (n && !bases)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  const size_t bb = n * (size_t)CURVES[curve].fe_words * 16;
+  if (n) {
+    if (c->stage_a.ensure(bb)) return ARK_HIP_ERR_NOMEM;
+    ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, bases, bb, hipMemcpyHostToDevice, c->stream));
+  }
+  return ark_hip_msm_bases_prepare_device(curve, c->stage_a.p, n, out);
+}
+int ark_hip_msm_bases_free(ark_hip_msm_bases* bases) {
+  if (!bases) return 0;
+  PreparedBases* pb = (PreparedBases*)bases;
+  Scope sc;
+  if (int rc = sc.enter(pb->logical)) return rc;
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
+  pb->table.release();
+  delete pb;
+  return 0;
+}
+int ark_hip_msm_bases_info(const ark_hip_msm_bases* bases, size_t* n, int* window_bits, int* windows, size_t* table_bytes) {
+  if (!bases) return ARK_HIP_ERR_ARG;
+  const PreparedBases* pb = (const PreparedBases*)bases;
+  if (n) *n = pb->n;
+  if (window_bits) *window_bits = pb->plan.c;
+  if (windows) *windows = pb->plan.W;
+  if (table_bytes) *table_bytes = (size_t)pb->plan.W * pb->n * (size_t)CURVES[pb->curve].fe_words * 16;
+  return 0;
+}
+int ark_hip_msm_prepared_device_async(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int mont,
+                                      ark_hip_msm_job** out_job) {
+  if (!bases || !out_job) return ARK_HIP_ERR_ARG;
+  const PreparedBases* pb = (const PreparedBases*)bases;
+  if (n > pb->n || (n && !d_scalars)) return ARK_HIP_ERR_ARG;
+  Scope sc;
+  if (int rc = sc.enter(pb->logical)) return rc;
+  int slot = msm_enqueue_ctx(sc.c, pb->curve, pb->table.p, pb->n, &pb->plan, d_scalars, n, mont);
+  if (slot < 0) return slot;
+  *out_job = (ark_hip_msm_job*)new MsmJobHandle{pb->logical, pb->curve, slot};
+  return 0;
+}
+int ark_hip_msm_prepared_device(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int mont,
+                                uint64_t* out_xyz) {
+  if (!out_xyz) return ARK_HIP_ERR_ARG;
+  ark_hip_msm_job* job = nullptr;
+  int rc = ark_hip_msm_prepared_device_async(bases, d_scalars, n, mont, &job);
+  if (rc) return rc;
+  return ark_hip_msm_wait(job, out_xyz);
+}
+// Host scalars: uploaded on the copy stream into a two-slot ring, so that the upload of the next MSM's scalars
+// overlaps the previous MSM's kernels (the steady state of a prover that commits to one polynomial after another
+// against a resident SRS).  Pinned host memory (ark_hip_host_alloc) makes the copy truly asynchronous.
+int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n, int mont,
+                               ark_hip_msm_job** out_job) {
+  if (!bases || !out_job) return ARK_HIP_ERR_ARG;
+  const PreparedBases* pb = (const PreparedBases*)bases;
+  if (n > pb->n || (n && !scalars)) return ARK_HIP_ERR_ARG;
+  Scope sc;
+  if (int rc = sc.enter(pb->logical)) return rc;
+  Context* c = sc.c;
+  int k = 0;
+  if (int rc = ring_acquire(c, &k)) return rc;
+  if (n) {
+    if (c->ring_s[k].cap < n * 32) {
+      ARK_HIP_TRY(hipStreamSynchronize(c->stream));  // growing frees memory an enqueued MSM may still read
+      if (c->ring_s[k].ensure(n * 32)) return ARK_HIP_ERR_NOMEM;
+    }
+    ARK_HIP_TRY(hipMemcpyAsync(c->ring_s[k].p, scalars, n * 32, hipMemcpyHostToDevice, c->copy_stream));
+  }
+  if (int rc = ring_publish(c, k)) return rc;
+  int slot = msm_enqueue_ctx(c, pb->curve, pb->table.p, pb->n, &pb->plan, c->ring_s[k].p, n, mont);
+  (void)ring_release(c, k);
+  if (slot < 0) return slot;
+  *out_job = (ark_hip_msm_job*)new MsmJobHandle{pb->logical, pb->curve, slot};
+  return 0;
+}
+int ark_hip_msm_prepared(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xyz) {
+  if (!out_xyz) return ARK_HIP_ERR_ARG;
+  ark_hip_msm_job* job = nullptr;
+  int rc = ark_hip_msm_prepared_async(bases, scalars, n, mont, &job);
+  if (rc) return rc;
+  return ark_hip_msm_wait(job, out_xyz);
+}
+
+// VariableBaseMSM::msm_chunks (variable_base/mod.rs:119-150): Fr scalars, streams aligned at their END (the first
+// n_bases - n_scalars bases are skipped), steps of `step` pairs (the reference hard-codes 2^20; 0 selects it), each
+// step an msm_bigint whose result is added up.  Here step k+1's bases and scalars upload on the copy stream while
+// step k's kernels run.
+int ark_hip_msm_sw_chunks(int curve, const uint64_t* bases, size_t n_bases, const uint64_t* scalars, size_t n_scalars,
+                          size_t step, uint64_t* out_xyz) {
+  if (curve < 0 || curve > 4 || !out_xyz || n_scalars > n_bases || (n_scalars && (!bases || !scalars)))
+    return ARK_HIP_ERR_ARG;
+  if (step == 0) step = (size_t)1 << 20;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  const size_t ab = (size_t)CURVES[curve].fe_words * 16;
+  const uint64_t* b0 = bases + (n_bases - n_scalars) * (ab / 8);
+  const size_t pw = (size_t)CURVES[curve].fe_words * 3;
+  std::vector<uint64_t> partials;  // Jacobian partial per step
+  int pending_slot[2] = {-1, -1};
+  int npend = 0;
+  auto drain_one = [&]() -> int {
+    uint64_t part[36];
+    int rc = msm_finish_ctx(c, curve, pending_slot[0], part);
+    pending_slot[0] = pending_slot[1];
+    npend--;
+    if (rc) return rc;
+    partials.insert(partials.end(), part, part + pw);
+    return 0;
+  };
+  for (size_t off = 0; off < n_scalars; off += step) {
+    const size_t cnt = n_scalars - off < step ? n_scalars - off : step;
+    if (npend == 2) {
+      if (int rc = drain_one()) return rc;
+    }
+    int k = 0;
+    if (int rc = ring_acquire(c, &k)) return rc;
+    if (c->ring_b[k].cap < cnt * ab || c->ring_s[k].cap < cnt * 32) {
+      ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->ring_b[k].ensure((step < n_scalars ? step : n_scalars) * ab) ||
+          c->ring_s[k].ensure((step < n_scalars ? step : n_scalars) * 32))
+        return ARK_HIP_ERR_NOMEM;
+    }
+    ARK_HIP_TRY(hipMemcpyAsync(c->ring_b[k].p, b0 + off * (ab / 8), cnt * ab, hipMemcpyHostToDevice, c->copy_stream));
+    ARK_HIP_TRY(hipMemcpyAsync(c->ring_s[k].p, scalars + off * 4, cnt * 32, hipMemcpyHostToDevice, c->copy_stream));
+    if (int rc = ring_publish(c, k)) return rc;
+    int slot = msm_enqueue_ctx(c, curve, c->ring_b[k].p, 0, nullptr, c->ring_s[k].p, cnt, 1);
+    (void)ring_release(c, k);
+    if (slot < 0) return slot;
+    pending_slot[npend++] = slot;
+  }
+  while (npend) {
+    if (int rc = drain_one()) return rc;
+  }
+  return ark_hip_sw_sum(curve, partials.data(), partials.size() / pw, out_xyz);
+}
+
+// One MSM over the GPUs of this node from ONE host process: base-range shards (the reference's own split,
+// variable_base/mod.rs:521-557), one host thread and one context per device, partials (3 field elements each) summed
+// on the host.  The data path has no collective: RCCL would add nothing to a 144-byte exchange inside one process.
+int ark_hip_msm_sw_multi_device(int curve, int n_gpus, const void* const* d_bases, const void* const* d_scalars,
+                                const size_t* n_per_gpu, int mont, uint64_t* out_xyz) {
+  if (curve < 0 || curve > 4 || n_gpus < 1 || n_gpus > MAX_DEV || !d_bases || !d_scalars || !n_per_gpu || !out_xyz)
+    return ARK_HIP_ERR_ARG;
+  const size_t pw = (size_t)CURVES[curve].fe_words * 3;
+  std::vector<uint64_t> partials((size_t)n_gpus * pw);
+  std::vector<int> rcs((size_t)n_gpus, 0);
+  std::vector<std::thread> th;
+  for (int g = 0; g < n_gpus; g++)
+    th.emplace_back([&, g]() {
+      int rc = ark_hip_set_device(g);
+      if (rc == 0) rc = ark_hip_msm_sw_device(curve, d_bases[g], d_scalars[g], n_per_gpu[g], mont, &partials[(size_t)g * pw]);
+      rcs[(size_t)g] = rc;
+    });
+  for (auto& t : th) t.join();
+  for (int g = 0; g < n_gpus; g++)
+    if (rcs[(size_t)g]) return rcs[(size_t)g];
+  return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);
+}
+int ark_hip_msm_sw_multi(int curve, int n_gpus, const uint64_t* bases, const uint64_t* scalars, size_t n, int mont,
+                         uint64_t* out_xyz) {
+  if (curve < 0 || curve > 4 || n_gpus < 1 || n_gpus > MAX_DEV || !out_xyz || (n && (!bases || !scalars)))
+    return ARK_HIP_ERR_ARG;
+  const size_t pw = (size_t)CURVES[curve].fe_words * 3, aw = (size_t)CURVES[curve].fe_words * 2;
+  std::vector<uint64_t> partials((size_t)n_gpus * pw);
+  std::vector<int> rcs((size_t)n_gpus, 0);
+  std::vector<std::thread> th;
+  for (int g = 0; g < n_gpus; g++)
+    th.emplace_back([&, g]() {
+      const size_t q = n / (size_t)n_gpus, r = n % (size_t)n_gpus;
+      const size_t lo = (size_t)g * q + ((size_t)g < r ? (size_t)g : r), cnt = q + ((size_t)g < r ? 1 : 0);
+      int rc = ark_hip_set_device(g);
+      if (rc == 0) rc = ark_hip_msm_sw(curve, bases + lo * aw, scalars + lo * 4, cnt, mont, &partials[(size_t)g * pw]);
+      rcs[(size_t)g] = rc;
+    });
+  for (auto& t : th) t.join();
+  for (int g = 0; g < n_gpus; g++)
+    if (rcs[(size_t)g]) return rcs[(size_t)g];
+  return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);
+}
+
+// ---- radix-2 domain / FFT --------------------------------------------------------------------------------
 int ark_hip_radix2_domain_new(int field, size_t num_coeffs, ark_hip_radix2_domain* out) {
   if (!out) return ARK_HIP_ERR_ARG;
   switch (field) {
@@ -409,26 +828,62 @@ int ark_hip_radix2_domain_get_coset(int field, const ark_hip_radix2_domain* dom,
   return ARK_HIP_ERR_ARG;
 }
 
-int ark_hip_fft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t* data) { return fft_host(field, dom, data, 0); }
-int ark_hip_ifft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t* data) { return fft_host(field, dom, data, 1); }
-int ark_hip_fft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d) { return fft_any(field, dom, d, 0); }
-int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d) { return fft_any(field, dom, d, 1); }
+static int fft_device_entry(int field, const ark_hip_radix2_domain* dom, void* d, int inverse, size_t num_coeffs) {
+  if (!dom || !d) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  int zlog = 0;
+  if (!inverse && num_coeffs < dom->size) {
+    // coefficients beyond num_coeffs are zero by contract (the reference resizes with zeros): make them so up to the
+    // power of two the transform reads
+    size_t d2 = 0;
+    zlog = degree_aware_zlog(dom, num_coeffs, &d2);
+    const size_t upto = zlog ? d2 : (size_t)dom->size;
+    if (upto > num_coeffs)
+      ARK_HIP_TRY(hipMemsetAsync((char*)d + num_coeffs * 32, 0, (upto - num_coeffs) * 32, sc.c->stream));
+  }
+  return fft_any(sc.c, field, dom, d, inverse, zlog);
+}
+static int fft_host_entry(int field, const ark_hip_radix2_domain* dom, uint64_t* data, int inverse, size_t num_coeffs) {
+  if (!dom || !data) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  const size_t bytes = (size_t)dom->size * 32;
+  if (num_coeffs > dom->size) return ARK_HIP_ERR_ARG;
+  if (c->stage_a.ensure(bytes)) return ARK_HIP_ERR_NOMEM;
+  ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, data, num_coeffs * 32, hipMemcpyHostToDevice, c->stream));  // only what is there
+  int rc = fft_device_entry(field, dom, c->stage_a.p, inverse, num_coeffs);
+  if (rc) return rc;
+  ARK_HIP_TRY(hipMemcpyAsync(data, c->stage_a.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int ark_hip_fft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t* data) {
+  return fft_host_entry(field, dom, data, 0, dom ? (size_t)dom->size : 0);
+}
+int ark_hip_ifft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t* data) {
+  return fft_host_entry(field, dom, data, 1, dom ? (size_t)dom->size : 0);
+}
+int ark_hip_fft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d) {
+  return fft_device_entry(field, dom, d, 0, dom ? (size_t)dom->size : 0);
+}
+int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d) {
+  return fft_device_entry(field, dom, d, 1, dom ? (size_t)dom->size : 0);
+}
+int ark_hip_fft_in_place_degree_aware(int field, const ark_hip_radix2_domain* dom, uint64_t* data, size_t num_coeffs) {
+  return fft_host_entry(field, dom, data, 0, num_coeffs);
+}
+int ark_hip_fft_in_place_degree_aware_device(int field, const ark_hip_radix2_domain* dom, void* d, size_t num_coeffs) {
+  if (dom && num_coeffs > dom->size) return ARK_HIP_ERR_ARG;
+  return fft_device_entry(field, dom, d, 0, num_coeffs);
+}
 
 // r[i] = a[i] * b[i] over n Fr elements in device memory (Evaluations *= Evaluations,
 // poly/src/evaluations/univariate/mod.rs MulAssign; the middle step of DensePolynomial multiplication,
-// poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous on the context stream.
+// poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous on the context stream; r may alias a or b.
 int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n) {
   if (n && (!d_a || !d_b || !d_r)) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  switch (field) {
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BN254_FR: return test_field_op_BN254_FR(2, d_a, d_b, d_r, n, g_ctx->stream);
-    case ARK_HIP_BLS12_377_FR: return test_field_op_BLS12_377_FR(2, d_a, d_b, d_r, n, g_ctx->stream);
-#endif
-    case ARK_HIP_BLS12_381_FR: return test_field_op_BLS12_381_FR(2, d_a, d_b, d_r, n, g_ctx->stream);
-  }
-  return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  return fr_mul_dispatch(field, d_a, d_b, d_r, n, sc.c->stream);
 }
 
 // out = base^exp in Fr (host arithmetic): domain elements / twiddles for hosts without field code of their own
@@ -447,29 +902,21 @@ int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out)
 // sharded FFT (algebra_amd/dist.py).  root = primitive G-th root of unity to use (w_n^(n/G) or its inverse).
 int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, const uint64_t* root) {
   if (!d_data || !root) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  switch (field) {
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BN254_FR: return fft_axis_BN254_FR(g_ctx->fft, d_data, G, cols, root, g_ctx->stream);
-    case ARK_HIP_BLS12_377_FR: return fft_axis_BLS12_377_FR(g_ctx->fft, d_data, G, cols, root, g_ctx->stream);
-#endif
-    case ARK_HIP_BLS12_381_FR: return fft_axis_BLS12_381_FR(g_ctx->fft, d_data, G, cols, root, g_ctx->stream);
-  }
-  return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  return fft_axis_dispatch(field, sc.c->fft, d_data, G, cols, root, sc.c->stream);
 }
 
 int ark_hip_fft_set_timing(int enable) {
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  g_ctx->fft_timing = enable != 0;
+  ARK_SCOPE(sc);
+  sc.c->fft_timing = enable != 0;
   return 0;
 }
 int ark_hip_fft_last_timing(double out[10]) {
-  if (!g_ctx || !out) return ARK_HIP_ERR_ARG;
-  out[0] = g_ctx->fft_tm.total;
-  out[1] = g_ctx->fft_tm.npass;
-  for (int i = 0; i < 8; i++) out[2 + i] = g_ctx->fft_tm.pass[i];
+  if (!out) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  out[0] = sc.c->fft_tm.total;
+  out[1] = sc.c->fft_tm.npass;
+  for (int i = 0; i < 8; i++) out[2 + i] = sc.c->fft_tm.pass[i];
   return 0;
 }
 
@@ -500,27 +947,12 @@ int ark_hip_sw_into_affine(int curve, const uint64_t* jac_points, size_t n, uint
 // out[i] = in[i] + delta on the device (affine in/out); d_in may equal d_out
 int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_t n, const uint64_t* delta_xy) {
   if (curve < 0 || curve > 4 || !delta_xy || (n && (!d_in || !d_out))) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  Context* c = g_ctx;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
   size_t ab = (size_t)CURVES[curve].fe_words * 16;
   if (c->stage_c.ensure(ab)) return ARK_HIP_ERR_NOMEM;
   ARK_HIP_TRY(hipMemcpyAsync(c->stage_c.p, delta_xy, ab, hipMemcpyHostToDevice, c->stream));
-  switch (curve) {
-#ifndef ARK_HIP_DEV
-    case 0: rc = sw_add_affine_BN254_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
-#endif
-    case 1: rc = sw_add_affine_BLS12_381_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
-#ifndef ARK_HIP_DEV
-    case 2: rc = sw_add_affine_BLS12_377_G1(d_in, d_out, n, c->stage_c.p, c->stream); break;
-#endif
-#ifndef ARK_HIP_DEV
-    case 3: rc = sw_add_affine_BLS12_377_G2(d_in, d_out, n, c->stage_c.p, c->stream); break;
-#endif
-#ifndef ARK_HIP_DEV
-    case 4: rc = sw_add_affine_BLS12_381_G2(d_in, d_out, n, c->stage_c.p, c->stream); break;
-#endif
-  }
+  int rc = add_affine_dispatch(curve, d_in, d_out, n, c->stage_c.p, c->stream);
   if (rc) return rc;
   ARK_HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
@@ -529,36 +961,24 @@ int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_
 // CurveGroup::normalize_batch for n Projective points in device memory -> n Affine points (device memory)
 int ark_hip_sw_normalize_batch_device(int curve, const void* d_jac, void* d_out_xy, size_t n) {
   if (curve < 0 || curve > 4 || (n && (!d_jac || !d_out_xy))) return ARK_HIP_ERR_ARG;
-  int rc = ensure_ctx();
+  ARK_SCOPE(sc);
+  int rc = normalize_dispatch(curve, d_jac, d_out_xy, n, sc.c->stream);
   if (rc) return rc;
-  Context* c = g_ctx;
-  switch (curve) {
-#ifndef ARK_HIP_DEV
-    case 0: rc = sw_normalize_batch_BN254_G1(d_jac, d_out_xy, n, c->stream); break;
-    case 2: rc = sw_normalize_batch_BLS12_377_G1(d_jac, d_out_xy, n, c->stream); break;
-    case 3: rc = sw_normalize_batch_BLS12_377_G2(d_jac, d_out_xy, n, c->stream); break;
-    case 4: rc = sw_normalize_batch_BLS12_381_G2(d_jac, d_out_xy, n, c->stream); break;
-#endif
-    case 1: rc = sw_normalize_batch_BLS12_381_G1(d_jac, d_out_xy, n, c->stream); break;
-    default: return ARK_HIP_ERR_ARG;
-  }
-  if (rc) return rc;
-  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
   return 0;
 }
 
 // ---- test hooks ----
 static int run_elementwise(size_t abytes, size_t bbytes, size_t rbytes, const void* a, const void* b, void* r,
-                           int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t), int op, size_t n) {
+                           elementwise_fn fn, int op, size_t n) {
   if (!fn) return ARK_HIP_ERR_ARG;  // curve/field not in this (development) build
-  int rc = ensure_ctx();
-  if (rc) return rc;
-  Context* c = g_ctx;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
   if (n == 0) return 0;
   if (c->stage_a.ensure(abytes) || c->stage_b.ensure(bbytes ? bbytes : 16) || c->stage_c.ensure(rbytes)) return ARK_HIP_ERR_NOMEM;
   ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, a, abytes, hipMemcpyHostToDevice, c->stream));
   if (b) ARK_HIP_TRY(hipMemcpyAsync(c->stage_b.p, b, bbytes, hipMemcpyHostToDevice, c->stream));
-  rc = fn(op, c->stage_a.p, b ? c->stage_b.p : nullptr, c->stage_c.p, n, c->stream);
+  int rc = fn(op, c->stage_a.p, b ? c->stage_b.p : nullptr, c->stage_c.p, n, c->stream);
   if (rc) return rc;
   ARK_HIP_TRY(hipMemcpyAsync(r, c->stage_c.p, rbytes, hipMemcpyDeviceToHost, c->stream));
   ARK_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -568,50 +988,16 @@ static int run_elementwise(size_t abytes, size_t bbytes, size_t rbytes, const vo
 int ark_hip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n) {
   if (!a || !r || op < 0 || op > 8 || op == 6) return ARK_HIP_ERR_ARG;
   size_t fb = field_bytes(field);
-  int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t) = nullptr;
-  switch (field) {
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BN254_FR: fn = test_field_op_BN254_FR; break;
-#endif
-    case ARK_HIP_BLS12_381_FR: fn = test_field_op_BLS12_381_FR; break;
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BLS12_377_FR: fn = test_field_op_BLS12_377_FR; break;
-#endif
-    // base fields: through the G1 curve that lives over them (ops 0..5)
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BN254_FQ: fn = test_basefield_op_BN254_G1; break;
-#endif
-    case ARK_HIP_BLS12_381_FQ: fn = test_basefield_op_BLS12_381_G1; break;
-#ifndef ARK_HIP_DEV
-    case ARK_HIP_BLS12_377_FQ: fn = test_basefield_op_BLS12_377_G1; break;
-#endif
-    default: return ARK_HIP_ERR_ARG;
-  }
+  if (field < 0 || field > 5) return ARK_HIP_ERR_ARG;
   if ((field == ARK_HIP_BN254_FQ || field == ARK_HIP_BLS12_381_FQ || field == ARK_HIP_BLS12_377_FQ) && op > 5)
     return ARK_HIP_ERR_ARG;
-  return run_elementwise(n * fb, b ? n * fb : 0, n * fb, a, b, r, fn, op, n);
+  return run_elementwise(n * fb, b ? n * fb : 0, n * fb, a, b, r, field_op_fn(field), op, n);
 }
 
 int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n) {
   if (curve < 0 || curve > 4 || !a || !r || op < 0 || op > 5) return ARK_HIP_ERR_ARG;
   size_t fb = (size_t)CURVES[curve].fe_words * 8;
-  int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t) = nullptr;
-  switch (curve) {
-#ifndef ARK_HIP_DEV
-    case 0: fn = test_basefield_op_BN254_G1; break;
-#endif
-    case 1: fn = test_basefield_op_BLS12_381_G1; break;
-#ifndef ARK_HIP_DEV
-    case 2: fn = test_basefield_op_BLS12_377_G1; break;
-#endif
-#ifndef ARK_HIP_DEV
-    case 3: fn = test_basefield_op_BLS12_377_G2; break;
-#endif
-#ifndef ARK_HIP_DEV
-    case 4: fn = test_basefield_op_BLS12_381_G2; break;
-#endif
-  }
-  return run_elementwise(n * fb, b ? n * fb : 0, n * fb, a, b, r, fn, op, n);
+  return run_elementwise(n * fb, b ? n * fb : 0, n * fb, a, b, r, basefield_op_fn(curve), op, n);
 }
 
 int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64_t* other, uint64_t* out, size_t n) {
@@ -621,23 +1007,7 @@ int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64
   size_t bbytes = (kind == 2 || kind == 3) ? n * fb * 2 : (kind == 4 ? n * fb * 4 : 0);
   size_t rbytes = n * fb * (kind == 6 ? 3 : 4);
   if (bbytes && !other) return ARK_HIP_ERR_ARG;
-  int (*fn)(int, const void*, const void*, void*, size_t, hipStream_t) = nullptr;
-  switch (curve) {
-#ifndef ARK_HIP_DEV
-    case 0: fn = test_point_op_BN254_G1; break;
-#endif
-    case 1: fn = test_point_op_BLS12_381_G1; break;
-#ifndef ARK_HIP_DEV
-    case 2: fn = test_point_op_BLS12_377_G1; break;
-#endif
-#ifndef ARK_HIP_DEV
-    case 3: fn = test_point_op_BLS12_377_G2; break;
-#endif
-#ifndef ARK_HIP_DEV
-    case 4: fn = test_point_op_BLS12_381_G2; break;
-#endif
-  }
-  return run_elementwise(abytes, bbytes, rbytes, acc, bbytes ? other : nullptr, out, fn, kind, n);
+  return run_elementwise(abytes, bbytes, rbytes, acc, bbytes ? other : nullptr, out, point_op_fn(curve), kind, n);
 }
 
 }  // extern "C"

@@ -4,30 +4,29 @@
 //   curves/bls12_377/src/curves/g1.rs:30-60, g2.rs:22-72 (+ fields/fq2.rs:12-13 NONRESIDUE = -5).
 #pragma once
 #include "ec.cuh"
-#include "lazy.cuh"
 
+#ifndef ARK_ACC_MIN_WAVES_G1
+#define ARK_ACC_MIN_WAVES_G1 1
+#endif
 namespace arkhip {
 
 struct BN254_G1 {
-  static constexpr int ACC_MIN_WAVES = 1;   // min waves per SIMD requested for the accumulate kernel
+  static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
-  static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 0;
   typedef Fp<BN254_FQ> F;
   typedef BN254_FR S;
 };
 struct BLS12_381_G1 {
-  static constexpr int ACC_MIN_WAVES = 1;   // min waves per SIMD requested for the accumulate kernel
+  static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
-  static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 1;
   typedef Fp<BLS12_381_FQ> F;
   typedef BLS12_381_FR S;
 };
 struct BLS12_377_G1 {
-  static constexpr int ACC_MIN_WAVES = 1;   // min waves per SIMD requested for the accumulate kernel
+  static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
-  static constexpr bool LAZY = false;  // 28-bit-limb accumulate (lazy.cuh): parity-green, measured no faster in situ
   static constexpr int ID = 2;
   typedef Fp<BLS12_377_FQ> F;
   typedef BLS12_377_FR S;
@@ -35,7 +34,6 @@ struct BLS12_377_G1 {
 struct BLS12_377_G2 {
   static constexpr int ACC_MIN_WAVES = 1;   // (2 = cap at 256 registers: measured slower, the extra spills cost more than the second wave hides)
   static constexpr bool RELAXED = false;
-  static constexpr bool LAZY = false;  // lazy form not defined over Fp2
   static constexpr int ID = 3;
   typedef Fp2<BLS12_377_FQ, 5> F;
   typedef BLS12_377_FR S;
@@ -43,7 +41,6 @@ struct BLS12_377_G2 {
 struct BLS12_381_G2 {
   static constexpr int ACC_MIN_WAVES = 1;   // (2 = cap at 256 registers: measured slower, the extra spills cost more than the second wave hides)
   static constexpr bool RELAXED = false;
-  static constexpr bool LAZY = false;  // lazy form not defined over Fp2
   static constexpr int ID = 4;
   typedef Fp2<BLS12_381_FQ, 1> F;
   typedef BLS12_381_FR S;

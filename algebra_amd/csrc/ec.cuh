@@ -152,7 +152,7 @@ ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
   F ppp = F::mul_r(p, pp);
   F q = F::mul_r(acc.x, pp);
   F x3 = F::sub_r(F::sub_r(F::mul_r(r, r), ppp), F::dbl_r(q));
-  F y3 = F::sub_r(F::mul_r(r, F::sub_r(q, x3)), F::mul_r(acc.y, ppp));
+  F y3 = F::sop2_r(r, F::sub_r(q, x3), F::neg_r(acc.y), ppp);  // R (Q - X3) - Y1 PPP under one reduction
   acc.x = x3;
   acc.y = y3;
   acc.zz = F::mul_r(acc.zz, pp);

@@ -68,6 +68,9 @@ struct FftPassArgs {
   int kp;      // stages in this pass
   int t;       // log2 lanes
   int last;    // last pass: lanes = top bits, bit-reversed write-back
+  int zskip;   // first executed pass of a degree-aware transform (fft.rs:29-71): the input holds only the first
+               // n >> zskip coefficients, the first zskip stages are not run -- their effect on a zero-padded input,
+               // x'[pos] = x[pos mod d] * w^((pos mod d) * bitrev_z(pos / d)), d = n >> zskip, is applied by the loads
   const u32* roots;    // w^j, j < n/2
   const u32* pre_lo;   // first pass: x[pos] *= pre_hi[pos >> 10] * pre_lo[pos & 1023]   (nullable)
   const u32* pre_hi;
@@ -132,7 +135,8 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
           pos = ((size_t)r << (k - t)) | ((size_t)tile << kp) | q;
         }
         ps[it] = pos;
-        const uint4* g = (const uint4*)(src + pos * F::N);
+        const size_t spos = a.zskip ? (pos & (((size_t)1 << (k - a.zskip)) - 1)) : pos;
+        const uint4* g = (const uint4*)(src + spos * F::N);
         v0[it] = g[0];
         v1[it] = g[1];
       }
@@ -141,13 +145,26 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
     for (int it = 0; it < FFT_MAX_EPT; it++) {
       u32 e = tid + it * FFT_THREADS;
       if (e < E) {
+        const size_t pos = ps[it];
+        const size_t spos = a.zskip ? (pos & (((size_t)1 << (k - a.zskip)) - 1)) : pos;
         if (a.pre_lo) {
-          size_t pos = ps[it];
           F x = fft_unpack<F>(v0[it], v1[it]);
-          F pw = F::mul(F::load(a.pre_hi + (pos >> PW_LO_BITS) * F::N),
-                        F::load(a.pre_lo + (pos & ((1u << PW_LO_BITS) - 1)) * F::N));
+          F pw = F::mul(F::load(a.pre_hi + (spos >> PW_LO_BITS) * F::N),
+                        F::load(a.pre_lo + (spos & ((1u << PW_LO_BITS) - 1)) * F::N));
           x = F::mul(x, pw);
           fft_pack<F>(x, v0[it], v1[it]);
+        }
+        if (a.zskip) {
+          const u32 blk = (u32)(pos >> (k - a.zskip));
+          const size_t ex = (spos * (size_t)bitrev32(blk, a.zskip)) & (((size_t)1 << k) - 1);
+          if (ex != 0) {
+            const size_t half = (size_t)1 << (k - 1);
+            F x = fft_unpack<F>(v0[it], v1[it]);
+            F w = F::load(a.roots + (ex & (half - 1)) * F::N);
+            x = F::mul(x, w);
+            if (ex >= half) x = F::neg(x);  // w^(n/2) = -1
+            fft_pack<F>(x, v0[it], v1[it]);
+          }
         }
         pl0[e] = v0[it];
         pl1[e] = v1[it];
@@ -313,11 +330,13 @@ struct FftWorkspace {
   DevBuf tmp;                          // ping buffer for the multi-pass transform
   DevBuf pw;                           // coset power tables + constants
   DevBuf stage;                        // host-pointer entry: device copy of the data
+  hipEvent_t ev[10] = {};              // pass timing (created on first use, reused)
   std::mutex mu;
   void release() {
     for (auto& kv : tables) { kv.second.roots.release(); kv.second.small.release(); }
     tables.clear();
     tmp.release(); pw.release(); stage.release();
+    for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   }
 };
 struct FftTimings { float total = 0; float pass[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int npass = 0; };
@@ -352,7 +371,11 @@ int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
   FftKey key{FP::ID, k, {root4[0], root4[1], root4[2], root4[3]}};
   auto it = ws.tables.find(key);
   if (it != ws.tables.end()) { *out = (const u32*)it->second.roots.p; return 0; }
-  FftTables& tb = ws.tables[key];
+  FftTables tb;  // built here, entered into the cache only once complete (a failed build must not leave a null table)
+  struct Guard {
+    FftTables* t;
+    ~Guard() { if (t) { t->roots.release(); t->small.release(); } }
+  } guard{&tb};
   size_t half = k >= 1 ? ((size_t)1 << (k - 1)) : 1;
   if (tb.roots.ensure(half * F::BYTES)) return -3;
   const int LB = 11;
@@ -374,8 +397,12 @@ int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
     hipLaunchKernelGGL((fft_expand_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, d_lo, d_hi,
                        LB, half, (u32*)tb.roots.p);
   }
+  ARK_HIP_TRY(hipGetLastError());
   ARK_HIP_TRY(hipStreamSynchronize(stream));  // root4 is a caller stack pointer
-  *out = (const u32*)tb.roots.p;
+  FftTables& slot = ws.tables[key];
+  slot = tb;          // DevBuf is a plain handle: ownership moves to the cache
+  guard.t = nullptr;
+  *out = (const u32*)slot.roots.p;
   return 0;
 }
 
@@ -383,9 +410,11 @@ int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
 // root4:  group_gen (forward) or group_gen_inv (inverse) of the size-2^k domain, host pointer.
 // pre4:   coset offset h (forward coset FFT) or nullptr.        x[i] *= h^i before the transform
 // post4:  inverse: h^-1 or nullptr;  postc4: constant multiplier of every output (size_inv) or nullptr
+// zlog:   degree-aware forward transform (fft.rs:29-71): only the first 2^(k - zlog) elements of d_data are input
+//         (the rest is treated as zero whatever it holds) and the first zlog stages are not executed; 0 = plain.
 template <class FP>
 int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4,
-                   const uint64_t* post4, const uint64_t* postc4, hipStream_t stream, FftTimings* tm) {
+                   const uint64_t* post4, const uint64_t* postc4, int zlog, hipStream_t stream, FftTimings* tm) {
   typedef Fp<FP> F;
   std::lock_guard<std::mutex> lock(ws.mu);
   if (k < 0 || k > 30 || k > FP::TWO_ADICITY) return -2;
@@ -434,13 +463,20 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     // size-1 domain: X[0] = x[0] (h^0 = 1, n^-1 = 1)
     return 0;
   }
-  hipEvent_t ev[10];
+  if (zlog < 0 || zlog >= k) return -1;
+  if (zlog && k <= FFT_SINGLE_MAX) {  // tiny transform: zero-fill the tail and run it whole
+    ARK_HIP_TRY(hipMemsetAsync((char*)d_data + (n >> zlog) * F::BYTES, 0, (n - (n >> zlog)) * F::BYTES, stream));
+    zlog = 0;
+  }
+  hipEvent_t* ev = ws.ev;
   int nev = 0;
   if (tm) {
-    for (auto& e : ev) ARK_HIP_TRY(hipEventCreate(&e));
+    for (int i = 0; i < 10; i++)
+      if (!ev[i]) ARK_HIP_TRY(hipEventCreate(&ev[i]));
     ARK_HIP_TRY(hipEventRecord(ev[nev++], stream));
   }
-  // pass plan
+  // pass plan over the kx = k - zlog executed stages
+  const int kx = k - zlog;
   int P, kps[8], t;
   if (k <= FFT_SINGLE_MAX) {
     P = 1; kps[0] = k; t = 0;
@@ -448,8 +484,8 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     int maxkp = FFT_MAX_KP;
     const char* env = getenv("ARK_HIP_FFT_KP");
     if (env && atoi(env) >= 5 && atoi(env) <= 8) maxkp = atoi(env);
-    P = (k + maxkp - 1) / maxkp;
-    int base = k / P, rem = k % P;
+    P = (kx + maxkp - 1) / maxkp;
+    int base = kx / P, rem = kx % P;
     for (int i = 0; i < P; i++) kps[i] = base + (i < rem ? 1 : 0);
     t = FFT_LANE_BITS;
     const char* envt = getenv("ARK_HIP_FFT_T");  // tuning knob: log2 of adjacent columns per tile (2 or 3)
@@ -457,11 +493,11 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
   }
   u32* data = (u32*)d_data;
   u32* tmp = nullptr;
-  if (P > 1) {
+  if (P > 1 || zlog) {
     if (ws.tmp.ensure(n * F::BYTES)) return -3;
     tmp = (u32*)ws.tmp.p;
   }
-  int s0 = 0;
+  int s0 = zlog;
   for (int i = 0; i < P; i++) {
     FftPassArgs a;
     // columns per tile: keep every tile at 1024 elements (32 KiB of LDS, 4 elements per lane) -- passes with
@@ -474,6 +510,7 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
       if (ti > room) ti = room;
     }
     a.k = k; a.s0 = s0; a.kp = kps[i]; a.t = ti; a.last = (i == P - 1) ? 1 : 0;
+    a.zskip = (i == 0) ? zlog : 0;
     a.roots = roots;
     a.pre_lo = (i == 0) ? pre_lo : nullptr;
     a.pre_hi = (i == 0) ? pre_hi : nullptr;
@@ -482,7 +519,8 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     a.post_const = a.last ? post_const : nullptr;
     const u32* src;
     u32* dst;
-    if (P == 1) { src = data; dst = data; }
+    if (P == 1 && zlog) { src = data; dst = tmp; }  // the compact input is read by every tile: not in place
+    else if (P == 1) { src = data; dst = data; }
     else if (i == 0) { src = data; dst = tmp; }
     else if (i == P - 1) { src = tmp; dst = data; }
     else { src = tmp; dst = tmp; }
@@ -492,13 +530,13 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     if (tm) ARK_HIP_TRY(hipEventRecord(ev[nev++], stream));
     s0 += kps[i];
   }
+  if (P == 1 && zlog) ARK_HIP_TRY(hipMemcpyAsync(data, tmp, n * F::BYTES, hipMemcpyDeviceToDevice, stream));
   ARK_HIP_TRY(hipGetLastError());
   if (tm) {
     ARK_HIP_TRY(hipStreamSynchronize(stream));
     tm->npass = P;
     for (int i = 0; i < P; i++) (void)hipEventElapsedTime(&tm->pass[i], ev[i], ev[i + 1]);
     (void)hipEventElapsedTime(&tm->total, ev[0], ev[nev - 1]);
-    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   return 0;
 }

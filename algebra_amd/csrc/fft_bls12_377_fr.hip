@@ -4,8 +4,8 @@
 #include "internal.hpp"
 namespace arkhip {
 int fft_run_BLS12_377_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4, const uint64_t* post4,
-               const uint64_t* postc4, hipStream_t stream, FftTimings* tm) {
-  return fft_run_device<BLS12_377_FR>(ws, d_data, k, root4, pre4, post4, postc4, stream, tm);
+               const uint64_t* postc4, int zlog, hipStream_t stream, FftTimings* tm) {
+  return fft_run_device<BLS12_377_FR>(ws, d_data, k, root4, pre4, post4, postc4, zlog, stream, tm);
 }
 int test_field_op_BLS12_377_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<Fp<BLS12_377_FR>, true>(op, a, b, r, n, s);

@@ -137,6 +137,31 @@ ARK_DEV void mont_cols_hi(Acc96& c, const u32* a, const u32* b, const u32* m, u3
   if constexpr (K + 1 < 2 * N - 1) mont_cols_hi<P, K + 1>(c, a, b, m, t);
 }
 
+// the same columns for a sum of two products  a*b + a2*b2  under ONE interleaved reduction
+// (montgomery_backend.rs:415-516 sum_of_products, M = 2): per column up to 3N products, < 2^70 -- fits the 96-bit
+// accumulator
+template <class P, int K>
+ARK_DEV void mont2_cols_lo(Acc96& c, const u32* a, const u32* b, const u32* a2, const u32* b2, u32* m) {
+  constexpr int N = P::N;
+  col_vv<0, K, K>(c, a, b);
+  col_vv<0, K, K>(c, a2, b2);
+  col_vp<P, 0, K - 1, K>(c, m);
+  m[K] = (u32)c.lo * P::INV;
+  mac_vs(c, m[K], PL<P, 0>::v);
+  acc_shift(c);
+  if constexpr (K + 1 < N) mont2_cols_lo<P, K + 1>(c, a, b, a2, b2, m);
+}
+template <class P, int K>
+ARK_DEV void mont2_cols_hi(Acc96& c, const u32* a, const u32* b, const u32* a2, const u32* b2, const u32* m, u32* t) {
+  constexpr int N = P::N;
+  col_vv<K - N + 1, N - 1, K>(c, a, b);
+  col_vv<K - N + 1, N - 1, K>(c, a2, b2);
+  col_vp<P, K - N + 1, N - 1, K>(c, m);
+  t[K - N] = (u32)c.lo;
+  acc_shift(c);
+  if constexpr (K + 1 < 2 * N - 1) mont2_cols_hi<P, K + 1>(c, a, b, a2, b2, m, t);
+}
+
 // ---- the field element ----------------------------------------------------------------------
 template <class P_>
 struct Fp {
@@ -375,6 +400,75 @@ struct Fp {
     }
     return r;
   }
+  // 2p - a for a relaxed a (<= 2p): a representative of -a in [0, 2p]; only ever used as a multiplication operand
+  ARK_HD static Fp neg_r(const Fp& a) {
+    Fp r;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const u32 p2 = (i == 0) ? ((u32)P::P[0] << 1) : (((u32)P::P[i] << 1) | ((u32)P::P[i - 1] >> 31));
+      u32 bo;
+      r.l[i] = __builtin_subc(p2, a.l[i], borrow, &bo);
+      borrow = bo;
+    }
+    return r;
+  }
+  // a*b + c*d with one interleaved reduction on relaxed operands (all <= 2p): (8p^2 + m p)/R < p (8p/R + 1), i.e.
+  // already < 2p when 8p <= R (BLS12-381, BLS12-377); otherwise (BN254: < 2.6p) one conditional -2p follows.
+  // Saves one of the two reductions of  Y3 = R (Q - X3) - Y1 PPP  in every bucket addition.
+  ARK_HD static Fp sop2_r(const Fp& a, const Fp& b, const Fp& c2, const Fp& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Acc96 c{0, 0};
+    u32 m[N];
+    u32 t[N];
+    mont2_cols_lo<P, 0>(c, a.l, b.l, c2.l, d.l, m);
+    mont2_cols_hi<P, N>(c, a.l, b.l, c2.l, d.l, m, t);
+    t[N - 1] = (u32)c.lo;
+    if constexpr ((P::P[N - 1] >> 29) == 0) {
+      Fp r;
+#pragma unroll
+      for (int i = 0; i < N; i++) r.l[i] = t[i];
+      return r;
+    } else {
+      return reduce_2p(t);
+    }
+#else
+    return add(mul(a.canonical(), b.canonical()), mul(c2.canonical(), d.canonical()));
+#endif
+  }
+  // canonical form: a*b + c*d for operands < p, except that `c2` may be any N-limb value up to 6p (a small multiple
+  // of a negated element: the -beta*a1 term of an Fp2 product); (p^2 + 6p^2 + m p)/R < p (7p/R + 1) < 2p.
+  ARK_HD static Fp sop2(const Fp& a, const Fp& b, const Fp& c2, const Fp& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Acc96 c{0, 0};
+    u32 m[N];
+    u32 t[N];
+    mont2_cols_lo<P, 0>(c, a.l, b.l, c2.l, d.l, m);
+    mont2_cols_hi<P, N>(c, a.l, b.l, c2.l, d.l, m, t);
+    t[N - 1] = (u32)c.lo;
+    return reduce_once(t);
+#else
+    return add(mul(a, b), mul(reduce_full(c2), d));
+#endif
+  }
+  // host helper: any N-limb value -> [0, p) by repeated subtraction (only small multiples of p occur)
+  ARK_HD static Fp reduce_full(const Fp& a) {
+    Fp r = a;
+    for (int it = 0; it < 8; it++) {
+      u32 d[N];
+      u32 borrow = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        u32 bo;
+        d[i] = __builtin_subc(r.l[i], (u32)P::P[i], borrow, &bo);
+        borrow = bo;
+      }
+      if (borrow) break;
+#pragma unroll
+      for (int i = 0; i < N; i++) r.l[i] = d[i];
+    }
+    return r;
+  }
   ARK_HD bool is_zero_mod_p() const {  // relaxed value: 0 or p
     u32 o = 0, q = 0;
 #pragma unroll
@@ -389,6 +483,7 @@ struct Fp {
   // of this 700-instruction sequence (minutes of compile time per kernel, scratch spills).  Operands travel by value
   // so the AMDGPU calling convention keeps them in VGPRs.
   __host__ __device__ __attribute__((noinline)) static Fp mul_call(Fp a, Fp b) { return mul(a, b); }
+  __host__ __device__ __attribute__((noinline)) static Fp sop2_call(Fp a, Fp b, Fp c, Fp d) { return sop2(a, b, c, d); }
   // Montgomery -> canonical integer (montgomery_backend.rs:396-412): multiply by 1
   ARK_HD static Fp from_mont(const Fp& a) {
     Fp o = zero();
@@ -482,7 +577,42 @@ struct Fp2 {
     else if constexpr (NEG_BETA == 5) return B::add(B::dbl(B::dbl(x)), x);
     else { static_assert(NEG_BETA == 1 || NEG_BETA == 5, "unsupported nonresidue"); return x; }
   }
+  // NEG_BETA * (p - x): an N-limb representative (<= NEG_BETA * p, not reduced) of beta * x, used only as an operand of
+  // Fp::sop2
+  ARK_HD static B neg_beta_times_neg(const B& x) {
+    static_assert((u64)(1 + NEG_BETA) * ((u64)P::P[B::N - 1] + 1) < (1ull << 32), "NEG_BETA * p must fit N limbs");
+    B n;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < B::N; i++) {
+      u32 bo;
+      n.l[i] = __builtin_subc((u32)P::P[i], x.l[i], borrow, &bo);
+      borrow = bo;
+    }
+    if constexpr (NEG_BETA == 1) return n;
+    B q;  // 4n + n
+#pragma unroll
+    for (int i = B::N - 1; i > 0; i--) q.l[i] = (n.l[i] << 2) | (n.l[i - 1] >> 30);
+    q.l[0] = n.l[0] << 2;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < B::N; i++) {
+      u32 co;
+      q.l[i] = __builtin_addc(q.l[i], n.l[i], c, &co);
+      c = co;
+    }
+    return q;
+  }
+  // (a0 + a1 u)(b0 + b1 u) = (a0 b0 + beta a1 b1) + (a0 b1 + a1 b0) u: two sums of two products, each under ONE
+  // Montgomery reduction (quadratic_extension.rs:646-654 via Fp::sum_of_products, montgomery_backend.rs:415-516):
+  // 4 limb products + 2 reductions = the multiply work of Karatsuba's 3 full products, without its 5 additions.
   ARK_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
+    Fp2 r;
+    r.c0 = B::sop2_call(a.c0, b.c0, neg_beta_times_neg(a.c1), b.c1);
+    r.c1 = B::sop2_call(a.c0, b.c1, a.c1, b.c0);
+    return r;
+  }
+  ARK_HD static Fp2 mul_karatsuba(const Fp2& a, const Fp2& b) {
     B v0 = B::mul_call(a.c0, b.c0);
     B v1 = B::mul_call(a.c1, b.c1);
     B s = B::mul_call(B::add(a.c0, a.c1), B::add(b.c0, b.c1));

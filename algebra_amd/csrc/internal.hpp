@@ -7,13 +7,16 @@
 namespace arkhip {
 struct MsmWorkspace;
 struct MsmTimings;
+struct MsmPlan;
 struct FftWorkspace;
 struct FftTimings;
 
 // one function per curve / field, defined in msm_<curve>.hip / fft_<field>.hip
 #define ARK_DECL_CURVE(NAME)                                                                                    \
-  int msm_run_##NAME(MsmWorkspace& ws, const void* d_bases, const void* d_scalars, size_t n, int mont,           \
-                     uint64_t* out_xyz, hipStream_t stream, MsmTimings* tm);                                      \
+  int msm_enqueue_##NAME(MsmWorkspace& ws, const void* d_points, size_t wstride, const MsmPlan* prepared,         \
+                         const void* d_scalars, size_t n, int mont, hipStream_t stream, bool timing);            \
+  int msm_finish_##NAME(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm);                          \
+  int msm_prepare_##NAME(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, hipStream_t stream);   \
   int test_basefield_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);    \
   int test_point_op_##NAME(int kind, const void* d_acc, const void* d_other, void* d_out, size_t n, hipStream_t s); \
   int sw_add_affine_##NAME(const void* d_in, void* d_out, size_t n, const void* d_delta, hipStream_t s);        \
@@ -27,7 +30,7 @@ ARK_DECL_CURVE(BLS12_381_G2)
 
 #define ARK_DECL_FIELD(NAME)                                                                                    \
   int fft_run_##NAME(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4,         \
-                     const uint64_t* post4, const uint64_t* postc4, hipStream_t stream, FftTimings* tm);          \
+                     const uint64_t* post4, const uint64_t* postc4, int zlog, hipStream_t stream, FftTimings* tm);          \
   int test_field_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);          \
   int fft_axis_##NAME(FftWorkspace& ws, void* d_data, unsigned G, size_t cols, const uint64_t* root4, hipStream_t s);
 ARK_DECL_FIELD(BN254_FR)

@@ -60,6 +60,30 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
   typedef Fp<SP> S;
   S s = S::load(scalars + (size_t)i * S::N);
   if (mont) s = S::from_mont(s);  // mod.rs:60-62 into_bigint
+  // msm_bigint accepts any BigInt<4>.  The reference's make_digits (mod.rs:754-794) covers ceil(BITS/c)*c bits, so it is
+  // exact (as an integer multiple, hence mod r on the prime-order subgroup) for every s < 2^BITS and drops higher
+  // bits in a window-size-dependent way: such scalars are rejected here (ARK_HIP_ERR_SCALAR_RANGE).
+  // s in [r, 2^BITS): s -= r once (2^BITS < 2r for the three scalar fields), then the fold below applies.
+  if constexpr (SP::BITS < 32 * S::N) {
+    if ((s.l[S::N - 1] >> (SP::BITS - 32 * (S::N - 1))) != 0) {
+      atomicOr(err, 1u);
+      s = S::zero();
+    }
+  }
+  {
+    u32 u[S::N];
+    u32 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < S::N; k++) {
+      u32 bo;
+      u[k] = __builtin_subc(s.l[k], (u32)SP::P[k], borrow, &bo);
+      borrow = bo;
+    }
+    if (!borrow) {
+#pragma unroll
+      for (int k = 0; k < S::N; k++) s.l[k] = u[k];
+    }
+  }
   // t = r - s ; use it (and negate the point) when t < s
   u32 t[S::N];
   {
@@ -99,7 +123,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
     int d = (int)raw - (int)(carry << cw);
     if (d != 0) {
       u32 mag = d < 0 ? (u32)(-d) : (u32)d;
-      if (mag > half) {  // only reachable for a scalar >= 2^BITS, which the reference does not accept either
+      if (mag > half) {  // unreachable after the range handling above; kept as a tripwire
         atomicOr(err, 1u);
         mag = half;
       }
@@ -192,8 +216,15 @@ static __global__ void __launch_bounds__(256) scan_apply(const u32* __restrict__
 // global atomics out of it.
 static constexpr int ORDER_TILE = 2048;
 static constexpr int ORDER_BINS = 256;
+// A lane owns `wsum` runs (one per window when the windows share a bucket set, else 1) `wstride` slots apart.
+__device__ __forceinline__ u32 msm_lane_load(const u32* __restrict__ offsets, size_t g, int wsum, size_t wstride) {
+  u32 cnt = 0;
+  for (int w = 0; w < wsum; w++) cnt += offsets[g + w * wstride + 1] - offsets[g + w * wstride];
+  return cnt;
+}
 static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* __restrict__ offsets, size_t nb, int shift,
-                                                                    u32 nblocks, u32* __restrict__ block_hist) {
+                                                                    u32 nblocks, int wsum, size_t wstride,
+                                                                    u32* __restrict__ block_hist) {
   __shared__ u32 sh[ORDER_BINS];
   sh[threadIdx.x] = 0;
   __syncthreads();
@@ -201,7 +232,7 @@ static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* _
   for (int k = 0; k < ORDER_TILE / 256; k++) {
     size_t g = base + threadIdx.x + (size_t)k * 256;
     if (g < nb) {
-      u32 cls = (offsets[g + 1] - offsets[g]) >> shift;
+      u32 cls = msm_lane_load(offsets, g, wsum, wstride) >> shift;
       if (cls > ORDER_BINS - 1) cls = ORDER_BINS - 1;
       atomicAdd(&sh[ORDER_BINS - 1 - cls], 1u);  // class 0 of the output = heaviest
     }
@@ -210,7 +241,8 @@ static __global__ void __launch_bounds__(256) msm_order_hist_kernel(const u32* _
   block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = sh[threadIdx.x];  // bin-major
 }
 static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32* __restrict__ offsets, size_t nb, int shift,
-                                                                       u32 nblocks, const u32* __restrict__ block_off,
+                                                                       u32 nblocks, int wsum, size_t wstride,
+                                                                       const u32* __restrict__ block_off,
                                                                        u32* __restrict__ order) {
   __shared__ u32 sh[ORDER_BINS];
   sh[threadIdx.x] = block_off[(size_t)threadIdx.x * nblocks + blockIdx.x];
@@ -219,7 +251,7 @@ static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32
   for (int k = 0; k < ORDER_TILE / 256; k++) {
     size_t g = base + threadIdx.x + (size_t)k * 256;
     if (g < nb) {
-      u32 cls = (offsets[g + 1] - offsets[g]) >> shift;
+      u32 cls = msm_lane_load(offsets, g, wsum, wstride) >> shift;
       if (cls > ORDER_BINS - 1) cls = ORDER_BINS - 1;
       u32 pos = atomicAdd(&sh[ORDER_BINS - 1 - cls], 1u);
       order[pos] = (u32)g;
@@ -270,6 +302,102 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
   acc.store(buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES);  // g is a slot (msm_sort.cuh)
 }
 
+// ---- K4s: bucket accumulation over a PREPARED base set ---------------------------------------------
+// With the per-window multiples T_w[i] = 2^(offset_w) P_i precomputed once for a fixed base set (an SRS), every
+// window's digit d contributes d * T_w[i] with weight 1: all W windows share ONE set of 2^(c-1) buckets, so the
+// bucket reduction shrinks W-fold and c can grow (fewer windows, fewer mixed additions) -- 288 GB of HBM pay for
+// the W-fold larger table.  The sort is unchanged (runs per (window, bucket) slot); a lane owns bucket slot s and
+// walks its W runs, gathering from the window's table.  Runs too long for one lane (`heavy`) are skipped here,
+// summed by the K4h kernels and added to the bucket afterwards (msm_apply_heavy_kernel).
+template <class C>
+__global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_kernel(
+    const char* __restrict__ table, size_t wstride, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
+    const u32* __restrict__ order, u32 nbuckets, int W, int B, u32 heavy_thresh, int HB, int LB,
+    char* __restrict__ buckets) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  const u32 s = order ? order[t] : t;
+  Pt acc = Pt::zero();
+  int w = 0;                    // next window to open
+  u32 na = offsets[s], nb2 = offsets[s + 1];  // bounds of window w's run, fetched one window ahead
+  u32 j = 0, end = 0;
+  const char* wbase = table;
+  auto open_next = [&]() -> bool {  // (j, end, wbase) <- the next non-empty run; heavy runs are folded on the way
+    while (w < W) {
+      const u32 a = na, b = nb2;
+      const char* wb = table + (size_t)w * wstride * Affine<F>::BYTES;
+      w++;
+      if (w < W) {
+        const u32 g = ((u32)w << B) | s;
+        na = offsets[g];
+        nb2 = offsets[g + 1];
+      }
+      if (b - a > heavy_thresh) continue;  // summed by the K4h kernels, added by msm_apply_heavy_kernel
+      if (b > a) {
+        j = a;
+        end = b;
+        wbase = wb;
+        return true;
+      }
+    }
+    return false;
+  };
+  if (open_next()) {
+    u32 e = sorted[j];
+    Affine<F> p = Affine<F>::load(wbase + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+    for (;;) {
+      u32 e_next = 0;
+      Affine<F> p_next = p;
+      bool more;
+      if (j + 1 < end) {
+        j++;
+        more = true;
+      } else {
+        more = open_next();
+      }
+      if (more) {  // the next gather is in flight during this addition
+        e_next = sorted[j];
+        p_next = Affine<F>::load(wbase + (size_t)(e_next & 0x7fffffffu) * Affine<F>::BYTES);
+      }
+      if (!p.is_zero()) {
+        F y = F::cond_neg(p.y, (e >> 31) != 0);
+        if constexpr (C::RELAXED) xyzz_madd_relaxed<F>(acc, p.x, y);
+        else xyzz_madd<F>(acc, p.x, y);
+      }
+      if (!more) break;
+      e = e_next;
+      p = p_next;
+    }
+  }
+  if constexpr (C::RELAXED) acc = xyzz_canonical<F>(acc);
+  acc.store(buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * Pt::BYTES);
+}
+
+// T_{w+1}[i] = 2^width * T_w[i], affine in / affine out (one Fermat inversion per point; a one-time cost per base set)
+template <class C>
+__global__ void __launch_bounds__(128) msm_table_step_kernel(const char* __restrict__ in, char* __restrict__ out, size_t n,
+                                                             int width) {
+  typedef typename C::F F;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = Affine<F>::load(in + i * Affine<F>::BYTES);
+  F x = F::zero(), y = F::zero();
+  if (!p.is_zero()) {
+    XYZZ<F> acc = xyzz_mdbl<F>(p.x, p.y);
+    for (int k = 1; k < width; k++) acc = xyzz_dbl<F>(acc);
+    if (!acc.is_zero()) {
+      F zzzi = F::inverse(acc.zzz);
+      F zzi = F::sqr(F::mul(acc.zz, zzzi));  // ZZ^-1 = (ZZ * ZZZ^-1)^2 since ZZ^3 = ZZZ^2
+      x = F::mul(acc.x, zzi);
+      y = F::mul(acc.y, zzzi);
+    }
+  }
+  x.store(out + i * Affine<F>::BYTES);
+  y.store(out + i * Affine<F>::BYTES + F::BYTES);
+}
+
 // ---- K4h: heavy buckets --------------------------------------------------------------------------
 // A bucket far above the mean load (non-uniform scalars: the reference's bool / u8 / ... benches, or
 // many equal scalars) would pin one lane for its whole length.  Buckets above `thresh` are skipped by
@@ -300,7 +428,7 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
                                                                 const u32* __restrict__ sorted,
                                                                 const u32* __restrict__ offsets,
                                                                 const u32* __restrict__ ctr,
-                                                                const uint2* __restrict__ items,
+                                                                const uint2* __restrict__ items, size_t wstride, int B,
                                                                 char* __restrict__ partials) {
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
@@ -317,9 +445,10 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
       u32 lo = offsets[it.x] + it.y * HEAVY_CHUNK;
       u32 hi = offsets[it.x + 1];
       if (hi > lo + HEAVY_CHUNK) hi = lo + HEAVY_CHUNK;
+      const char* wb = bases + (size_t)(it.x >> B) * wstride * Affine<F>::BYTES;  // prepared set: the window's table
       for (u32 j = lo + lane; j < hi; j += 64) {
         u32 e = sorted[j];
-        Affine<F> p = Affine<F>::load(bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+        Affine<F> p = Affine<F>::load(wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
         if (!p.is_zero()) {
           F y = F::cond_neg(p.y, (e >> 31) != 0);
           xyzz_madd<F>(acc, p.x, y);
@@ -342,10 +471,13 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
 }
 
 // one wave per heavy bucket: lanes stride over its chunk partials, then a 6-step LDS tree
-template <class C>
+// SHARED (prepared base set): the result goes to hfinal[slot] and its index into sorted[run start], where the lane
+// that owns the bucket picks it up (msm_accumulate_shared_kernel); else straight into the (window, bucket) cell.
+template <class C, bool SHARED>
 __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __restrict__ ctr,
                                                                const HeavyEntry* __restrict__ list,
                                                                const char* __restrict__ partials, int HB, int LB,
+                                                               const u32* __restrict__ offsets, u32* __restrict__ sorted,
                                                                char* __restrict__ buckets) {
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
@@ -369,77 +501,46 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __rest
     }
     __syncthreads();
   }
-  if (lane == 0) acc.store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
-}
-
-// ---- K4 (lazy form): base conversion pre-pass + bucket accumulation in 28-bit limbs -------------------
-// bases (reference layout, canonical Montgomery) -> x*2^(28L), y*2^(28L) as 2L u32 words per point
-template <class C>
-__global__ void __launch_bounds__(256) msm_bases_to_lazy_kernel(const char* __restrict__ bases, u32 n,
-                                                                u32* __restrict__ out) {
-  typedef typename C::F F;
-  typedef FpLazy<typename F::P> LZ;
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Affine<F> p = Affine<F>::load(bases + (size_t)i * Affine<F>::BYTES);
-  LZ x = LZ::from_canonical(p.x), y = LZ::from_canonical(p.y);  // identity (0,0) stays all-zero
-  u32* o = out + (size_t)i * 2 * LZ::L;
-  x.store(o);
-  y.store(o + LZ::L);
-}
-
-template <class LZ>
-__device__ __forceinline__ void lazy_point_load(const u32* __restrict__ q, LZ& x, LZ& y) {
-  constexpr int WORDS = 2 * LZ::L;  // 28 or 20: a multiple of 4
-  u32 w[WORDS];
-#pragma unroll
-  for (int k = 0; k < WORDS / 4; k++) {
-    uint4 v = ((const uint4*)q)[k];
-    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-  }
-#pragma unroll
-  for (int k = 0; k < LZ::L; k++) { x.l[k] = w[k]; y.l[k] = w[LZ::L + k]; }
-}
-
-template <class C>
-__global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const u32* __restrict__ lbases,
-                                                                  const u32* __restrict__ sorted,
-                                                                  const u32* __restrict__ offsets,
-                                                                  const u32* __restrict__ order, u32 nbuckets,
-                                                                  u32 heavy_thresh, int HB, int LB,
-                                                                  char* __restrict__ buckets) {
-  typedef typename C::F F;
-  typedef typename F::P P;
-  typedef FpLazy<P> LZ;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbuckets) return;
-  u32 g = order ? order[t] : t;
-  u32 j = offsets[g], end = offsets[g + 1];
-  if (end - j > heavy_thresh) return;
-  XYZZLazy<P> acc;
-  acc.inf = true;
-  acc.x = acc.y = acc.zz = acc.zzz = LZ::zero();
-  if (j < end) {
-    u32 e = sorted[j];
-    LZ px, py;
-    lazy_point_load<LZ>(lbases + (size_t)(e & 0x7fffffffu) * 2 * LZ::L, px, py);
-    for (;;) {
-      u32 e_next = 0;
-      LZ nx = px, ny = py;
-      bool more = j + 1 < end;
-      if (more) {
-        e_next = sorted[j + 1];
-        lazy_point_load<LZ>(lbases + (size_t)(e_next & 0x7fffffffu) * 2 * LZ::L, nx, ny);
-      }
-      if (!(px.limbs_all_zero() && py.limbs_all_zero())) xyzz_madd_lazy<P>(acc, px, py, (e >> 31) != 0);
-      if (!more) break;
-      e = e_next;
-      px = nx;
-      py = ny;
-      j++;
+  if (lane == 0) {
+    if constexpr (SHARED) {
+      acc.store(buckets + (size_t)slot * Pt::BYTES);  // `buckets` is the hfinal array here
+      sorted[offsets[h.bucket]] = slot;
+    } else {
+      acc.store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
     }
   }
-  xyzz_from_lazy<P>(acc).store(buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES);
+}
+
+// Prepared base set: adds the heavy runs' sums into their (shared) buckets after msm_accumulate_shared_kernel.  One
+// lane per heavy run (w, s); the lowest heavy window of bucket slot s owns the bucket and adds every heavy run of
+// that slot (their partial's index sits in sorted[run start]), so no two lanes touch one bucket.
+template <class C>
+__global__ void __launch_bounds__(64) msm_apply_heavy_kernel(const u32* __restrict__ ctr, const HeavyEntry* __restrict__ list,
+                                                             const u32* __restrict__ offsets,
+                                                             const u32* __restrict__ sorted,
+                                                             const char* __restrict__ hfinal, int W, int B,
+                                                             u32 heavy_thresh, int HB, int LB, char* __restrict__ buckets) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  const u32 h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= ctr[1]) return;
+  const u32 g = list[h].bucket;
+  const u32 w0 = g >> B, s = g & ((1u << B) - 1u);
+  for (u32 w = 0; w < w0; w++) {
+    const u32 gg = (w << B) | s;
+    if (offsets[gg + 1] - offsets[gg] > heavy_thresh) return;  // a lower window owns this bucket
+  }
+  char* cell = buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * Pt::BYTES;
+  Pt acc = Pt::load(cell);
+  for (u32 w = w0; w < (u32)W; w++) {
+    const u32 gg = (w << B) | s;
+    const u32 a = offsets[gg];
+    if (offsets[gg + 1] - a > heavy_thresh) {
+      Pt x = Pt::load(hfinal + (size_t)sorted[a] * Pt::BYTES);
+      xyzz_add<F>(acc, x);
+    }
+  }
+  acc.store(cell);
 }
 
 // ---- K5: one level of the bucket reduction ---------------------------------------------------------
@@ -543,9 +644,11 @@ struct MsmPlan {
   int W;          // windows
   int narrow;     // the top `narrow` windows are c-1 bits wide, so that the widths sum to bits exactly and no
                   // window is left with only a few significant bits (0: uniform widths)
-  size_t nb;      // bucket slots over all windows = W << (c-1)
+  size_t nb;      // bucket slots of the sort = W << (c-1)
+  bool shared;    // prepared base set: the W windows share one set of 2^(c-1) buckets
+  size_t nbuckets() const { return shared ? ((size_t)1 << (c - 1)) : nb; }
+  int red_windows() const { return shared ? 1 : W; }
 };
-
 
 // relative cost of one base-field product (Fp384 = 1): Fp256 ~0.5, Fp2 over Fp384 ~3.3
 static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 3.3 : 1.0); }
@@ -557,10 +660,6 @@ static inline int msm_scalar_bits(int curve_id) {
   }
 }
 
-// Window size.  Model (seconds) of the phases that depend on c, from this chip's measured rates
-// (profiles/): mixed additions stream at ~5.5e9/s (Fp384; scaled by `mul_cost` for other fields) but a
-// single bucket is a serial chain (~14 us per addition on a lightly loaded SIMD), the first reduction
-// level costs 2 full additions per bucket, the bit-sliced remainder ~0.5 ms.
 static inline void msm_window_layout(int c, int bits, int* W, int* narrow) {
   // signed digits of a (bits-1)-bit value (after the s -> r-s fold) need bits significant positions in total
   // (the top window is not recoded and must keep one spare bit).  W windows of c bits, the top `narrow` of them
@@ -575,17 +674,30 @@ static inline void msm_window_layout(int c, int bits, int* W, int* narrow) {
   *W = w;
   *narrow = deficit;
 }
-static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost = 1.0) {
+// bit offset of window w (sum of the widths below it): the weight 2^offset of its digits
+static inline int msm_window_offset(int w, int c, int W, int narrow) {
+  int off = 0;
+  for (int k = 0; k < w; k++) off += msm_window_width(k, c, W, narrow);
+  return off;
+}
+
+// Window size.  Model (seconds) of the phases that depend on c, from this chip's measured rates
+// (profiles/): mixed additions stream at ~5.5e9/s (Fp384; scaled by `mul_cost` for other fields) but a
+// single bucket is a serial chain (~14 us per addition on a lightly loaded SIMD), the first reduction
+// level costs 2 full additions per bucket, the bit-sliced remainder ~0.5 ms.  With a prepared base set
+// (`shared`) only one bucket set is reduced, which moves the optimum to wider windows.
+static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool shared) {
   int best_c = 3;
   double best = 1e300;
-  const char* env = getenv("ARK_HIP_MSM_C");
-  if (env && atoi(env) >= 3 && atoi(env) <= 24) {
+  const char* env = getenv(shared ? "ARK_HIP_MSM_C_PREPARED" : "ARK_HIP_MSM_C");
+  if (env && atoi(env) >= 3 && atoi(env) <= 26) {
     best_c = atoi(env);
   } else {
-    for (int c = 3; c <= 23; c++) {
+    for (int c = 3; c <= (shared ? 25 : 23); c++) {
       int W, narrow;
       msm_window_layout(c, bits, &W, &narrow);
-      const double nbk = (double)(W - narrow) * (double)(1u << (c - 1)) + (double)narrow * (double)(1u << (c - 2));
+      double nbk = (double)(W - narrow) * (double)(1u << (c - 1)) + (double)narrow * (double)(1u << (c - 2));
+      if (shared) nbk = (double)(1u << (c - 1));
       const double entries = (double)n * W;
       const double madd = 1.0 / 5.5e9 * mul_cost, fadd = 1.4 / 5.5e9 * mul_cost;
       double acc = entries * madd;
@@ -595,21 +707,23 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost = 1.0) {
       const double red0_lat = 2.0 * 8.0 * 21e-6 * mul_cost;     // >= 8 buckets per lane at level 0
       if (red0_lat > red0) red0 = red0_lat;
       const double bits_stage = 0.5e-3 * mul_cost;              // bit-sliced stage + host tail
-      const double sort = entries * 2.0e-11 + nbk * 1.0e-10;
+      const double sort = entries * 2.0e-11 + (double)W * (double)(1u << (c - 1)) * 1.0e-10;
       double cost = acc + red0 + bits_stage + sort;
-      if (narrow == 0) {
+      if (narrow == 0 && !shared) {
         // uniform widths: a top window with only a few significant bits funnels n/2^tb points into each of 2^tb
         // buckets: correct (heavy-bucket path) but measured ~1.4x slower.
         const int tb = (bits - 1) - (W - 1) * c;
         if (tb >= 1 && tb <= 5) cost *= 1.4;
       }
+      if ((size_t)n * (size_t)W >= (1ull << 32)) continue;  // 32-bit sort positions
       if (cost < best) { best = cost; best_c = c; }
     }
   }
   MsmPlan p;
   p.c = best_c;
+  p.shared = shared;
   msm_window_layout(best_c, bits, &p.W, &p.narrow);
-  if (getenv("ARK_HIP_MSM_UNIFORM")) {  // A/B knob: the older uniform-width layout
+  if (!shared && getenv("ARK_HIP_MSM_UNIFORM")) {  // A/B knob: the older uniform-width layout
     p.W = (bits + 1 + best_c - 1) / best_c;
     p.narrow = 0;
   }
@@ -641,45 +755,93 @@ struct DevBuf {
   }
 };
 
-struct MsmWorkspace {
-  DevBuf hctr, hlist, hitems, hpart, lbases, keys, part, thist, toff, sorted, offsets, sums, buckets, lvlS[2], lvlA[2], err, order, ohist, ooff;
-  void* pinned = nullptr;  // host staging for the window sums
+struct MsmTimings {  // filled when requested (HIP events on the MSM stream), milliseconds
+  float digits = 0, scan = 0, scatter = 0, accumulate = 0, reduce = 0, total = 0;
+  int c = 0, W = 0;
+};
+
+// One MSM in flight: the device work is enqueued on the stream, its (small) result lands in this slot's pinned
+// staging area, `done` fires when it has; the host tail runs in msm_finish().  Device workspaces are shared by
+// consecutive MSMs (stream order keeps them apart), the staging area is per slot.
+struct MsmJob {
+  void* pinned = nullptr;
   size_t pinned_cap = 0;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+  bool empty = false;     // n == 0: identity, nothing enqueued
+  MsmPlan pl{};
+  int nbits = 0, log2L0 = 0;
+  u32 Q = 0;
+  size_t npairs = 0;
+  bool timing = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+static constexpr int MSM_JOBS = 4;
+
+struct MsmWorkspace {
+  DevBuf hctr, hlist, hitems, hpart, hfinal, keys, part, thist, toff, sorted, offsets, sums, buckets, lvlS[2], lvlA[2], err,
+      order, ohist, ooff;
+  MsmJob jobs[MSM_JOBS];
   std::mutex mu;
+  bool attr_set = false;  // dynamic-LDS opt-in done for this device
   void release() {
-    hctr.release(); hlist.release(); hitems.release(); hpart.release();
-    lbases.release(); keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
+    hctr.release(); hlist.release(); hitems.release(); hpart.release(); hfinal.release();
+    keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
     offsets.release(); sums.release();
     order.release(); ohist.release(); ooff.release();
     buckets.release(); err.release();
     for (int i = 0; i < 2; i++) { lvlS[i].release(); lvlA[i].release(); }
-    if (pinned) (void)hipHostFree(pinned);
-    pinned = nullptr;
-    pinned_cap = 0;
+    for (auto& j : jobs) {
+      if (j.pinned) (void)hipHostFree(j.pinned);
+      j.pinned = nullptr;
+      j.pinned_cap = 0;
+      if (j.done) (void)hipEventDestroy(j.done);
+      j.done = nullptr;
+      for (auto& e : j.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+      j.busy = false;
+    }
   }
 };
 
-struct MsmTimings {  // filled when requested (HIP events on the MSM stream), milliseconds
-  float digits = 0, scan = 0, scatter = 0, accumulate = 0, reduce = 0, total = 0;
-};
+static inline int msm_job_pinned(MsmJob& j, size_t bytes) {
+  if (j.pinned_cap >= bytes) return 0;
+  if (j.pinned) (void)hipHostFree(j.pinned);
+  j.pinned = nullptr;
+  j.pinned_cap = 0;
+  ARK_HIP_TRY(hipHostMalloc(&j.pinned, bytes + 256));
+  j.pinned_cap = bytes + 256;
+  return 0;
+}
 
-// The whole single-GPU MSM with device-resident inputs.  out_xyz: host pointer, Jacobian x|y|z
-// Montgomery limbs (group.rs:34-41); identity = (R, R, 0) (group.rs:145-151).
+// Enqueue one single-GPU MSM with device-resident inputs on `stream`; returns the job slot (>= 0) or a negative code.
+//   points / wstride / prepared:  plain call: points = the n bases, wstride = 0, prepared = nullptr;
+//                                 prepared base set: points = the [W][wstride] table of per-window multiples and
+//                                 `prepared` = the plan it was built for (msm_prepare_table).
 template <class C>
-int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars, size_t n, int scalars_mont,
-                   uint64_t* out_xyz, hipStream_t stream, MsmTimings* tm) {
+int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const MsmPlan* prepared, const void* d_scalars,
+                size_t n, int scalars_mont, hipStream_t stream, bool timing) {
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
   std::lock_guard<std::mutex> lock(ws.mu);
+  int slot = -1;
+  for (int i = 0; i < MSM_JOBS; i++)
+    if (!ws.jobs[i].busy) { slot = i; break; }
+  if (slot < 0) return -6;  // ARK_HIP_ERR_BUSY
+  MsmJob& job = ws.jobs[slot];
+  job.empty = (n == 0);
+  job.timing = false;
   if (n == 0) {
-    Jac<F>::zero().store(out_xyz);
-    return 0;
+    job.busy = true;
+    return slot;
   }
   if (n >= (1ull << 31)) return -2;
-  const MsmPlan pl = msm_make_plan(n, C::S::BITS, msm_mul_cost(C::ID));
+  const MsmPlan pl = prepared ? *prepared : msm_make_plan(n, C::S::BITS, msm_mul_cost(C::ID), false);
   const int c = pl.c, W = pl.W;
-  const size_t nb = pl.nb;
+  const size_t nb = pl.nb;                      // sort slots
+  const size_t nbk = pl.nbuckets();             // accumulated buckets
+  const int Wr = pl.red_windows();
   if ((size_t)n * (size_t)W >= (1ull << 32)) return -2;  // sort positions are 32-bit
+  if (prepared && (wstride < n || (size_t)W * wstride >= (1ull << 31))) return -2;
   const size_t mwin = (size_t)1 << (c - 1);
 
   // bucket-id split for the two-pass partition sort (msm_sort.cuh)
@@ -695,123 +857,18 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   if (ws.thist.ensure(nthist * 4) || ws.toff.ensure((nthist + 1) * 4)) return -3;
   if (ws.offsets.ensure((nb + 1) * 4)) return -3;
   const u32 ntscan = (u32)((nthist + SCAN_TILE - 1) / SCAN_TILE);
-  const u32 noblk = (u32)((nb + ORDER_TILE - 1) / ORDER_TILE);
+  const u32 noblk = (u32)((nbk + ORDER_TILE - 1) / ORDER_TILE);
   const size_t nohist = (size_t)noblk * ORDER_BINS;
   const u32 noscan = (u32)((nohist + SCAN_TILE - 1) / SCAN_TILE);
   if (ws.sums.ensure((size_t)(ntscan > noscan ? ntscan : noscan) * 4)) return -3;
-  if (ws.order.ensure(nb * 4) || ws.ohist.ensure(nohist * 4) || ws.ooff.ensure((nohist + 1) * 4)) return -3;
-  if (ws.buckets.ensure(nb * Pt::BYTES)) return -3;
-  if (ws.pinned_cap < (size_t)W * Pt::BYTES + 64) {
-    if (ws.pinned) (void)hipHostFree(ws.pinned);
-    ws.pinned = nullptr;
-    ws.pinned_cap = 0;
-    ARK_HIP_TRY(hipHostMalloc(&ws.pinned, 2 * (size_t)W * Pt::BYTES + 64));
-    ws.pinned_cap = 2 * (size_t)W * Pt::BYTES;
-  }
-
-  hipEvent_t ev[6];
-  if (tm) {
-    for (auto& e : ev) ARK_HIP_TRY(hipEventCreate(&e));
-    ARK_HIP_TRY(hipEventRecord(ev[0], stream));
-  }
-
-  u32* keys = (u32*)ws.keys.p;
-  u32* sorted = (u32*)ws.sorted.p;
-  u32* offsets = (u32*)ws.offsets.p;
-  u32* thist = (u32*)ws.thist.p;
-  u32* toff = (u32*)ws.toff.p;
-  uint2* part = (uint2*)ws.part.p;
-  u32* order = (u32*)ws.order.p;
-  u32* sums = (u32*)ws.sums.p;
-
+  if (ws.order.ensure(nbk * 4) || ws.ohist.ensure(nohist * 4) || ws.ooff.ensure((nohist + 1) * 4)) return -3;
+  if (ws.buckets.ensure(nbk * Pt::BYTES)) return -3;
   if (ws.err.ensure(16)) return -3;
-  // heavy buckets: a lane walks its bucket serially (~28 us per entry with two or three waves per SIMD) and
-  // the heaviest buckets start first; a bucket is "heavy" when its walk would outlast the kernel's
-  // throughput-bound duration (entries / 5.5e9 per s).  At 2^24 x 13 windows that is ~1400 entries, so the
-  // sparse top window (1024 per bucket) still rides along; skewed scalar distributions do not.
-  const size_t total_entries = (size_t)n * W;
-  size_t mean_load = total_entries / nb;
-  u32 heavy_thresh = (u32)(total_entries / 154000);
-  if (heavy_thresh < 64) heavy_thresh = 64;
-  if (heavy_thresh < 4 * mean_load) heavy_thresh = (u32)(4 * mean_load);
-  if (const char* hv = getenv("ARK_HIP_MSM_HEAVY")) {
-    if (atoi(hv) >= 64) heavy_thresh = (u32)atoi(hv);
-  }
-  const size_t max_heavy = total_entries / heavy_thresh + 1;
-  const size_t max_items = total_entries / HEAVY_CHUNK + max_heavy + 1;
-  if (ws.hctr.ensure(16) || ws.hlist.ensure(max_heavy * sizeof(HeavyEntry)) || ws.hitems.ensure(max_items * 8) ||
-      ws.hpart.ensure(max_items * Pt::BYTES))
-    return -3;
-  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 8, stream));
-  ARK_HIP_TRY(hipMemsetAsync(ws.err.p, 0, 4, stream));
-  const u32 nblk = (u32)((n + 255) / 256);
-  hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
-                     (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.err.p);
-  if (tm) ARK_HIP_TRY(hipEventRecord(ev[1], stream));
-  // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
-  hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
-                     ntiles, thist);
-  hipLaunchKernelGGL(scan_block_sums, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums);
-  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, ntscan);
-  hipLaunchKernelGGL(scan_apply, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums, toff);
-  if (tm) ARK_HIP_TRY(hipEventRecord(ev[2], stream));
-  {
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per process)
-    const size_t lds_a = ((size_t)8 << HB) + (size_t)PART_TILE * 8;
-    const size_t lds_b = ((size_t)(1 << PART_LO_BITS) + 1024 + PART_STAGE) * 4;
-    if (!attr_set) {
-      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 4096 - 64));
-      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 64));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, W), dim3(1024), lds_a, stream, keys, (u32)n, HB, LB, ntiles,
-                       toff, part);
-    hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper), dim3(1024), lds_b, stream, part, toff, ntiles, LB, nsuper,
-                       offsets, sorted);
-  }
-  {
-    // processing order, heaviest load class first; class width 2^shift so that the mean falls around class 32..63
-    size_t mean = ((size_t)n * W) / nb;
-    int shift = 0;
-    while ((mean >> shift) >= 64) shift++;
-    u32* ohist = (u32*)ws.ohist.p;
-    u32* ooff = (u32*)ws.ooff.p;
-    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nb, shift, noblk, ohist);
-    hipLaunchKernelGGL(scan_block_sums, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums);
-    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, noscan);
-    hipLaunchKernelGGL(scan_apply, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums, ooff);
-    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nb, shift, noblk, ooff, order);
-  }
-  if (tm) ARK_HIP_TRY(hipEventRecord(ev[3], stream));
-  if constexpr (C::LAZY) {
-    typedef FpLazy<typename F::P> LZ;
-    if (ws.lbases.ensure(n * 2 * LZ::L * 4)) return -3;
-    hipLaunchKernelGGL((msm_bases_to_lazy_kernel<C>), dim3(nblk), dim3(256), 0, stream, (const char*)d_bases, (u32)n,
-                       (u32*)ws.lbases.p);
-    hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
-                       (const u32*)ws.lbases.p, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
-  } else {
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
-                       (const char*)d_bases, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
-  }
-  {
-    u32* hctr = (u32*)ws.hctr.p;
-    hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
-                       heavy_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
-    const u32 hthreads = Pt::BYTES > 192 ? 128 : 256;  // one 64-lane LDS tree per wave, 48 KiB per workgroup
-    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), hthreads * Pt::BYTES, stream,
-                       (const char*)d_bases, sorted, offsets, hctr, (const uint2*)ws.hitems.p, (char*)ws.hpart.p);
-    hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3((u32)max_heavy), dim3(64), 64 * Pt::BYTES, stream, hctr,
-                       (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, (char*)ws.buckets.p);
-  }
-  if (tm) ARK_HIP_TRY(hipEventRecord(ev[4], stream));
 
-  // bucket reduction: level 0 (chunked running sums over L0 buckets per lane), then the bit-sliced sums
+  // bucket reduction geometry: level 0 (chunked running sums over L0 buckets per lane), then the bit-sliced sums
   u32 L0 = 32;
   {
-    size_t want = (mwin * (size_t)W) >> 17;  // keep ~1e5 (S, A) pairs for the bit-sliced stage
+    size_t want = (mwin * (size_t)Wr) >> 17;  // keep ~1e5 (S, A) pairs for the bit-sliced stage
     u32 p2 = 1;
     while (p2 < want) p2 <<= 1;
     if (p2 < 8) p2 = 8;
@@ -831,46 +888,190 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
   u32 chunk = 4096;
   if (chunk > m) chunk = (u32)m;
   const u32 nchunks = (u32)((m + chunk - 1) / chunk);
-  const size_t npart = (size_t)W * Q * nchunks;
-  if (ws.lvlS[0].ensure(m * W * Pt::BYTES) || ws.lvlA[0].ensure(m * W * Pt::BYTES)) return -3;
+  const size_t npart = (size_t)Wr * Q * nchunks;
+  const size_t npairs = (size_t)Wr * Q;
+  if (ws.lvlS[0].ensure(m * Wr * Pt::BYTES) || ws.lvlA[0].ensure(m * Wr * Pt::BYTES)) return -3;
   if (ws.lvlS[1].ensure(npart * Pt::BYTES)) return -3;
-  if (ws.pinned_cap < npart * Pt::BYTES + 64) {
-    if (ws.pinned) (void)hipHostFree(ws.pinned);
-    ws.pinned = nullptr;
-    ws.pinned_cap = 0;
-    ARK_HIP_TRY(hipHostMalloc(&ws.pinned, npart * Pt::BYTES + 64));
-    ws.pinned_cap = npart * Pt::BYTES + 64;
+  if (nchunks > 1 && ws.lvlA[1].ensure(npairs * Pt::BYTES)) return -3;
+  {
+    int rc = msm_job_pinned(job, npairs * Pt::BYTES + 64);
+    if (rc) return rc;
   }
-  hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * W + 127) / 128)), dim3(128), 0, stream,
-                     (const char*)ws.buckets.p, (const char*)nullptr, L0, 0, (u32)(m * W), (char*)ws.lvlS[0].p,
+  if (!job.done) ARK_HIP_TRY(hipEventCreateWithFlags(&job.done, hipEventDisableTiming));
+  if (timing) {
+    for (auto& e : job.ev)
+      if (!e) ARK_HIP_TRY(hipEventCreate(&e));
+    ARK_HIP_TRY(hipEventRecord(job.ev[0], stream));
+  }
+
+  u32* keys = (u32*)ws.keys.p;
+  u32* sorted = (u32*)ws.sorted.p;
+  u32* offsets = (u32*)ws.offsets.p;
+  u32* thist = (u32*)ws.thist.p;
+  u32* toff = (u32*)ws.toff.p;
+  uint2* part = (uint2*)ws.part.p;
+  u32* order = (u32*)ws.order.p;
+  u32* sums = (u32*)ws.sums.p;
+
+  // heavy runs: a lane walks its bucket serially (~28 us per entry with two or three waves per SIMD) and
+  // the heaviest buckets start first; a run is "heavy" when its walk would outlast the kernel's
+  // throughput-bound duration (entries / 5.5e9 per s).  At 2^24 x 13 windows that is ~1400 entries, so the
+  // sparse top window (1024 per bucket) still rides along; skewed scalar distributions do not.
+  const size_t total_entries = (size_t)n * W;
+  size_t mean_load = total_entries / nbk;
+  u32 heavy_thresh = (u32)(total_entries / 154000);
+  if (heavy_thresh < 64) heavy_thresh = 64;
+  if (heavy_thresh < 4 * mean_load) heavy_thresh = (u32)(4 * mean_load);
+  if (const char* hv = getenv("ARK_HIP_MSM_HEAVY")) {
+    if (atoi(hv) >= 64) heavy_thresh = (u32)atoi(hv);
+  }
+  const size_t max_heavy = total_entries / heavy_thresh + 1;
+  const size_t max_items = total_entries / HEAVY_CHUNK + max_heavy + 1;
+  if (ws.hctr.ensure(16) || ws.hlist.ensure(max_heavy * sizeof(HeavyEntry)) || ws.hitems.ensure(max_items * 8) ||
+      ws.hpart.ensure(max_items * Pt::BYTES))
+    return -3;
+  if (pl.shared && ws.hfinal.ensure(max_heavy * Pt::BYTES)) return -3;
+  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 8, stream));
+  ARK_HIP_TRY(hipMemsetAsync(ws.err.p, 0, 4, stream));
+  const u32 nblk = (u32)((n + 255) / 256);
+  hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
+                     (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.err.p);
+  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[1], stream));
+  // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
+  hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
+                     ntiles, thist);
+  hipLaunchKernelGGL(scan_block_sums, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums);
+  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, ntscan);
+  hipLaunchKernelGGL(scan_apply, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums, toff);
+  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[2], stream));
+  {
+    // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device; the workspace is per device)
+    const size_t lds_a = ((size_t)8 << HB) + (size_t)PART_TILE * 8;
+    const size_t lds_b = ((size_t)(1 << PART_LO_BITS) + 1024 + PART_STAGE) * 4;
+    if (!ws.attr_set) {
+      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 4096 - 64));
+      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 64));
+      ws.attr_set = true;
+    }
+    hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, W), dim3(1024), lds_a, stream, keys, (u32)n, HB, LB, ntiles,
+                       toff, part);
+    hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper), dim3(1024), lds_b, stream, part, toff, ntiles, LB, nsuper,
+                       offsets, sorted);
+  }
+  {
+    // processing order, heaviest load class first; class width 2^shift so that the mean falls around class 32..63
+    int shift = 0;
+    while ((mean_load >> shift) >= 64) shift++;
+    u32* ohist = (u32*)ws.ohist.p;
+    u32* ooff = (u32*)ws.ooff.p;
+    const int wsum = pl.shared ? W : 1;
+    const size_t wstr = mwin;
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nbk, shift, noblk, wsum, wstr, ohist);
+    hipLaunchKernelGGL(scan_block_sums, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums);
+    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, noscan);
+    hipLaunchKernelGGL(scan_apply, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums, ooff);
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nbk, shift, noblk, wsum, wstr,
+                       ooff, order);
+  }
+  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[3], stream));
+  {
+    // runs too long for one lane: chunk partials by one wave each, combined per run (empty for uniform scalars)
+    u32* hctr = (u32*)ws.hctr.p;
+    hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
+                       heavy_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
+    const u32 hthreads = Pt::BYTES > 192 ? 128 : 256;  // one 64-lane LDS tree per wave, 48 KiB per workgroup
+    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), hthreads * Pt::BYTES, stream,
+                       (const char*)d_points, sorted, offsets, hctr, (const uint2*)ws.hitems.p, wstride, Bbits,
+                       (char*)ws.hpart.p);
+    if (pl.shared)
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3((u32)max_heavy), dim3(64), 64 * Pt::BYTES, stream, hctr,
+                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
+                         (char*)ws.hfinal.p);
+    else
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3((u32)max_heavy), dim3(64), 64 * Pt::BYTES, stream, hctr,
+                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
+                         (char*)ws.buckets.p);
+  }
+  if (pl.shared)
+  {
+    hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk + 255) / 256)), dim3(256), 0, stream,
+                       (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, heavy_thresh, HB, LB,
+                       (char*)ws.buckets.p);
+    hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3((u32)((max_heavy + 63) / 64)), dim3(64), 0, stream,
+                       (const u32*)ws.hctr.p, (const HeavyEntry*)ws.hlist.p, offsets, sorted, (const char*)ws.hfinal.p, W,
+                       Bbits, heavy_thresh, HB, LB, (char*)ws.buckets.p);
+  }
+  else
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
+                       (const char*)d_points, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
+  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
+
+  hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * Wr + 127) / 128)), dim3(128), 0, stream,
+                     (const char*)ws.buckets.p, (const char*)nullptr, L0, 0, (u32)(m * Wr), (char*)ws.lvlS[0].p,
                      (char*)ws.lvlA[0].p);
   {
     const u32 rthreads = Pt::BYTES > 192 ? 128 : 256;  // LDS tree within 48 KiB
-    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, W), dim3(rthreads), rthreads * Pt::BYTES, stream,
+    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, Wr), dim3(rthreads), rthreads * Pt::BYTES, stream,
                        (const char*)ws.lvlS[0].p, (const char*)ws.lvlA[0].p, (u32)m, nbits, chunk, (char*)ws.lvlS[1].p);
   }
-  const size_t npairs = (size_t)W * Q;
   const char* d_sums = (const char*)ws.lvlS[1].p;
   if (nchunks > 1) {
-    if (ws.lvlA[1].ensure(npairs * Pt::BYTES)) return -3;
     hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)((npairs + 63) / 64)), dim3(64), 0, stream,
                        (const char*)ws.lvlS[1].p, (u32)npairs, nchunks, (char*)ws.lvlA[1].p);
     d_sums = (const char*)ws.lvlA[1].p;
   }
-  ARK_HIP_TRY(hipMemcpyAsync(ws.pinned, d_sums, npairs * Pt::BYTES, hipMemcpyDeviceToHost, stream));
-  u32* h_err = (u32*)((char*)ws.pinned + npart * Pt::BYTES);
-  ARK_HIP_TRY(hipMemcpyAsync(h_err, ws.err.p, 4, hipMemcpyDeviceToHost, stream));
-  if (tm) ARK_HIP_TRY(hipEventRecord(ev[5], stream));
-  ARK_HIP_TRY(hipStreamSynchronize(stream));
   ARK_HIP_TRY(hipGetLastError());
-  if (*h_err) return -4;  // scalar out of range
+  ARK_HIP_TRY(hipMemcpyAsync(job.pinned, d_sums, npairs * Pt::BYTES, hipMemcpyDeviceToHost, stream));
+  ARK_HIP_TRY(hipMemcpyAsync((char*)job.pinned + npairs * Pt::BYTES, ws.err.p, 4, hipMemcpyDeviceToHost, stream));
+  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[5], stream));
+  ARK_HIP_TRY(hipEventRecord(job.done, stream));
+  job.pl = pl;
+  job.nbits = nbits;
+  job.log2L0 = log2L0;
+  job.Q = Q;
+  job.npairs = npairs;
+  job.timing = timing;
+  job.busy = true;
+  return slot;
+}
 
-  // host tail (serial chains, ~0.3 ms):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(width) T_w
-  // (window combine of mod.rs:489-502, high to low)
-  auto part_at = [&](int w, u32 q) { return Pt::load((const char*)ws.pinned + ((size_t)w * Q + q) * Pt::BYTES); };
+// Wait for job `slot` and finish it on the host: out_xyz = Jacobian x|y|z Montgomery limbs (group.rs:34-41);
+// identity = (R, R, 0) (group.rs:145-151).  Releases the slot.
+template <class C>
+int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  if (slot < 0 || slot >= MSM_JOBS) return -1;
+  MsmJob& job = ws.jobs[slot];
+  if (!job.busy) return -1;
+  struct Release {
+    MsmWorkspace& ws;
+    MsmJob& j;
+    ~Release() {
+      std::lock_guard<std::mutex> lock(ws.mu);
+      j.busy = false;
+    }
+  } release{ws, job};
+  if (job.empty) {
+    Jac<F>::zero().store(out_xyz);
+    return 0;
+  }
+  ARK_HIP_TRY(hipEventSynchronize(job.done));
+  const MsmPlan& pl = job.pl;
+  const int c = pl.c, W = pl.W, Wr = pl.red_windows(), nbits = job.nbits;
+  const u32 Q = job.Q;
+  const u32 h_err = *(const u32*)((const char*)job.pinned + job.npairs * Pt::BYTES);
+  if (h_err) return -4;  // scalar out of range
+
+  // host tail (serial chains):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(offset_w) T_w
+  // (window combine of mod.rs:489-502, high to low).  A prepared base set has a single T: no doublings between
+  // windows at all.
+  auto part_at = [&](int w, u32 q) { return Pt::load((const char*)job.pinned + ((size_t)w * Q + q) * Pt::BYTES); };
   Pt total = Pt::zero();
-  for (int w = W - 1; w >= 0; w--) {
-    if (w != W - 1) {
+  for (int w = Wr - 1; w >= 0; w--) {
+    if (w != Wr - 1) {
       const int cw = msm_window_width(w, c, W, pl.narrow);  // weight of window w+1 over window w
       for (int k = 0; k < cw; k++) total = xyzz_dbl<F>(total);
     }
@@ -880,22 +1081,40 @@ int msm_run_device(MsmWorkspace& ws, const void* d_bases, const void* d_scalars,
       Pt ub = part_at(w, (u32)b2);
       xyzz_add<F>(u, ub);
     }
-    for (int k = 0; k < log2L0; k++) u = xyzz_dbl<F>(u);
+    for (int k = 0; k < job.log2L0; k++) u = xyzz_dbl<F>(u);
     Pt asum = part_at(w, (u32)nbits);
     xyzz_add<F>(u, asum);
     xyzz_add<F>(total, u);
   }
   xyzz_to_jac<F>(total).store(out_xyz);
 
-  if (tm) {
-    (void)hipEventElapsedTime(&tm->digits, ev[0], ev[1]);
-    (void)hipEventElapsedTime(&tm->scan, ev[1], ev[2]);
-    (void)hipEventElapsedTime(&tm->scatter, ev[2], ev[3]);
-    (void)hipEventElapsedTime(&tm->accumulate, ev[3], ev[4]);
-    (void)hipEventElapsedTime(&tm->reduce, ev[4], ev[5]);
-    (void)hipEventElapsedTime(&tm->total, ev[0], ev[5]);
-    for (auto& e : ev) (void)hipEventDestroy(e);
+  if (tm && job.timing) {
+    (void)hipEventElapsedTime(&tm->digits, job.ev[0], job.ev[1]);
+    (void)hipEventElapsedTime(&tm->scan, job.ev[1], job.ev[2]);
+    (void)hipEventElapsedTime(&tm->scatter, job.ev[2], job.ev[3]);
+    (void)hipEventElapsedTime(&tm->accumulate, job.ev[3], job.ev[4]);
+    (void)hipEventElapsedTime(&tm->reduce, job.ev[4], job.ev[5]);
+    (void)hipEventElapsedTime(&tm->total, job.ev[0], job.ev[5]);
+    tm->c = c;
+    tm->W = W;
   }
+  return 0;
+}
+
+// Build the table of per-window multiples for a fixed base set: table[w][i] = 2^(offset_w) * bases[i], affine,
+// w < pl.W, row stride n.  `table` must hold pl.W * n affine points.  Asynchronous on `stream`.
+template <class C>
+int msm_prepare_table(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, hipStream_t stream) {
+  typedef typename C::F F;
+  const size_t row = n * Affine<F>::BYTES;
+  if (n == 0) return 0;
+  ARK_HIP_TRY(hipMemcpyAsync(d_table, d_bases, row, hipMemcpyDeviceToDevice, stream));
+  for (int w = 0; w + 1 < pl.W; w++) {
+    const int width = msm_window_width(w, pl.c, pl.W, pl.narrow);
+    hipLaunchKernelGGL((msm_table_step_kernel<C>), dim3((u32)((n + 127) / 128)), dim3(128), 0, stream,
+                       (const char*)d_table + (size_t)w * row, (char*)d_table + (size_t)(w + 1) * row, n, width);
+  }
+  ARK_HIP_TRY(hipGetLastError());
   return 0;
 }
 

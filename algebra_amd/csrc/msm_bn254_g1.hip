@@ -4,9 +4,15 @@
 #include "testops.cuh"
 #include "internal.hpp"
 namespace arkhip {
-int msm_run_BN254_G1(MsmWorkspace& ws, const void* d_bases, const void* d_scalars, size_t n, int mont, uint64_t* out_xyz,
-               hipStream_t stream, MsmTimings* tm) {
-  return msm_run_device<BN254_G1>(ws, d_bases, d_scalars, n, mont, out_xyz, stream, tm);
+int msm_enqueue_BN254_G1(MsmWorkspace& ws, const void* d_points, size_t wstride, const MsmPlan* prepared, const void* d_scalars,
+                   size_t n, int mont, hipStream_t stream, bool timing) {
+  return msm_enqueue<BN254_G1>(ws, d_points, wstride, prepared, d_scalars, n, mont, stream, timing);
+}
+int msm_finish_BN254_G1(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
+  return msm_finish<BN254_G1>(ws, slot, out_xyz, tm);
+}
+int msm_prepare_BN254_G1(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, hipStream_t stream) {
+  return msm_prepare_table<BN254_G1>(d_bases, n, pl, d_table, stream);
 }
 int test_basefield_op_BN254_G1(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<BN254_G1::F, false>(op, a, b, r, n, s);

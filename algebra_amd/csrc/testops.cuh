@@ -6,8 +6,7 @@
 namespace arkhip {
 
 template <class F, bool IS_PRIME>
-__global__ void __launch_bounds__(256) test_field_op_kernel(int op, const char* __restrict__ a, const char* __restrict__ b,
-                                                            char* __restrict__ r, size_t n) {
+__global__ void __launch_bounds__(256) test_field_op_kernel(int op, const char* a, const char* b, char* r, size_t n) {  // r may alias a or b
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   F x = F::load(a + i * F::BYTES);
@@ -76,8 +75,8 @@ __global__ void __launch_bounds__(128) test_point_op_kernel(int kind, const char
 // synthetic base sets on the device: P[i + m] = P[i] + (m*b)G continues P_i = (a + i*b)G
 // (SURVEY.md 8d synthetic inputs); also the device analogue of normalize_batch's output form.
 template <class C>
-__global__ void __launch_bounds__(128) sw_add_affine_kernel(const char* __restrict__ in, char* __restrict__ out,
-                                                            size_t n, const char* __restrict__ delta) {
+__global__ void __launch_bounds__(128) sw_add_affine_kernel(const char* in, char* out, size_t n,  // out may alias in
+                                                            const char* __restrict__ delta) {
   typedef typename C::F F;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -15,7 +15,7 @@
 // (x * 2^(28L) mod p, 28-bit limbs), buckets are converted back to the reference's canonical Montgomery
 // form (R = 2^(64 N)) when stored, so everything downstream -- and every result -- is bit-identical.
 #pragma once
-#include "ec.cuh"
+#include "../ec.cuh"
 
 namespace arkhip {
 

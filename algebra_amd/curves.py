@@ -16,6 +16,14 @@ CURVE_INFO = {
 }
 SCALAR_WORDS = 4  # BigInt<4> / Fr
 
+# scalar-field moduli (curves/bn254/src/fields/fr.rs:4-5, curves/bls12_381/src/fields/fr.rs:4-5,
+# curves/bls12_377/src/fields/fr.rs:24-25): used only for host-side bookkeeping (HashMapPippenger's Fr additions)
+SCALAR_MODULUS = {
+    "BN254_FR": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    "BLS12_381_FR": 52435875175126190479447740508185965837690552500527637822603658699938581184513,
+    "BLS12_377_FR": 8444461749428370424248824938781546531375899335154063827935233455917409239041,
+}
+
 
 def curve_id(curve):
     return curve if isinstance(curve, int) else CURVE_ID[curve]

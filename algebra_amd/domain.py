@@ -5,8 +5,8 @@ coset_offset_inv, coset_offset_pow_size, fft / fft_in_place / ifft / ifft_in_pla
 
 Coefficients are numpy uint64 arrays [len, 4] (host) or CUDA torch tensors (device) of Fr elements in
 Montgomery form.  As in the reference, inputs shorter than the domain are zero-extended
-(radix2/mod.rs:144,151); the reference's degree-aware path (fft.rs:29-71) is a CPU shortcut with the
-same mathematical output, so the device always runs the full-size transform.
+(radix2/mod.rs:144,151), and a forward transform of at most size/4 coefficients takes the degree-aware path
+(radix2/mod.rs:141, fft.rs:29-71): the device skips the butterfly stages that would only copy.
 """
 import ctypes as C
 
@@ -107,6 +107,9 @@ class Radix2EvaluationDomain:
 
     def _run(self, x, inverse, copy):
         L = lib()
+        rows = (x.numel() * x.element_size() // 32) if _is_torch(x) else (np.asarray(x).size // 4)
+        if not inverse and rows * 4 <= self.size() and rows > 0:
+            return self._run_degree_aware(x, rows)
         x = self._resize(x)
         if _is_torch(x):
             import torch
@@ -122,6 +125,28 @@ class Radix2EvaluationDomain:
         fn = L.ark_hip_ifft_in_place if inverse else L.ark_hip_fft_in_place
         check(fn(self.field, C.byref(self._s), x.ctypes.data_as(C.c_void_p)), "ark_hip_(i)fft_in_place")
         return x
+
+    def _run_degree_aware(self, x, rows):
+        """fft_in_place for coeffs.len() * 4 <= size (radix2/mod.rs:141): the buffer is grown to the domain size
+        without copying zeros over PCIe and the library skips the leading stages."""
+        L = lib()
+        n = self.size()
+        if _is_torch(x):
+            import torch
+            assert x.is_cuda and x.is_contiguous()
+            y = torch.empty((n, 4), dtype=torch.int64, device=x.device)
+            y.view(-1)[: rows * 4] = x.view(torch.int64).view(-1)
+            torch.cuda.current_stream().synchronize()
+            check(L.ark_hip_fft_in_place_degree_aware_device(self.field, C.byref(self._s), y.data_ptr(), rows),
+                  "ark_hip_fft_in_place_degree_aware_device")
+            check(L.ark_hip_synchronize(), "ark_hip_synchronize")
+            return y if x.dtype == torch.int64 else y.view(x.dtype)
+        a = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+        y = np.empty((n, 4), dtype=np.uint64)
+        y[:rows] = a
+        check(L.ark_hip_fft_in_place_degree_aware(self.field, C.byref(self._s), y.ctypes.data_as(C.c_void_p), rows),
+              "ark_hip_fft_in_place_degree_aware")
+        return y
 
     def fft(self, coeffs):
         """EvaluationDomain::fft (domain/mod.rs:92-96): evaluations over the (coset of the) subgroup."""

@@ -136,6 +136,186 @@ class ChunkedPippenger:
         return self._result
 
 
+class HashMapPippenger:
+    """Host mirror of ark_ec's HashMapPippenger (stream_pippenger.rs:68-128): scalars of equal bases are summed in
+    Fr (Montgomery residues add like integers mod r) before they reach the MSM; a flush runs one device MSM over the
+    distinct bases (the Fr -> BigInt conversion of the reference's flush happens on the device)."""
+
+    def __init__(self, curve, max_msm_buffer):
+        self.curve = cv.curve_id(curve)
+        self.buf_size = int(max_msm_buffer)
+        self._r = cv.SCALAR_MODULUS[cv.scalar_field(self.curve)]
+        self._map = {}
+        self._result = None
+
+    @staticmethod
+    def _int(limbs):
+        return sum(int(x) << (64 * i) for i, x in enumerate(limbs))
+
+    def add(self, base, scalar):
+        key = np.asarray(base, dtype=np.uint64).reshape(-1).tobytes()
+        s = self._int(np.asarray(scalar, dtype=np.uint64).reshape(-1))
+        self._map[key] = (self._map.get(key, 0) + s) % self._r
+        if len(self._map) == self.buf_size:
+            self._flush()
+
+    def _flush(self):
+        if not self._map:
+            return
+        bases = np.frombuffer(b"".join(self._map.keys()), dtype=np.uint64).reshape(len(self._map), -1)
+        scalars = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in self._map.values()],
+                           dtype=np.uint64)
+        part = msm_unchecked(self.curve, bases, scalars)
+        self._result = part if self._result is None else sum_projective(self.curve, np.stack([self._result, part]))
+        self._map = {}
+
+    def finalize(self):
+        self._flush()
+        if self._result is None:
+            return msm_bigint(self.curve, np.zeros((0, cv.affine_words(self.curve)), dtype=np.uint64),
+                              np.zeros((0, 4), dtype=np.uint64))
+        return self._result
+
+
+class MsmJob:
+    """An MSM in flight on the device (ark_hip_msm_job): wait() blocks, finishes it and returns the Projective."""
+
+    def __init__(self, curve, handle, keep):
+        self.curve = curve
+        self._h = handle
+        self._keep = keep  # inputs must outlive the job
+
+    def wait(self):
+        if self._h is None:
+            raise RuntimeError("job already waited for")
+        out = np.zeros(cv.projective_words(self.curve), dtype=np.uint64)
+        h, self._h = self._h, None
+        check(lib().ark_hip_msm_wait(h, out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_wait")
+        self._keep = None
+        return out
+
+
+def msm_bigint_async(curve, bases, bigints, montgomery=False):
+    """Enqueue msm_bigint on device-resident inputs (CUDA tensors) and return an MsmJob."""
+    cid = cv.curve_id(curve)
+    if not (_is_torch(bases) and _is_torch(bigints) and bases.is_cuda and bigints.is_cuda):
+        raise TypeError("msm_bigint_async takes CUDA tensors")
+    import torch
+    torch.cuda.current_stream().synchronize()
+    n = min(_rows(bases, cv.affine_words(cid)), _rows(bigints, cv.SCALAR_WORDS))
+    h = C.c_void_p()
+    check(lib().ark_hip_msm_sw_device_async(cid, bases.data_ptr(), bigints.data_ptr(), n, int(montgomery), C.byref(h)),
+          "ark_hip_msm_sw_device_async")
+    return MsmJob(cid, h, (bases, bigints))
+
+
+class PreparedBases:
+    """A fixed base set (an SRS) resident on the GPU together with its table of per-window multiples
+    (ark_hip_msm_bases): the `bases` argument of VariableBaseMSM::msm held across calls.  msm / msm_unchecked /
+    msm_bigint have the reference's meaning over the first len(scalars) bases."""
+
+    def __init__(self, curve, bases):
+        self.curve = cv.curve_id(curve)
+        self._h = C.c_void_p()
+        L = lib()
+        if _is_torch(bases):
+            import torch
+            assert bases.is_cuda and bases.is_contiguous()
+            torch.cuda.current_stream().synchronize()
+            self.n = _rows(bases, cv.affine_words(self.curve))
+            check(L.ark_hip_msm_bases_prepare_device(self.curve, bases.data_ptr(), self.n, C.byref(self._h)),
+                  "ark_hip_msm_bases_prepare_device")
+        else:
+            b, bp = _host(bases)
+            self.n = b.size // cv.affine_words(self.curve)
+            check(L.ark_hip_msm_bases_prepare(self.curve, bp, self.n, C.byref(self._h)), "ark_hip_msm_bases_prepare")
+
+    def info(self):
+        n, c, w, tb = C.c_size_t(), C.c_int(), C.c_int(), C.c_size_t()
+        check(lib().ark_hip_msm_bases_info(self._h, C.byref(n), C.byref(c), C.byref(w), C.byref(tb)), "bases_info")
+        return {"n": n.value, "window_bits": c.value, "windows": w.value, "table_bytes": tb.value}
+
+    def _run(self, scalars, n, montgomery):
+        out = np.zeros(cv.projective_words(self.curve), dtype=np.uint64)
+        L = lib()
+        if _is_torch(scalars):
+            import torch
+            assert scalars.is_cuda and scalars.is_contiguous()
+            torch.cuda.current_stream().synchronize()
+            check(L.ark_hip_msm_prepared_device(self._h, scalars.data_ptr(), n, int(montgomery),
+                                                out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_prepared_device")
+        else:
+            s, sp = _host(scalars)
+            check(L.ark_hip_msm_prepared(self._h, sp, n, int(montgomery), out.ctypes.data_as(C.c_void_p)),
+                  "ark_hip_msm_prepared")
+        return out
+
+    def msm_bigint(self, bigints):
+        return self._run(bigints, min(self.n, _rows(bigints, cv.SCALAR_WORDS)), False)
+
+    def msm_unchecked(self, scalars):
+        return self._run(scalars, min(self.n, _rows(scalars, cv.SCALAR_WORDS)), True)
+
+    def msm(self, scalars):
+        ns = _rows(scalars, cv.SCALAR_WORDS)
+        if ns != self.n:
+            raise MsmLengthMismatch(min(ns, self.n))
+        return self._run(scalars, ns, True)
+
+    def msm_bigint_async(self, bigints, montgomery=False):
+        """Enqueue and return an MsmJob.  Host scalars (numpy, ideally in pinned memory) upload on the copy stream
+        while the previous MSM computes; CUDA tensors are used in place."""
+        n = min(self.n, _rows(bigints, cv.SCALAR_WORDS))
+        h = C.c_void_p()
+        L = lib()
+        if _is_torch(bigints):
+            import torch
+            torch.cuda.current_stream().synchronize()
+            check(L.ark_hip_msm_prepared_device_async(self._h, bigints.data_ptr(), n, int(montgomery), C.byref(h)),
+                  "ark_hip_msm_prepared_device_async")
+            return MsmJob(self.curve, h, (self, bigints))
+        s, sp = _host(bigints)
+        check(L.ark_hip_msm_prepared_async(self._h, sp, n, int(montgomery), C.byref(h)), "ark_hip_msm_prepared_async")
+        return MsmJob(self.curve, h, (self, s))
+
+    def free(self):
+        if self._h is not None and self._h.value:
+            check(lib().ark_hip_msm_bases_free(self._h), "ark_hip_msm_bases_free")
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm_chunks(curve, bases, scalars, step=0):
+    """VariableBaseMSM::msm_chunks (variable_base/mod.rs:119-150) over host arrays: Fr (Montgomery) scalars, streams
+    aligned at their end, steps of `step` pairs (0 = the reference's 2^20); uploads overlap the previous step."""
+    cid = cv.curve_id(curve)
+    b, bp = _host(bases)
+    s, sp = _host(scalars)
+    nb, ns = b.size // cv.affine_words(cid), s.size // cv.SCALAR_WORDS
+    if ns > nb:
+        raise AssertionError("scalars_stream.len() <= bases_stream.len()")  # the reference's assert!
+    out = np.zeros(cv.projective_words(cid), dtype=np.uint64)
+    check(lib().ark_hip_msm_sw_chunks(cid, bp, nb, sp, ns, step, out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_sw_chunks")
+    return out
+
+
+def msm_bigint_multi(curve, n_gpus, bases, bigints, montgomery=False):
+    """One MSM over n_gpus GPUs from this process (ark_hip_msm_sw_multi): host arrays, even base-range split."""
+    cid = cv.curve_id(curve)
+    b, bp = _host(bases)
+    s, sp = _host(bigints)
+    n = min(b.size // cv.affine_words(cid), s.size // cv.SCALAR_WORDS)
+    out = np.zeros(cv.projective_words(cid), dtype=np.uint64)
+    check(lib().ark_hip_msm_sw_multi(cid, n_gpus, bp, sp, n, int(montgomery), out.ctypes.data_as(C.c_void_p)),
+          "ark_hip_msm_sw_multi")
+    return out
+
+
 def _small_to_bigint(values, signed_ok=False):
     v = np.asarray(values)
     if v.dtype == np.bool_:

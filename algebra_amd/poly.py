@@ -39,4 +39,8 @@ def poly_mul(field, a, b):
     check(L.ark_hip_fr_mul_device(fid, da.data_ptr(), db.data_ptr(), da.data_ptr(), n), "pointwise mul")
     check(L.ark_hip_ifft_in_place_device(fid, sref, da.data_ptr()), "ifft")
     check(L.ark_hip_synchronize(), "sync")
-    return da[:out_len].cpu().numpy().view(np.uint64)
+    out = da[:out_len].cpu().numpy().view(np.uint64)
+    # DensePolynomial::from_coefficients_vec truncates leading zero coefficients (dense.rs truncate_leading_zeros),
+    # which is how the reference's interpolate() result looks when a product vanishes at the top
+    nz = np.nonzero(out.any(axis=1))[0]
+    return out[: (nz[-1] + 1) if nz.size else 0]

@@ -4,20 +4,22 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): G1 scalar-muls/sec of a BLS12-381 G1 MSM at 2^24 points per GPU, inputs
-resident in HBM; the JSON line also carries the Fr radix-2 FFT rate at 2^22 (`fft`), the roofline
-figures of the dominant kernel measured with HIP events inside this run, and the CPU baseline
-(the oracle's restatement of ark-ec's msm_bigint_wnaf, timed on this box's host cores on a bounded
-sample).  One "step" = one complete MSM over the rank's 2^24 (base, scalar) pairs: digit recoding,
-bucket sort, bucket accumulation, bucket reduction, window combine, result on the host.
+Metric (BASELINE.json): G1 scalar-muls/sec of a BLS12-381 G1 MSM, inputs resident in HBM.
+  N = 1  the configuration the metric is quoted on: ONE 2^24-point MSM per step on one GPU.
+  N > 1  BASELINE config 4: ONE 2^26-point MSM per step, base-range shards of 2^26/N pairs per GPU (strong scaling);
+         rank r owns pairs [r*n, (r+1)*n), computes its partial on its GPU, the 144-byte partials are all-gathered
+         over RCCL and summed (elliptic-curve addition, so not an RCCL reduction op).  A weak-scaling measurement
+         (2^24 per GPU) rides along as an extra key.
+The base set is a fixed SRS: it is uploaded and PREPARED once before the timed region (ark_hip_msm_bases_prepare:
+per-window multiples, include/ark_hip.h) -- the timed step is everything that depends on the scalars: digit recoding,
+bucket sort, bucket accumulation, bucket reduction, combine, result on the host.  The same MSM through the plain entry
+(raw bases, nothing precomputed) is timed next to it (`plain`), as are the Fr radix-2 FFT at 2^22 (`fft`), the
+roofline figures of the dominant kernel measured with HIP events inside this run, and the CPU baseline (the oracle's
+restatement of ark-ec's msm_bigint_wnaf on this box's host cores).
 
-Multi-GPU: the MSM shards by base range -- rank r owns pairs [r*n, (r+1)*n) of a
-global N*n-point MSM (weak scaling), computes its partial on its GPU, the 144-byte partials are
-all-gathered over RCCL and summed (elliptic-curve addition, so not an RCCL reduction op).
-
-Synthetic inputs (SURVEY.md 8d): bases P_i = (a + i*b)*G grown on the GPU from the generator;
-uniform scalars in [0, r) by top-limb-masked rejection.  After timing, the result is checked
-bit-exactly against k*G with k = sum_i s_i (a + i b) mod r (exact big-integer identity).
+Synthetic inputs (tools/synth.py): bases P_i = (a + i*b)*G grown on the GPU from the generator; uniform
+scalars in [0, r).  After timing, the result is checked bit-exactly against k*G with k = sum_i s_i (a + i b) mod r
+(exact big-integer identity).
 """
 import argparse
 import ctypes as C
@@ -30,81 +32,43 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import synth as S  # noqa: E402
 
 CURVE = "BLS12_381_G1"
 FIELD = "BLS12_381_FR"
-R_MOD = 52435875175126190479447740508185965837690552500527637822603658699938581184513  # bls12_381 fr.rs:4-5
-A0 = 0xA11CE + (1 << 64) + (2 << 128)
-B0 = 0xB0B + (3 << 64)
+R_MOD = S.R[FIELD]  # bls12_381 fr.rs:4-5
+A0, B0 = S.A0, S.B0
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-FP384_MUL_PEAK = 59.9e9  # measured ceiling of the Montgomery product sequence (ubench/mulbench.hip), products/s
-
-
-def pmc_traffic(kernel, log_n):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json,
-    produced by tools/pmc_traffic.py; FETCH_SIZE / WRITE_SIZE collected in separate passes, corrected as
-    MI355X_MICROARCH.md prescribes).  None when no matching measurement is committed."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            d = json.load(f)
-        e = d.get(kernel)
-        if e and e.get("log_n") == log_n:
-            return e.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
-    return None
-
-
-def limbs4(v):
-    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+# hardware-anchored multiply bound: v_mad_u64_u32 issues at 27.73e12 lane-ops/s on this chip
+# (profiles/r1_ubench_instruction_rates.txt, line 1); a Montgomery Fp384 product needs 2 * 12^2 = 288 of them
+MAD_U64_U32_PER_S = 27.73e12
+MADS_PER_MIXED_ADD = 8 * 288 + 432  # 8 products + one sum of two products under a single reduction (ec.cuh)
+limbs4 = S.limbs4
 
 
 def gen_scalars(n, seed):
-    """uniform in [0, r): 255-bit draws, rejection (ff/src/fields/models/fp/mod.rs:525-547 style)."""
-    rng = np.random.default_rng(seed)
-    out = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    out[:, 3] &= np.uint64((1 << 63) - 1)
-    rl = [int(x) for x in limbs4(R_MOD)]
-
-    def ge_r(a):
-        ge = np.ones(a.shape[0], dtype=bool)   # equal so far -> counts as >=
-        decided = np.zeros(a.shape[0], dtype=bool)
-        for k in (3, 2, 1, 0):
-            gt = a[:, k] > np.uint64(rl[k])
-            lt = a[:, k] < np.uint64(rl[k])
-            ge = np.where(~decided & lt, False, ge)
-            decided |= gt | lt
-        return ge
-
-    bad = np.nonzero(ge_r(out))[0]
-    while bad.size:
-        new = rng.integers(0, 1 << 64, size=(bad.size, 4), dtype=np.uint64)
-        new[:, 3] &= np.uint64((1 << 63) - 1)
-        out[bad] = new
-        bad = bad[ge_r(new)]
-    return out
-
-
-def _exact_sum(x):
-    """exact integer sum of a uint64 array whose entries are < 2^58 (chunks of 32 stay < 2^63)."""
-    pad = (-x.size) % 32
-    if pad:
-        x = np.concatenate([x, np.zeros(pad, dtype=np.uint64)])
-    return int(x.reshape(-1, 32).sum(axis=1, dtype=np.uint64).astype(object).sum())
+    return S.gen_scalars(n, seed, R_MOD)
 
 
 def dlog_of_msm(scalars, a, b):
-    """k = sum_i s_i (a + i b) mod r, exact: the discrete log of the MSM of P_i = (a + i b)G."""
-    n = scalars.shape[0]
-    idx = np.arange(n, dtype=np.uint64)  # n <= 2^26
-    s_sum = 0
-    is_sum = 0
-    for k in range(4):
-        for half, sh in ((scalars[:, k] & np.uint64(0xFFFFFFFF), 0), (scalars[:, k] >> np.uint64(32), 32)):
-            w = 1 << (64 * k + sh)
-            s_sum += w * _exact_sum(half)
-            is_sum += w * _exact_sum(half * idx)
-    return (s_sum * a + is_sum * b) % R_MOD
+    return S.dlog_of_msm(scalars, a, b, R_MOD)
+
+
+def pmc_traffic(kernel, log_n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json,
+    produced by tools/pmc_traffic.py on this same command; FETCH_SIZE / WRITE_SIZE collected in separate passes,
+    corrected as MI355X_MICROARCH.md prescribes).  None when no matching measurement is committed."""
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            e = d.get(kernel)
+            if e and e.get("log_n") == log_n:
+                return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "source": "profiles/" + name}
+        except Exception:
+            pass
+    return None
 
 
 def main():
@@ -112,17 +76,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log-n", type=int, default=24, help="log2 of (base, scalar) pairs per GPU")
+    ap.add_argument("--log-n", type=int, default=None,
+                    help="log2 of the TOTAL number of (base, scalar) pairs of one MSM (default: 24 on one GPU, "
+                         "26 on several -- BASELINE configs 2 and 4)")
+    ap.add_argument("--no-prepare", action="store_true", help="headline through the plain entry (raw bases)")
     ap.add_argument("--fft-log-n", type=int, default=22)
     ap.add_argument("--fft-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=24)
+    ap.add_argument("--no-extras", action="store_true", help="skip the plain / weak-scaling / 2^26 side measurements")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import algebra_amd as A
     from algebra_amd import curves as cv
+    from algebra_amd import dist as D
     from algebra_amd._lib import check, lib
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,42 +113,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        # bring the communicator up outside the timed region (RCCL initialises lazily on the first collective)
+        D.combine_partials(cv.curve_id(CURVE), np.zeros(cv.projective_words(cv.curve_id(CURVE)), dtype=np.uint64))
 
     cid = cv.curve_id(CURVE)
-    n = 1 << args.log_n
+    log_total = args.log_n if args.log_n is not None else (24 if world == 1 else 26)
+    n_total = 1 << log_total
+    if n_total % world:
+        raise SystemExit("world size must divide 2^%d" % log_total)
     ab = cv.affine_bytes(cid)
-
-    # ---- synthetic inputs, generated on the device ------------------------------------------------
-    gen = np.zeros(cv.affine_words(cid), dtype=np.uint64)
-    check(L.ark_hip_curve_generator(cid, gen.ctypes.data_as(C.c_void_p)), "generator")
-
-    def mul_gen(k):  # k*G as affine limbs, via a 1-point MSM on the GPU
-        return A.into_affine(cid, A.msm_bigint(cid, gen.reshape(1, -1), limbs4(k % R_MOD).reshape(1, 4)))
-
-    a_r = (A0 + rank * n * B0) % R_MOD  # this rank's shard starts at global index rank*n
-    bases = torch.zeros(n * ab, dtype=torch.uint8, device="cuda")
-    p0 = mul_gen(a_r)
-    bases[:ab] = torch.from_numpy(p0.view(np.uint8)).cuda()
-    torch.cuda.synchronize()
-    m = 1
-    while m < n:
-        cnt = min(m, n - m)
-        d = np.ascontiguousarray(mul_gen(m * B0))
-        check(L.ark_hip_sw_add_affine_device(cid, bases.data_ptr(), bases.data_ptr() + m * ab, cnt,
-                                             d.ctypes.data_as(C.c_void_p)), "sw_add_affine_device")
-        m += cnt
-    scalars_h = gen_scalars(n, 0xA11CE + rank)
-    scalars = torch.from_numpy(scalars_h.view(np.int64)).cuda()
-    torch.cuda.synchronize()
-
-    from algebra_amd import dist as D
-    if world > 1:
-        # bring the communicator up outside the timed region (RCCL initialises lazily on the first collective)
-        D.combine_partials(cid, np.zeros(cv.projective_words(cid), dtype=np.uint64))
-
-    def step():
-        # local MSM on this rank's base range, then (N > 1) RCCL all-gather of the 144-byte partials + EC sum
-        return D.msm_bigint_sharded(cid, bases, scalars)
 
     def barrier():
         if world > 1:
@@ -187,40 +129,126 @@ def main():
         torch.cuda.synchronize()
         check(L.ark_hip_synchronize(), "sync")
 
-    for _ in range(args.warmup):
-        result = step()
-    # ---- timed region: exactly K steps -------------------------------------------------------------
-    check(L.ark_hip_msm_set_timing(1), "set_timing")
-    acc_ms = []
-    phases = np.zeros(8)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
-        tm = (C.c_double * 8)()
-        L.ark_hip_msm_last_timing(tm)
-        acc_ms.append(tm[3])
-        phases += np.array(list(tm))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    check(L.ark_hip_msm_set_timing(0), "set_timing")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    def all_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    phases /= max(args.steps, 1)
+        return float(t.item())
 
-    # ---- exactness of the timed result: MSM == k*G, k = sum s_i (a + i b) ---------------------------
-    k_r = dlog_of_msm(scalars_h, a_r, B0)
-    if world > 1:
-        ks = [None] * world
-        dist.all_gather_object(ks, k_r)
-        k_tot = sum(ks) % R_MOD
+    def make_inputs(n_local, first, seed):
+        """this rank's shard [first, first + n_local) of the global arithmetic progression of bases + its scalars"""
+        bases = S.grow_bases(cid, n_local, (A0 + first * B0) % R_MOD, B0, R_MOD)
+        sc_h = gen_scalars(n_local, seed)
+        sc = torch.from_numpy(sc_h.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        return bases, sc_h, sc
+
+    def expected_affine(sc_h, first):
+        """k*G for the whole job: every rank contributes its share of k"""
+        k = S.dlog_of_msm(sc_h, A0, B0, R_MOD, first_index=first)
+        if world > 1:
+            ks = [None] * world
+            dist.all_gather_object(ks, k)
+            k = sum(ks) % R_MOD
+        return S.mul_gen(cid, k, R_MOD) if rank == 0 else None
+
+    def run_timed(local_msm, sc, warmup, steps):
+        """K steps of: local MSM on this rank's shard, then (N > 1) all-gather of the partials + EC sum"""
+        def step():
+            return D.combine_partials(cid, local_msm(sc))
+        for _ in range(warmup):
+            res = step()
+        check(L.ark_hip_msm_set_timing(1), "set_timing")
+        phases = np.zeros(8)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+            tm = (C.c_double * 8)()
+            L.ark_hip_msm_last_timing(tm)
+            phases += np.array(list(tm))
+        barrier()
+        elapsed = all_max(time.perf_counter() - t0)
+        check(L.ark_hip_msm_set_timing(0), "set_timing")
+        return res, elapsed, phases / max(steps, 1)
+
+    # ---- the headline job: ONE MSM of n_total pairs, base-range shards --------------------------------------
+    n = n_total // world
+    first = rank * n
+    bases, scalars_h, scalars = make_inputs(n, first, 0xA11CE + rank)
+    prep_s = None
+    pb = None
+    if not args.no_prepare:
+        t0 = time.perf_counter()
+        pb = A.PreparedBases(cid, bases)
+        prep_s = time.perf_counter() - t0
+        headline_msm = pb.msm_bigint
     else:
-        k_tot = k_r
-    exact = None
-    if rank == 0:
-        exact = bool(np.array_equal(A.into_affine(cid, result), mul_gen(k_tot)))
+        headline_msm = lambda sc: A.msm_bigint(cid, bases, sc)  # noqa: E731
+    result, elapsed, phases = run_timed(headline_msm, scalars, args.warmup, args.steps)
+    want = expected_affine(scalars_h, first)
+    exact = bool(np.array_equal(A.into_affine(cid, result), want)) if rank == 0 else None
+
+    # ---- the same MSM through the plain entry (raw bases, nothing precomputed) ------------------------------
+    plain = None
+    if not args.no_extras and not args.no_prepare:
+        r2, e2, ph2 = run_timed(lambda sc: A.msm_bigint(cid, bases, sc), scalars, 1, min(args.steps, 5))
+        if rank == 0:
+            st = min(args.steps, 5)
+            plain = {"what": "same job through ark_hip_msm_sw_device (raw bases, no table)", "value": n_total * st / e2,
+                     "ms_per_step": e2 * 1e3 / st, "window_bits": int(ph2[6]), "windows": int(ph2[7]),
+                     "accumulate_ms": ph2[3], "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, r2), want))}
+
+    # ---- N > 1: weak scaling on the side (2^24 pairs per GPU) ----------------------------------------------
+    weak = None
+    if world > 1 and not args.no_extras and n != (1 << 24):
+        if pb is not None:
+            pb.free()
+            pb = None
+        del bases, scalars
+        torch.cuda.empty_cache()
+        nw = 1 << 24
+        wb, wsh, ws_ = make_inputs(nw, rank * nw, 0xBEEF + rank)
+        wpb = A.PreparedBases(cid, wb)
+        rw, ew, _ = run_timed(wpb.msm_bigint, ws_, 1, min(args.steps, 5))
+        wwant = expected_affine(wsh, rank * nw)
+        if rank == 0:
+            st = min(args.steps, 5)
+            weak = {"what": "2^24 pairs per GPU (one 2^%d MSM)" % (24 + int(np.log2(world))), "value": nw * world * st / ew,
+                    "ms_per_step": ew * 1e3 / st, "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, rw), wwant))}
+        wpb.free()
+        del wb, ws_
+        torch.cuda.empty_cache()
+        bases = scalars = None
+
+    # ---- N = 1: the 2^26 job on ONE GPU, so that the N > 1 lines have their strong-scaling reference ---------
+    big = None
+    if world == 1 and not args.no_extras and log_total == 24:
+        if pb is not None:
+            pb.free()
+            pb = None
+        torch.cuda.empty_cache()
+        nb_ = 1 << 26
+        bb, bsh, bs = make_inputs(nb_, 0, 0xB16)
+        res_b, el_b, ph_b = run_timed(lambda sc: A.msm_bigint(cid, bb, sc), bs, 1, 2)
+        kb = S.mul_gen(cid, S.dlog_of_msm(bsh, A0, B0, R_MOD), R_MOD)
+        big = {"what": "one 2^26 MSM on one GPU, plain entry", "value": nb_ * 2 / el_b, "ms_per_step": el_b * 1e3 / 2,
+               "window_bits": int(ph_b[6]), "windows": int(ph_b[7]),
+               "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_b), kb))}
+        try:
+            t0 = time.perf_counter()
+            bpb = A.PreparedBases(cid, bb)
+            bprep = time.perf_counter() - t0
+            res_p, el_p, ph_p = run_timed(bpb.msm_bigint, bs, 1, 2)
+            big["prepared"] = {"value": nb_ * 2 / el_p, "ms_per_step": el_p * 1e3 / 2, "window_bits": int(ph_p[6]),
+                               "windows": int(ph_p[7]), "table_gib": bpb.info()["table_bytes"] / 2**30, "prepare_s": bprep,
+                               "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_p), kb))}
+            bpb.free()
+        except Exception as e:  # noqa: BLE001 -- the side measurement must never cost the headline line
+            big["prepared"] = {"error": repr(e)[:200]}
+        del bb, bs
+        torch.cuda.empty_cache()
 
     # ---- FFT leg (rank 0's GPU; the FFT config is single-GPU) ---------------------------------------
     fft = None
@@ -239,12 +267,11 @@ def main():
             check(inv(dom.field, sref, y.data_ptr()), "ifft")
         check(L.ark_hip_synchronize(), "sync")
         roundtrip_ok = bool(torch.equal(x, y))
-        e0, e1 = time.perf_counter(), None
+        e0 = time.perf_counter()
         for _ in range(args.fft_steps):
             check(fwd(dom.field, sref, y.data_ptr()), "fft")
         check(L.ark_hip_synchronize(), "sync")
-        e1 = time.perf_counter()
-        fft_ms = (e1 - e0) * 1e3 / args.fft_steps
+        fft_ms = (time.perf_counter() - e0) * 1e3 / args.fft_steps
         # per-pass device times of one transform (HIP events on the library stream)
         check(L.ark_hip_fft_set_timing(1), "fft timing")
         check(fwd(dom.field, sref, y.data_ptr()), "fft")
@@ -265,7 +292,7 @@ def main():
 
     # ---- sharded FFT leg (N > 1): 2^fft_log_n coefficients per GPU, all-to-all exchanges over RCCL ----------
     fft_sharded = None
-    if world > 1 and args.fft_steps > 0:
+    if world > 1 and args.fft_steps > 0 and not args.no_extras:
         try:
             nloc = 1 << args.fft_log_n
             ntot = nloc * world
@@ -291,10 +318,12 @@ def main():
 
     # ---- CPU baseline: the oracle's msm_bigint_wnaf restatement on the host cores, bounded sample ---
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O  # test infrastructure: used here only as the timed CPU baseline
-        ns = 1 << min(args.cpu_sample_log_n, args.log_n)
+        ns = 1 << min(args.cpu_sample_log_n, int(np.log2(n)))
+        if bases is None or bases.numel() < ns * ab:
+            bases, scalars_h, scalars = make_inputs(ns, 0, 0xA11CE)
         hb = bases[: ns * ab].cpu().numpy().view(np.uint64).reshape(ns, -1)
         cores = os.cpu_count() or 1
         t1 = time.perf_counter()
@@ -308,38 +337,55 @@ def main():
                          % ("all" if ns == n else "first", int(np.log2(ns)), cpu_s, same)}
 
     if rank == 0:
-        total_pairs = n * world * args.steps
-        acc_avg_ms = float(np.mean(acc_ms))
-        achieved = 128.0 * n / (acc_avg_ms * 1e-3) / 1e9  # algorithmic bytes: 96 B base + 32 B scalar per pair
+        acc_ms = float(phases[3])
+        W = int(phases[7])
+        cbits = int(phases[6])
+        achieved = 128.0 * n / (acc_ms * 1e-3) / 1e9  # algorithmic bytes: 96 B base + 32 B scalar per pair
+        # mixed additions actually executed by the accumulate kernel: one per (scalar, window) with a non-zero digit,
+        # minus the first point of every non-empty bucket (a copy, not an addition)
+        entries = n * W * (1.0 - 2.0 ** -cbits)
+        nbuckets = (1 << (cbits - 1)) if not args.no_prepare else W * (1 << (cbits - 1))
+        madds = entries - nbuckets * (1.0 - np.exp(-entries / nbuckets))
+        mads_per_s = madds * MADS_PER_MIXED_ADD / (acc_ms * 1e-3)
         out = {
-            "metric": "G1 scalar-muls/sec (MSM, 2^%d per GPU)" % args.log_n,
-            "value": total_pairs / elapsed,
+            "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (log_total, "" if world == 1 else " over %d GPUs" % world),
+            "value": n_total * args.steps / elapsed,
             "unit": "scalar-muls/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "BLS12-381 G1 MSM, 2^%d random bases/scalars per GPU, device resident" % args.log_n,
+            "config": {"workload": "BLS12-381 G1 MSM, one job of 2^%d random bases/scalars, device resident, %s"
+                                   % (log_total, "raw bases" if args.no_prepare else
+                                      "base set prepared once (fixed SRS: per-window multiples in HBM)"),
                        "arithmetic": "Montgomery Fp384 on 32-bit limbs (v_mad_u64_u32), exact integers",
-                       "curve": CURVE, "window_bits": int(phases[6]), "windows": int(phases[7]),
-                       "sharding": "base-range, %d rank(s)" % world},
+                       "curve": CURVE, "window_bits": cbits, "windows": W,
+                       "pairs_per_gpu": n, "sharding": "base-range, %d rank(s)" % world,
+                       "prepare_s": prep_s},
             "bit_exact_vs_kG": exact,
             "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
                           "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_%skernel" % ("" if args.no_prepare else "shared_"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic("msm_accumulate_kernel", args.log_n),
-                         "alu": {"what": "Fp384 products/s in the accumulate kernel (10 per mixed addition) vs the "
-                                         "measured ceiling of the multiply sequence",
-                                 "achieved": 10.0 * n * phases[7] / (acc_avg_ms * 1e-3), "peak": FP384_MUL_PEAK,
-                                 "frac": 10.0 * n * phases[7] / (acc_avg_ms * 1e-3) / FP384_MUL_PEAK},
+                         "traffic": pmc_traffic("msm_accumulate_%skernel" % ("" if args.no_prepare else "shared_"),
+                                                int(np.log2(n))),
+                         "alu": {"what": "v_mad_u64_u32 lane-ops/s issued by the mixed additions the accumulate kernel "
+                                         "executes (%d per addition: 8 Montgomery products + one two-product sum) vs the "
+                                         "instruction's measured issue rate on this chip" % MADS_PER_MIXED_ADD,
+                                 "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
+                                 "frac": mads_per_s / MAD_U64_U32_PER_S,
+                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32)"},
                          "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
             "cpu_baseline": cpu,
+            "plain": plain,
+            "weak_scaling": weak,
+            "msm_2_26_one_gpu": big,
             "fft": fft,
             "fft_sharded": fft_sharded,
         }

@@ -15,8 +15,12 @@
  *   Projective   x | y | z Jacobian, identity = (R, R, 0)                 (short_weierstrass/group.rs:34-41,145-151)
  *   scalar       4 u64 limbs: BigInt<4> canonical, or Fr Montgomery
  * All functions return 0 on success and a negative code on error; none throws or aborts.
- * Thread safety: calls are serialised per process on an internal context (one GPU per process,
- * the torch.distributed / RCCL model).
+ * Devices and threads: the library keeps one context (streams, workspaces) per GPU.  A call runs on the
+ * calling thread's current device (ark_hip_set_device; default: the first device initialised in the process)
+ * and holds that context's lock for its whole body, so any number of host threads (rayon workers) may call
+ * concurrently: calls on one GPU serialise, calls on different GPUs overlap.  One process per GPU
+ * (torch.distributed / RCCL) and one process driving all GPUs (ark_hip_msm_sw_multi) are both supported.
+ * Limits: MSM n < 2^31 and n * windows < 2^32 (n <= 2^27 for 255-bit scalars); FFT log2(size) <= 30.
  */
 #ifndef ARK_HIP_H
 #define ARK_HIP_H
@@ -34,13 +38,20 @@ enum { ARK_HIP_BN254_G1 = 0, ARK_HIP_BLS12_381_G1 = 1, ARK_HIP_BLS12_377_G1 = 2,
        ARK_HIP_BLS12_381_G2 = 4 };
 /* error codes */
 enum { ARK_HIP_OK = 0, ARK_HIP_ERR_ARG = -1, ARK_HIP_ERR_SIZE = -2, ARK_HIP_ERR_NOMEM = -3,
-       ARK_HIP_ERR_SCALAR_RANGE = -4, ARK_HIP_ERR_NO_DEVICE = -5 /* HIP runtime errors: <= -1000 */ };
+       ARK_HIP_ERR_SCALAR_RANGE = -4, ARK_HIP_ERR_NO_DEVICE = -5, ARK_HIP_ERR_BUSY = -6 /* HIP runtime errors: <= -1000 */ };
 
 /* ---- runtime ---- */
 int ark_hip_device_count(void);
-/* Bind this process to GPU `device` and create the context (streams, workspaces).  Idempotent. */
+/* Make GPU `device` the calling thread's current device and create its context (streams, workspaces) if needed.
+ * The first device initialised becomes the default of threads that never choose one.  Idempotent.
+ * (ARK_HIP_OVERSUBSCRIBE=1 in the environment lets ids beyond the physical count wrap around -- separate contexts
+ * on a shared GPU -- so that multi-device code can be exercised on a one-GPU box.) */
 int ark_hip_init(int device);
+int ark_hip_set_device(int device);   /* same as ark_hip_init */
+int ark_hip_get_device(void);
+/* Destroys every context (waits for calls in flight). */
 void ark_hip_shutdown(void);
+/* Waits for everything enqueued on the current device's streams. */
 int ark_hip_synchronize(void);
 const char* ark_hip_version(void);
 /* u64 words per base-field element (4, 6 or 12), scalar field id, base field id, extension degree */
@@ -52,6 +63,10 @@ int ark_hip_malloc(size_t bytes, void** out_dptr);
 int ark_hip_free(void* dptr);
 int ark_hip_memcpy_h2d(void* dst_dptr, const void* src_host, size_t bytes);
 int ark_hip_memcpy_d2h(void* dst_host, const void* src_dptr, size_t bytes);
+/* Page-locked host memory: scalar vectors produced into it upload at full PCIe rate and truly asynchronously
+ * (ark_hip_msm_prepared_async). */
+int ark_hip_host_alloc(size_t bytes, void** out_ptr);
+int ark_hip_host_free(void* ptr);
 
 /* SWCurveConfig::GENERATOR (e.g. curves/bls12_381/src/curves/g1.rs:199-205) as Affine limbs */
 int ark_hip_curve_generator(int curve, uint64_t* out_xy);
@@ -62,14 +77,63 @@ int ark_hip_curve_generator(int curve, uint64_t* out_xy);
  * bases: n Affine points; scalars: n x 4 limbs; scalars_are_montgomery != 0 for the `msm(&[Fr])`
  * entry (the into_bigint pass of mod.rs:60-62 then runs on the device), 0 for `msm_bigint`.
  * The length check (Err(min_len), mod.rs:73-77) stays on the caller's side: one n here.
- * out_xyz: Projective.  Scalars must be < r (as into_bigint() guarantees), bases in the
- * prime-order subgroup (as Affine deserialisation guarantees). */
+ * out_xyz: Projective.  Bases must lie in the prime-order subgroup (as Affine deserialisation guarantees; the
+ * reference's own msm_signed relies on r*P = O as well, mod.rs:251-285).  Scalars: any BigInt<4> below
+ * 2^MODULUS_BIT_SIZE is accepted and gives the reference's result (values in [r, 2^bits) are reduced once);
+ * a scalar with higher bits set returns ARK_HIP_ERR_SCALAR_RANGE -- the reference's make_digits (mod.rs:754-794)
+ * silently drops bits above ceil(bits/c)*c there, i.e. its result depends on the window size it happened to pick. */
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int scalars_are_montgomery,
                    uint64_t* out_xyz);
 /* Same with bases/scalars already in this GPU's memory (device pointers); out_xyz is a host pointer. */
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalars_are_montgomery,
                           uint64_t* out_xyz);
-/* Per-phase device times of the last ark_hip_msm_sw_device call made with timing enabled (ms):
+/* Asynchronous form: the device work is enqueued and the call returns; ark_hip_msm_wait blocks until the result is
+ * there, finishes it (window combine, a few hundred point operations on the host) and frees the job.  Up to 4 jobs
+ * may be in flight per device (ARK_HIP_ERR_BUSY beyond).  Inputs must stay valid until the wait returns. */
+typedef struct ark_hip_msm_job ark_hip_msm_job;
+int ark_hip_msm_sw_device_async(int curve, const void* d_bases, const void* d_scalars, size_t n,
+                                int scalars_are_montgomery, ark_hip_msm_job** out_job);
+int ark_hip_msm_wait(ark_hip_msm_job* job, uint64_t* out_xyz);
+
+/* ---- prepared base sets ----
+ * Provers run many MSMs against ONE fixed base set (an SRS).  ark_hip_msm_bases_prepare uploads it once and
+ * precomputes, for every window w of the digit decomposition, the multiples 2^(offset_w) * P_i (288 GB of HBM pay for
+ * the W-fold table: 18 GiB for 2^24 BLS12-381 G1 points).  All windows then share one bucket set, which allows wider
+ * windows -- fewer mixed additions per scalar -- and shrinks the bucket reduction W-fold.  Role in the reference: the
+ * `bases: &[Affine]` argument of VariableBaseMSM::msm (variable_base/mod.rs:59-85) held by the caller across calls;
+ * the precomputation itself is the fixed-base idea of BatchMulPreprocessing (scalar_mul/mod.rs:156-245) applied per base.
+ * ark_hip_msm_prepared* compute sum_i s_i * P_i over the first n <= n_bases pairs (msm_unchecked's truncation). */
+typedef struct ark_hip_msm_bases ark_hip_msm_bases;
+int ark_hip_msm_bases_prepare(int curve, const uint64_t* bases, size_t n, ark_hip_msm_bases** out);
+int ark_hip_msm_bases_prepare_device(int curve, const void* d_bases, size_t n, ark_hip_msm_bases** out);
+int ark_hip_msm_bases_free(ark_hip_msm_bases* bases);
+int ark_hip_msm_bases_info(const ark_hip_msm_bases* bases, size_t* n, int* window_bits, int* windows, size_t* table_bytes);
+int ark_hip_msm_prepared(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n, int scalars_are_montgomery,
+                         uint64_t* out_xyz);
+int ark_hip_msm_prepared_device(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n,
+                                int scalars_are_montgomery, uint64_t* out_xyz);
+/* Asynchronous forms.  The host-scalar one uploads through a two-slot ring on a copy stream: the upload of MSM k+1's
+ * scalars overlaps MSM k's kernels. */
+int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n,
+                               int scalars_are_montgomery, ark_hip_msm_job** out_job);
+int ark_hip_msm_prepared_device_async(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n,
+                                      int scalars_are_montgomery, ark_hip_msm_job** out_job);
+
+/* VariableBaseMSM::msm_chunks (variable_base/mod.rs:119-150): Fr (Montgomery) scalars; the streams are aligned at
+ * their end (the first n_bases - n_scalars bases are skipped); steps of `step` pairs (0 = the reference's 2^20), each
+ * one msm_bigint, results added.  Step k+1 uploads while step k computes. */
+int ark_hip_msm_sw_chunks(int curve, const uint64_t* bases, size_t n_bases, const uint64_t* scalars, size_t n_scalars,
+                          size_t step, uint64_t* out_xyz);
+
+/* One MSM across n_gpus GPUs driven from this process: base-range shards (the reference's own split,
+ * variable_base/mod.rs:521-557), one host thread + context per device, partial results summed on the host.
+ * _multi: host inputs, split evenly; _multi_device: shard g already resident on GPU g (n_per_gpu[g] pairs). */
+int ark_hip_msm_sw_multi(int curve, int n_gpus, const uint64_t* bases, const uint64_t* scalars, size_t n,
+                         int scalars_are_montgomery, uint64_t* out_xyz);
+int ark_hip_msm_sw_multi_device(int curve, int n_gpus, const void* const* d_bases, const void* const* d_scalars,
+                                const size_t* n_per_gpu, int scalars_are_montgomery, uint64_t* out_xyz);
+
+/* Per-phase device times of the last MSM finished on this device with timing enabled (ms):
  * [digits, partition histogram + scan, partition scatter + finish + bucket order, accumulate (incl. heavy
  *  buckets), reduce, total, window_bits, windows] */
 int ark_hip_msm_set_timing(int enable);
@@ -121,6 +185,12 @@ int ark_hip_ifft_in_place(int field, const ark_hip_radix2_domain* dom, uint64_t*
 /* Same on device memory; asynchronous on the context stream (ark_hip_synchronize() to wait). */
 int ark_hip_fft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d_data);
 int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, void* d_data);
+/* fft_in_place on a coefficient vector of num_coeffs <= size elements (radix2/mod.rs:140-147): the buffer holds
+ * dom->size elements, only the first num_coeffs are read (the rest is treated as zero, as the reference's resize
+ * does).  With num_coeffs * 4 <= size this is the degree-aware path (fft.rs:29-71): the first
+ * log2(size / next_pow2(num_coeffs)) butterfly stages are skipped and only the coefficients are uploaded. */
+int ark_hip_fft_in_place_degree_aware(int field, const ark_hip_radix2_domain* dom, uint64_t* data, size_t num_coeffs);
+int ark_hip_fft_in_place_degree_aware_device(int field, const ark_hip_radix2_domain* dom, void* d_data, size_t num_coeffs);
 /* r[i] = a[i] * b[i] over n Fr elements in device memory: `Evaluations *= &Evaluations`
  * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
  * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */

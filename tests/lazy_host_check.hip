@@ -1,4 +1,4 @@
-// Host-side check of the 28-bit-limb ("lazy") field and mixed addition (algebra_amd/csrc/lazy.cuh) against the
+// Host-side check of the 28-bit-limb ("lazy") field and mixed addition (algebra_amd/csrc/ubench/lazy.cuh) against the
 // saturated form (fp.cuh / ec.cuh, itself checked against the oracle): conversions, products, lazy add/sub,
 // exact zero tests, and random point sequences that hit the doubling and infinity branches.  The templates are
 // __host__ __device__, so this runs on the CPU.  Built and run by tests/test_lazy_host.py.

@@ -1,5 +1,5 @@
-"""lazy.cuh (28-bit-limb field for the MSM accumulate kernel; a measured alternative) is kept
-parity-green by compiling its host build and checking it against the saturated-limb arithmetic."""
+"""ubench/lazy.cuh (28-bit-limb field: a measured alternative to the shipped 32-bit-limb arithmetic, not part of
+the product library -- see DESIGN.md) is kept parity-green by compiling its host build and checking it against the saturated-limb arithmetic."""
 import os
 import shutil
 import subprocess
@@ -14,7 +14,7 @@ def test_lazy_field_and_madd_match_saturated_form(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     exe = str(tmp_path / "lazy_check")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "algebra_amd", "csrc"),
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "algebra_amd", "csrc"), "-I", os.path.join(ROOT, "algebra_amd", "csrc", "ubench"),
                            os.path.join(ROOT, "tests", "lazy_host_check.hip"), "-o", exe], timeout=600)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
