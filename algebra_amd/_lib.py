@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libark_hip.so")
+LIB_PATH = os.environ.get("ARK_HIP_LIB") or os.path.join(_HERE, "libark_hip.so")  # ARK_HIP_LIB: A/B builds (tools/)
 
 u64p = C.POINTER(C.c_uint64)
 

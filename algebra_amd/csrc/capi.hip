@@ -348,11 +348,10 @@ int fft_any(Context* c, int field, const ark_hip_radix2_domain* dom, void* d_dat
 
 // Stage skipping of the degree-aware path (radix2/mod.rs:141, fft.rs:29-71): with num_coeffs * 4 <= size the first
 // log2(size / next_pow2(num_coeffs)) stages only copy; returns that count (0: plain transform).
-int degree_aware_zlog(const ark_hip_radix2_domain* dom, size_t num_coeffs, size_t* d_pow2) {
-  size_t d = 1;
-  while (d < num_coeffs) d <<= 1;
-  *d_pow2 = d;
+int degree_aware_zlog(const ark_hip_radix2_domain* dom, size_t num_coeffs) {
   if (num_coeffs == 0 || num_coeffs * 4 > dom->size) return 0;
+  size_t d = 2;  // at least two input elements are read (the last stage is always executed)
+  while (d < num_coeffs) d <<= 1;
   int z = 0;
   while ((d << z) < dom->size) z++;
   return z;
@@ -835,9 +834,8 @@ static int fft_device_entry(int field, const ark_hip_radix2_domain* dom, void* d
   if (!inverse && num_coeffs < dom->size) {
     // coefficients beyond num_coeffs are zero by contract (the reference resizes with zeros): make them so up to the
     // power of two the transform reads
-    size_t d2 = 0;
-    zlog = degree_aware_zlog(dom, num_coeffs, &d2);
-    const size_t upto = zlog ? d2 : (size_t)dom->size;
+    zlog = degree_aware_zlog(dom, num_coeffs);
+    const size_t upto = (size_t)dom->size >> zlog;
     if (upto > num_coeffs)
       ARK_HIP_TRY(hipMemsetAsync((char*)d + num_coeffs * 32, 0, (upto - num_coeffs) * 32, sc.c->stream));
   }

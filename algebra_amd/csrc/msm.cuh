@@ -277,15 +277,18 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
   if (end - j > heavy_thresh) return;  // left to the heavy-bucket kernels
   XYZZ<F> acc = XYZZ<F>::zero();
   if (j < end) {
+    // software pipeline, two deep on the indices: the gather of point t+1 (whose index arrived an iteration ago) and
+    // the index of point t+2 are both in flight during the ~10 multiplications of addition t
     u32 e = sorted[j];
+    u32 e1 = j + 1 < end ? sorted[j + 1] : 0;
     Affine<F> p = Affine<F>::load(bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
     for (;;) {
-      u32 e_next = 0;
+      u32 e2 = 0;
       Affine<F> p_next = p;
-      bool more = j + 1 < end;
-      if (more) {  // issue the next gather before the ~10 multiplications of this addition
-        e_next = sorted[j + 1];
-        p_next = Affine<F>::load(bases + (size_t)(e_next & 0x7fffffffu) * Affine<F>::BYTES);
+      const bool more = j + 1 < end;
+      if (more) {
+        p_next = Affine<F>::load(bases + (size_t)(e1 & 0x7fffffffu) * Affine<F>::BYTES);
+        if (j + 2 < end) e2 = sorted[j + 2];
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
         F y = F::cond_neg(p.y, (e >> 31) != 0);
@@ -293,7 +296,8 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
         else xyzz_madd<F>(acc, p.x, y);
       }
       if (!more) break;
-      e = e_next;
+      e = e1;
+      e1 = e2;
       p = p_next;
       j++;
     }
@@ -344,31 +348,40 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
     }
     return false;
   };
-  if (open_next()) {
-    u32 e = sorted[j];
-    Affine<F> p = Affine<F>::load(wbase + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+  // the run iterator runs two entries ahead of the additions: (e1, wb1) is entry t+1, whose gather is issued at the
+  // top of iteration t with an index that arrived an iteration ago; the index of entry t+2 is fetched meanwhile
+  auto next_entry = [&](u32& eo, const char*& wbo) -> bool {
+    if (j >= end && !open_next()) return false;
+    eo = sorted[j];
+    wbo = wbase;
+    j++;
+    return true;
+  };
+  u32 e = 0, e1 = 0;
+  const char *wb = table, *wb1 = table;
+  if (next_entry(e, wb)) {
+    Affine<F> p = Affine<F>::load(wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+    bool have1 = next_entry(e1, wb1);
     for (;;) {
-      u32 e_next = 0;
+      u32 e2 = 0;
+      const char* wb2 = table;
+      bool have2 = false;
       Affine<F> p_next = p;
-      bool more;
-      if (j + 1 < end) {
-        j++;
-        more = true;
-      } else {
-        more = open_next();
-      }
-      if (more) {  // the next gather is in flight during this addition
-        e_next = sorted[j];
-        p_next = Affine<F>::load(wbase + (size_t)(e_next & 0x7fffffffu) * Affine<F>::BYTES);
+      if (have1) {
+        p_next = Affine<F>::load(wb1 + (size_t)(e1 & 0x7fffffffu) * Affine<F>::BYTES);
+        have2 = next_entry(e2, wb2);
       }
       if (!p.is_zero()) {
         F y = F::cond_neg(p.y, (e >> 31) != 0);
         if constexpr (C::RELAXED) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
       }
-      if (!more) break;
-      e = e_next;
+      if (!have1) break;
+      e = e1;
       p = p_next;
+      e1 = e2;
+      wb1 = wb2;
+      have1 = have2;
     }
   }
   if constexpr (C::RELAXED) acc = xyzz_canonical<F>(acc);
@@ -622,20 +635,35 @@ __global__ void __launch_bounds__(256) msm_reduce_bits_kernel(const char* __rest
     acc.store(partial + (((size_t)w * gridDim.y + q) * gridDim.x + ch) * Pt::BYTES);
 }
 
-// sums the `nchunks` chunk partials of every (window, quantity) pair: one lane each (nchunks <= 16)
+// sums the `nchunks` chunk partials of every (window, quantity) pair: one wave per pair, lanes stride over the
+// partials, then a 6-step LDS tree (a single lane walking 16-32 partials serially cost ~0.5 ms of pure latency)
 template <class C>
 __global__ void __launch_bounds__(64) msm_sum_chunks_kernel(const char* __restrict__ partial, u32 npairs, u32 nchunks,
                                                             char* __restrict__ out) {
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ uint4 chunk_lds[];
+  char* sh = (char*)chunk_lds;
+  const u32 t = blockIdx.x, lane = threadIdx.x;
   if (t >= npairs) return;
-  Pt acc = Pt::load(partial + (size_t)t * nchunks * Pt::BYTES);
-  for (u32 k = 1; k < nchunks; k++) {
+  Pt acc = Pt::zero();
+  for (u32 k = lane; k < nchunks; k += 64) {
     Pt x = Pt::load(partial + ((size_t)t * nchunks + k) * Pt::BYTES);
     xyzz_add<F>(acc, x);
   }
-  acc.store(out + (size_t)t * Pt::BYTES);
+  u32 width = 1;
+  while (width < nchunks && width < 64) width <<= 1;
+  acc.store(sh + (size_t)lane * Pt::BYTES);
+  __syncthreads();
+  for (u32 o = width / 2; o > 0; o >>= 1) {
+    if (lane < o) {
+      Pt other = Pt::load(sh + (size_t)(lane + o) * Pt::BYTES);
+      xyzz_add<F>(acc, other);
+      acc.store(sh + (size_t)lane * Pt::BYTES);
+    }
+    __syncthreads();
+  }
+  if (lane == 0) acc.store(out + (size_t)t * Pt::BYTES);
 }
 
 // ---- host-side plan / workspace -----------------------------------------------------------------
@@ -846,8 +874,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
 
   // bucket-id split for the two-pass partition sort (msm_sort.cuh)
   const int Bbits = c - 1;
-  const int LB = Bbits < PART_LO_BITS ? Bbits : PART_LO_BITS;
-  const int HB = Bbits - LB;
+  int HB, LB;
+  msm_part_split(n, Bbits, &HB, &LB);
   const u32 nsuper = (u32)W << HB;
   const u32 ntiles = (u32)((n + PART_TILE - 1) / PART_TILE);
   const size_t nthist = (size_t)nsuper * ntiles;
@@ -947,7 +975,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   {
     // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device; the workspace is per device)
     const size_t lds_a = ((size_t)8 << HB) + (size_t)PART_TILE * 8;
-    const size_t lds_b = ((size_t)(1 << PART_LO_BITS) + 1024 + PART_STAGE) * 4;
+    const u32 stage_cap = msm_part_stage_cap(LB);
+    const size_t lds_b = ((size_t)(1 << LB) + 1024 + stage_cap) * 4;
     if (!ws.attr_set) {
       ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024 - 4096 - 64));
@@ -958,7 +987,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, W), dim3(1024), lds_a, stream, keys, (u32)n, HB, LB, ntiles,
                        toff, part);
     hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper), dim3(1024), lds_b, stream, part, toff, ntiles, LB, nsuper,
-                       offsets, sorted);
+                       stage_cap, offsets, sorted);
   }
   {
     // processing order, heaviest load class first; class width 2^shift so that the mean falls around class 32..63
@@ -1018,7 +1047,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   }
   const char* d_sums = (const char*)ws.lvlS[1].p;
   if (nchunks > 1) {
-    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)((npairs + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)npairs), dim3(64), 64 * Pt::BYTES, stream,
                        (const char*)ws.lvlS[1].p, (u32)npairs, nchunks, (char*)ws.lvlA[1].p);
     d_sums = (const char*)ws.lvlA[1].p;
   }

@@ -26,7 +26,33 @@
 
 namespace arkhip {
 
-static constexpr int PART_LO_BITS = 10;        // buckets per super-bucket = 2^10 (2^9 measured no better)
+static constexpr int PART_LO_BITS = 10;        // buckets per super-bucket = 2^10 by default (2^9 measured no better) ...
+static constexpr int PART_LO_BITS_MAX = 12;    // ... up to 2^12 where the window is wide (msm_part_split)
+static constexpr u32 PART_LDS_WORDS = (160 * 1024 - 64) / 4;  // dynamic LDS of the finish kernel, u32 words
+
+// Split of the B = c-1 bucket bits into HB super-bucket bits (pass A) and LB bits finished in LDS (pass B).  Pass A
+// keeps 2^HB counters per (window, 8192-key tile): its histogram array -- W * 2^HB * n/8192 counters, written and
+// scanned in bin-major order -- is what grows with wide windows, so HB is kept as small as pass B allows: a
+// super-bucket (n / 2^HB entries on average) must fit the finish kernel's LDS staging area (~32 K entries) and has at
+// most 2^12 buckets.
+static inline void msm_part_split(size_t n, int B, int* HB, int* LB) {
+  int hb = 0;
+  if (B > PART_LO_BITS) {
+    hb = B - PART_LO_BITS;                       // 2^10 buckets per super-bucket ...
+    if (hb > 9) {                                // ... unless that needs more than 2^9 counters per tile
+      hb = B - PART_LO_BITS_MAX;
+      if (hb < 9) hb = 9;
+    }
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    if (hb < lg - 15) hb = lg - 15;              // super-bucket (n / 2^hb entries) within the LDS staging area
+    if (hb > B) hb = B;
+  }
+  *HB = hb;
+  *LB = B - hb;
+}
+// staging entries of the finish kernel for a given LB
+static inline u32 msm_part_stage_cap(int LB) { return PART_LDS_WORDS - 1024u - (1u << LB) - 16u; }
 static constexpr int PART_TILE = 8192;         // keys per workgroup in pass A (64 KiB of staged pairs)
 static constexpr u32 PART_KEY_NONE = 0xffffffffu;
 
@@ -133,18 +159,18 @@ static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32
 
 // B: one workgroup per super-bucket sb = (w << HB | low bits): bucket SLOTS sb << LB | high bits.  The sorted indices
 // of the super-bucket are assembled in LDS and written out linearly; a super-bucket larger than the
-// staging area (skewed scalars) falls back to direct placement.
-static constexpr u32 PART_STAGE = 36864;  // u32 entries of staging: 144 KiB
+// staging area (skewed scalars) falls back to direct placement.  Dynamic LDS: (2^LB + 1024 + stage_cap) words.
 static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint2* __restrict__ part,
                                                                       const u32* __restrict__ tile_off, u32 ntiles,
-                                                                      int LB, u32 nsuper, u32* __restrict__ offsets,
+                                                                      int LB, u32 nsuper, u32 stage_cap,
+                                                                      u32* __restrict__ offsets,
                                                                       u32* __restrict__ sorted) {
   extern __shared__ u32 part_lds[];
-  u32* cnt = part_lds;                         // [1 << PART_LO_BITS]
-  u32* wsum = part_lds + (1 << PART_LO_BITS);  // [1024]
-  u32* stage = wsum + 1024;                    // [PART_STAGE]
-  const u32 sb = blockIdx.x;
   const u32 nlow = 1u << LB;
+  u32* cnt = part_lds;            // [nlow]
+  u32* wsum = part_lds + nlow;    // [1024]
+  u32* stage = wsum + 1024;       // [stage_cap]
+  const u32 sb = blockIdx.x;
   const u32 start = tile_off[(size_t)sb * ntiles];
   const u32 end = tile_off[(size_t)(sb + 1) * ntiles];  // tile_off has nsuper * ntiles + 1 entries
   for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
@@ -152,8 +178,12 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
   const u32 lmask = nlow - 1u;
   for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&cnt[part[j].x & lmask], 1u);
   __syncthreads();
-  // exclusive scan of cnt[0..nlow): lane t owns bin t (nlow <= 1024 = blockDim)
-  u32 v = threadIdx.x < nlow ? cnt[threadIdx.x] : 0;
+  // exclusive scan of cnt[0..nlow): lane t owns `per` consecutive bins (nlow <= 4096, blockDim = 1024)
+  const u32 per = nlow > blockDim.x ? nlow / blockDim.x : 1u;
+  const u32 b0 = threadIdx.x * per;
+  u32 v = 0;
+  if (b0 < nlow)
+    for (u32 k = 0; k < per; k++) v += cnt[b0 + k];
   wsum[threadIdx.x] = v;
   __syncthreads();
   for (u32 o = 1; o < blockDim.x; o <<= 1) {
@@ -162,15 +192,19 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
     wsum[threadIdx.x] += y;
     __syncthreads();
   }
-  const u32 excl = wsum[threadIdx.x] - v;
-  if (threadIdx.x < nlow) {
-    cnt[threadIdx.x] = excl;  // local placement cursor
-    offsets[((size_t)sb << LB) + threadIdx.x] = start + excl;
+  if (b0 < nlow) {
+    u32 run = wsum[threadIdx.x] - v;
+    for (u32 k = 0; k < per; k++) {
+      const u32 c = cnt[b0 + k];
+      cnt[b0 + k] = run;  // local placement cursor
+      offsets[((size_t)sb << LB) + b0 + k] = start + run;
+      run += c;
+    }
   }
   if (sb == nsuper - 1 && threadIdx.x == 0) offsets[(size_t)nsuper << LB] = end;
   __syncthreads();
   const u32 total = end - start;
-  if (total <= PART_STAGE) {
+  if (total <= stage_cap) {
     for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) {
       uint2 e = part[j];
       u32 pos = atomicAdd(&cnt[e.x & lmask], 1u);

@@ -1,0 +1,191 @@
+//! Raw FFI: one declaration per entry point of include/ark_hip.h that a Rust host binds, plus the one safe wrapper
+//! that must live below ark-poly in the dependency graph (`radix2_fft_in_place`).  This crate is the only `unsafe`
+//! surface: ark-ec and ark-poly `#![forbid(unsafe_code)]` (ec/src/lib.rs:10, poly/src/lib.rs:4).
+#![allow(non_camel_case_types)]
+use ark_ff::{FftField, Field, PrimeField};
+use core::ffi::{c_char, c_int, c_void};
+
+// field ids / curve ids of include/ark_hip.h
+pub const BN254_FQ: c_int = 0;
+pub const BN254_FR: c_int = 1;
+pub const BLS12_381_FQ: c_int = 2;
+pub const BLS12_381_FR: c_int = 3;
+pub const BLS12_377_FQ: c_int = 4;
+pub const BLS12_377_FR: c_int = 5;
+pub const BN254_G1: c_int = 0;
+pub const BLS12_381_G1: c_int = 1;
+pub const BLS12_377_G1: c_int = 2;
+pub const BLS12_377_G2: c_int = 3;
+pub const BLS12_381_G2: c_int = 4;
+pub const ERR_SCALAR_RANGE: c_int = -4;
+pub const ERR_BUSY: c_int = -6;
+
+/// Mirror of `Radix2EvaluationDomain<F>` (poly/src/domain/radix2/mod.rs:22-42) for a 4-limb F.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ark_hip_radix2_domain {
+    pub size: u64,
+    pub log_size_of_group: u32,
+    pub _pad: u32,
+    pub size_as_field_element: [u64; 4],
+    pub size_inv: [u64; 4],
+    pub group_gen: [u64; 4],
+    pub group_gen_inv: [u64; 4],
+    pub offset: [u64; 4],
+    pub offset_inv: [u64; 4],
+    pub offset_pow_size: [u64; 4],
+}
+/// Opaque handles.
+#[repr(C)]
+pub struct ark_hip_msm_bases {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct ark_hip_msm_job {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn ark_hip_device_count() -> c_int;
+    pub fn ark_hip_init(device: c_int) -> c_int;
+    pub fn ark_hip_set_device(device: c_int) -> c_int;
+    pub fn ark_hip_get_device() -> c_int;
+    pub fn ark_hip_shutdown();
+    pub fn ark_hip_synchronize() -> c_int;
+    pub fn ark_hip_version() -> *const c_char;
+    pub fn ark_hip_malloc(bytes: usize, out_dptr: *mut *mut c_void) -> c_int;
+    pub fn ark_hip_free(dptr: *mut c_void) -> c_int;
+    pub fn ark_hip_memcpy_h2d(dst_dptr: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
+    pub fn ark_hip_memcpy_d2h(dst_host: *mut c_void, src_dptr: *const c_void, bytes: usize) -> c_int;
+    pub fn ark_hip_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
+    pub fn ark_hip_host_free(ptr: *mut c_void) -> c_int;
+    pub fn ark_hip_msm_sw(curve: c_int, bases: *const u64, scalars: *const u64, n: usize,
+                          scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_sw_device(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,
+                                 scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_sw_device_async(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,
+                                       scalars_are_montgomery: c_int, out_job: *mut *mut ark_hip_msm_job) -> c_int;
+    pub fn ark_hip_msm_wait(job: *mut ark_hip_msm_job, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_bases_prepare(curve: c_int, bases: *const u64, n: usize, out: *mut *mut ark_hip_msm_bases) -> c_int;
+    pub fn ark_hip_msm_bases_prepare_device(curve: c_int, d_bases: *const c_void, n: usize,
+                                            out: *mut *mut ark_hip_msm_bases) -> c_int;
+    pub fn ark_hip_msm_bases_free(bases: *mut ark_hip_msm_bases) -> c_int;
+    pub fn ark_hip_msm_bases_info(bases: *const ark_hip_msm_bases, n: *mut usize, window_bits: *mut c_int,
+                                  windows: *mut c_int, table_bytes: *mut usize) -> c_int;
+    pub fn ark_hip_msm_prepared(bases: *const ark_hip_msm_bases, scalars: *const u64, n: usize,
+                                scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_prepared_device(bases: *const ark_hip_msm_bases, d_scalars: *const c_void, n: usize,
+                                       scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_prepared_async(bases: *const ark_hip_msm_bases, scalars: *const u64, n: usize,
+                                      scalars_are_montgomery: c_int, out_job: *mut *mut ark_hip_msm_job) -> c_int;
+    pub fn ark_hip_msm_prepared_device_async(bases: *const ark_hip_msm_bases, d_scalars: *const c_void, n: usize,
+                                             scalars_are_montgomery: c_int, out_job: *mut *mut ark_hip_msm_job) -> c_int;
+    pub fn ark_hip_msm_sw_chunks(curve: c_int, bases: *const u64, n_bases: usize, scalars: *const u64, n_scalars: usize,
+                                 step: usize, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_sw_multi(curve: c_int, n_gpus: c_int, bases: *const u64, scalars: *const u64, n: usize,
+                                scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_sw_multi_device(curve: c_int, n_gpus: c_int, d_bases: *const *const c_void,
+                                       d_scalars: *const *const c_void, n_per_gpu: *const usize,
+                                       scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_sw_sum(curve: c_int, jac_points: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_sw_normalize_batch_device(curve: c_int, d_jac: *const c_void, d_out_xy: *mut c_void, n: usize) -> c_int;
+    pub fn ark_hip_fft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;
+    pub fn ark_hip_ifft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;
+    pub fn ark_hip_fft_in_place_degree_aware(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64,
+                                             num_coeffs: usize) -> c_int;
+    pub fn ark_hip_fft_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void) -> c_int;
+    pub fn ark_hip_ifft_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void) -> c_int;
+    pub fn ark_hip_fr_mul_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+}
+
+const BN254_FR_MODULUS: [u64; 4] = [0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029];
+const BLS12_381_FR_MODULUS: [u64; 4] = [0xffffffff00000001, 0x53bda402fffe5bfe, 0x3339d80809a1d805, 0x73eda753299d7d48];
+const BLS12_377_FR_MODULUS: [u64; 4] = [0x0a11800000000001, 0x59aa76fed0000001, 0x60b44d1e5c37b001, 0x12ab655e9a2ca556];
+
+/// The library's id of `F` when `F` is one of the three scalar fields it serves (recognised by modulus), else `None`.
+pub fn fr_field_id<F: Field>() -> Option<c_int> {
+    if F::extension_degree() != 1 {
+        return None;
+    }
+    let m = <F::BasePrimeField as PrimeField>::MODULUS;
+    let l: &[u64] = m.as_ref();
+    if l.len() != 4 {
+        return None;
+    }
+    let l = [l[0], l[1], l[2], l[3]];
+    if l == BLS12_381_FR_MODULUS {
+        Some(BLS12_381_FR)
+    } else if l == BN254_FR_MODULUS {
+        Some(BN254_FR)
+    } else if l == BLS12_377_FR_MODULUS {
+        Some(BLS12_377_FR)
+    } else {
+        None
+    }
+}
+
+/// The Montgomery limbs of a 4-limb prime-field element.  `Fp` is `(BigInt<4>, PhantomData)`
+/// (ff/src/fields/models/fp/mod.rs:109-115): not `#[repr(C)]`, so the size is checked by every caller.
+fn limbs<F>(x: &F) -> [u64; 4] {
+    debug_assert_eq!(core::mem::size_of::<F>(), 32);
+    unsafe { *(x as *const F as *const [u64; 4]) }
+}
+
+/// `Radix2EvaluationDomain::{fft,ifft}_in_place` on the GPU when the coefficients are elements of a served scalar
+/// field (radix2/mod.rs:140-153).  Called by ark-poly's `hip` feature (patches/0003) with the domain's public fields
+/// `consts = [size_inv, group_gen, group_gen_inv, offset, offset_inv]`.  Returns `false` -- having changed nothing
+/// the CPU path cares about -- when `T` is not `F` (Rust has no specialisation: the coefficient type is recognised by
+/// name and layout), the field is not served, or the device reports an error; the caller then runs the CPU code.
+/// Forward transforms of at most size/4 coefficients take the degree-aware entry (fft.rs:29-71): only the
+/// coefficients cross PCIe.
+pub fn radix2_fft_in_place<F: FftField, T: Copy>(
+    size: u64,
+    log_size_of_group: u32,
+    consts: &[F; 5],
+    coeffs: &mut ark_std::vec::Vec<T>,
+    zero: T,
+    inverse: bool,
+) -> bool {
+    if core::any::type_name::<T>() != core::any::type_name::<F>()
+        || core::mem::size_of::<T>() != 32
+        || core::mem::size_of::<F>() != 32
+        || core::mem::align_of::<T>() != core::mem::align_of::<u64>()
+    {
+        return false;
+    }
+    let Some(fid) = fr_field_id::<F>() else {
+        return false;
+    };
+    let n = size as usize;
+    let len = coeffs.len();
+    if len > n {
+        return false; // the CPU path reports this the reference's way
+    }
+    let dom = ark_hip_radix2_domain {
+        size,
+        log_size_of_group,
+        _pad: 0,
+        size_as_field_element: [0; 4], // not read by the transforms
+        size_inv: limbs(&consts[0]),
+        group_gen: limbs(&consts[1]),
+        group_gen_inv: limbs(&consts[2]),
+        offset: limbs(&consts[3]),
+        offset_inv: limbs(&consts[4]),
+        offset_pow_size: [0; 4],
+    };
+    coeffs.resize(n, zero); // radix2/mod.rs:144,151
+    let p = coeffs.as_mut_ptr() as *mut u64;
+    let rc = unsafe {
+        if inverse {
+            ark_hip_ifft_in_place(fid, &dom, p)
+        } else {
+            ark_hip_fft_in_place_degree_aware(fid, &dom, p, len)
+        }
+    };
+    if rc != 0 {
+        // the device works on its own copy and writes back only on success: the input is intact
+        coeffs.truncate(len);
+        return false;
+    }
+    true
+}

@@ -1,10 +1,20 @@
-//! ark-hip: plugs libark_hip.so (MI355X MSM + radix-2 FFT) into ark-ec / ark-poly.
+//! ark-hip: plugs libark_hip.so (MI355X MSM + radix-2 FFT) into ark-ec / ark-poly 0.6.
 //!
-//! * `msm::Hip*Config`  -- `SWCurveConfig`s whose `msm` runs on the GPU: `Projective<HipBls12_381G1Config>::msm(..)`
-//! * `domain::HipRadix2EvaluationDomain<F>` -- an `EvaluationDomain<F>` whose (i)fft runs on the GPU
+//! Two ways in:
+//! * **patched arkworks** (patches/0001-0003): the upstream curve configs override `SWCurveConfig::msm` /
+//!   `msm_bigint` behind their `hip` feature and call [`msm::sw_msm`] / [`msm::sw_msm_bigint`]; `G1Projective` stays
+//!   the same type, `VariableBaseMSM::{msm, msm_unchecked, msm_bigint, msm_chunks}`, `ChunkedPippenger` and
+//!   `HashMapPippenger` all reach the GPU.  ark-poly's `hip` feature does the same for `Radix2EvaluationDomain`.
+//! * **unmodified arkworks**: [`hip_sw_config!`] declares a wrapper `SWCurveConfig` (every item of the trait
+//!   delegated, `msm` on the GPU) and [`domain::HipRadix2EvaluationDomain`] wraps the evaluation domain.
+//!
+//! Beyond the reference's surface: [`msm::PreparedBases`] (a fixed SRS resident on the GPU with its per-window
+//! multiples), [`msm::MsmJob`] (asynchronous MSMs), [`msm::msm_multi`] (one MSM over all GPUs of the node).
 //!
 //! SOURCE ONLY: the image this repository is built in has no Rust toolchain; the identical C ABI is exercised by
-//! tests/ through ctypes.  See INTEGRATION.md.
+//! tests/ through ctypes and through the compiled C++ mirror (include/ark_hip.hpp).
 pub mod domain;
 pub mod msm;
-pub mod sys;
+pub use ark_hip_sys as sys;
+pub use ark_hip_sys::{BLS12_377_G1, BLS12_377_G2, BLS12_381_G1, BLS12_381_G2, BN254_G1};
+pub use msm::{sw_msm, sw_msm_bigint};

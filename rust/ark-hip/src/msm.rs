@@ -1,68 +1,272 @@
-//! MSM hook.  `SWCurveConfig::msm` is the reference's designed override point
-//! (ec/src/models/short_weierstrass/mod.rs:111-119); `<Projective<P> as VariableBaseMSM>::msm` forwards to it
-//! (group.rs:650-657).  A wrapper config delegates every constant to the upstream config and overrides `msm`.
-use crate::sys;
+//! MSM entry points for short-Weierstrass curves.
+//!
+//! Reference surface replaced (ec/src/scalar_mul/variable_base/mod.rs:59-150, short_weierstrass/mod.rs:112-119,
+//! group.rs:650-657):  `msm` -> [`sw_msm`], `msm_bigint` (and through it `msm_unchecked`, `msm_chunks`,
+//! `ChunkedPippenger`, `HashMapPippenger`) -> [`sw_msm_bigint`].
 use ark_ec::short_weierstrass::{Affine, Projective, SWCurveConfig};
-use ark_ec::{scalar_mul::variable_base::VariableBaseMSM, CurveConfig};
-use ark_ff::{BigInt, PrimeField};
-use core::ffi::c_int;
+use ark_ec::scalar_mul::variable_base::VariableBaseMSM;
+use ark_ff::PrimeField;
+use ark_hip_sys as sys;
+use ark_std::vec::Vec;
+use core::ffi::{c_int, c_void};
+use core::marker::PhantomData;
+use core::mem::{size_of, MaybeUninit};
 
-/// Implemented for each upstream config served by libark_hip.so.
-pub trait HipCurve: SWCurveConfig {
-    const CURVE_ID: c_int;
-    /// u64 words of one base-field element (4, 6 or 12)
-    const FE_WORDS: usize;
+type BigIntOf<P> = <<P as ark_ec::CurveConfig>::ScalarField as PrimeField>::BigInt;
+
+/// u64 words of one base-field element for a library curve id
+pub const fn fe_words(curve: c_int) -> usize {
+    match curve {
+        0 => 4,
+        1 | 2 => 6,
+        _ => 12,
+    }
 }
 
 /// Layout guard.  arkworks types are not `#[repr(C)]`; in practice `Fp(BigInt([u64; N]), PhantomData)`,
-/// `Affine { x, y, infinity: () }` and `Projective { x, y, z }` are contiguous in declaration order.
-/// The shim refuses to run (and falls back to the CPU path) if the sizes disagree.
-fn layout_ok<P: HipCurve>() -> bool {
-    core::mem::size_of::<Affine<P>>() == 2 * P::FE_WORDS * 8
-        && core::mem::size_of::<Projective<P>>() == 3 * P::FE_WORDS * 8
-        && core::mem::size_of::<P::ScalarField>() == 32
+/// `Affine { x, y, infinity: () }` and `Projective { x, y, z }` are contiguous in declaration order, which is what the
+/// C ABI assumes.  A curve whose `ZeroFlag` is `bool` (an extra byte in `Affine`) or any other surprise fails the check:
+/// the call then takes the CPU path and says so once -- never silently.
+fn layout_ok<P: SWCurveConfig, S>(curve: c_int) -> bool {
+    let ok = size_of::<Affine<P>>() == 2 * fe_words(curve) * 8
+        && size_of::<Projective<P>>() == 3 * fe_words(curve) * 8
+        && size_of::<S>() == 32;
+    if !ok {
+        #[cfg(feature = "std")]
+        {
+            static WARNED: std::sync::Once = std::sync::Once::new();
+            WARNED.call_once(|| {
+                std::eprintln!(
+                    "ark-hip: in-memory layout of curve id {curve} does not match libark_hip.so \
+                     (Affine {} B, Projective {} B, scalar {} B): MSM stays on the CPU",
+                    size_of::<Affine<P>>(),
+                    size_of::<Projective<P>>(),
+                    size_of::<S>()
+                );
+            });
+        }
+        debug_assert!(ok, "ark-hip layout mismatch");
+    }
+    ok
 }
 
-/// `VariableBaseMSM::msm_unchecked` on the GPU (scalars are Fr in Montgomery form: the `into_bigint`
-/// pass of variable_base/mod.rs:60-62 runs on the device).  `None` => caller uses the CPU default.
-pub fn msm_fr<P: HipCurve>(bases: &[Affine<P>], scalars: &[P::ScalarField]) -> Option<Projective<P>> {
-    if !layout_ok::<P>() {
+/// One device MSM over host slices; `None` on layout mismatch or device error (the caller falls back to the CPU).
+fn device_msm<P: SWCurveConfig, S>(curve: c_int, bases: &[Affine<P>], scalars: &[S], montgomery: bool) -> Option<Projective<P>> {
+    if !layout_ok::<P, S>(curve) {
         return None;
     }
     let n = bases.len().min(scalars.len());
-    let mut out = core::mem::MaybeUninit::<Projective<P>>::uninit();
+    let mut out = MaybeUninit::<Projective<P>>::uninit();
     let rc = unsafe {
-        sys::ark_hip_msm_sw(P::CURVE_ID, bases.as_ptr() as *const u64, scalars.as_ptr() as *const u64, n, 1,
-                            out.as_mut_ptr() as *mut u64)
+        sys::ark_hip_msm_sw(curve, bases.as_ptr() as *const u64, scalars.as_ptr() as *const u64, n,
+                            montgomery as c_int, out.as_mut_ptr() as *mut u64)
     };
     (rc == 0).then(|| unsafe { out.assume_init() })
 }
 
-/// `VariableBaseMSM::msm_bigint` on the GPU (canonical BigInt<4> scalars) -- what the reference benches
-/// (bench-templates/src/macros/ec.rs:240) and ChunkedPippenger (stream_pippenger.rs:48) call.
-pub fn msm_bigint<P: HipCurve>(bases: &[Affine<P>], bigints: &[<P::ScalarField as PrimeField>::BigInt])
-                               -> Option<Projective<P>>
-where
-    P::ScalarField: PrimeField<BigInt = BigInt<4>>,
-{
-    if !layout_ok::<P>() {
+/// CPU fallback for canonical scalars.
+fn cpu_msm_bigint<P: SWCurveConfig>(bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Projective<P> {
+    #[cfg(feature = "ec-hook")]
+    {
+        ark_ec::scalar_mul::variable_base::msm_bigint_default(bases, bigints) // patches/0001
+    }
+    #[cfg(not(feature = "ec-hook"))]
+    {
+        <Projective<P> as VariableBaseMSM>::msm_bigint(bases, bigints) // trait default: msm_signed on the CPU
+    }
+}
+
+/// `SWCurveConfig::msm` (short_weierstrass/mod.rs:112-119): `Err(min_len)` when the lengths differ, else the sum
+/// on the GPU -- the `into_bigint` pass of variable_base/mod.rs:60-62 included (scalars cross as Montgomery residues).
+pub fn sw_msm<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalars: &[P::ScalarField]) -> Result<Projective<P>, usize> {
+    if bases.len() != scalars.len() {
+        return Err(bases.len().min(scalars.len()));
+    }
+    Ok(device_msm::<P, P::ScalarField>(curve, bases, scalars, true).unwrap_or_else(|| {
+        let bigints = scalars.iter().map(|s| s.into_bigint()).collect::<Vec<_>>();
+        cpu_msm_bigint::<P>(bases, &bigints)
+    }))
+}
+
+/// `VariableBaseMSM::msm_bigint` (variable_base/mod.rs:80-85): truncates to the shorter input like the reference.
+pub fn sw_msm_bigint<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Projective<P> {
+    device_msm::<P, BigIntOf<P>>(curve, bases, bigints, false).unwrap_or_else(|| cpu_msm_bigint::<P>(bases, bigints))
+}
+
+/// `VariableBaseMSM::msm_chunks` (variable_base/mod.rs:119-150) over slices: streams aligned at their end, steps of
+/// 2^20 pairs, the next step's upload overlapping the current step's kernels.  `None` on device error.
+pub fn sw_msm_chunks<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalars: &[P::ScalarField]) -> Option<Projective<P>> {
+    assert!(scalars.len() <= bases.len());
+    if !layout_ok::<P, P::ScalarField>(curve) {
+        return None;
+    }
+    let mut out = MaybeUninit::<Projective<P>>::uninit();
+    let rc = unsafe {
+        sys::ark_hip_msm_sw_chunks(curve, bases.as_ptr() as *const u64, bases.len(), scalars.as_ptr() as *const u64,
+                                   scalars.len(), 0, out.as_mut_ptr() as *mut u64)
+    };
+    (rc == 0).then(|| unsafe { out.assume_init() })
+}
+
+/// One MSM over `n_gpus` GPUs of this node, driven from this process (base-range shards, variable_base/mod.rs:521-557).
+pub fn msm_multi<P: SWCurveConfig>(curve: c_int, n_gpus: usize, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Option<Projective<P>> {
+    if !layout_ok::<P, BigIntOf<P>>(curve) {
         return None;
     }
     let n = bases.len().min(bigints.len());
-    let mut out = core::mem::MaybeUninit::<Projective<P>>::uninit();
+    let mut out = MaybeUninit::<Projective<P>>::uninit();
     let rc = unsafe {
-        sys::ark_hip_msm_sw(P::CURVE_ID, bases.as_ptr() as *const u64, bigints.as_ptr() as *const u64, n, 0,
-                            out.as_mut_ptr() as *mut u64)
+        sys::ark_hip_msm_sw_multi(curve, n_gpus as c_int, bases.as_ptr() as *const u64, bigints.as_ptr() as *const u64, n, 0,
+                                  out.as_mut_ptr() as *mut u64)
     };
     (rc == 0).then(|| unsafe { out.assume_init() })
 }
 
-/// Declares `$name`, a drop-in `SWCurveConfig` equal to `$up` except that `msm` runs on the MI355X.
+/// An MSM in flight on the device.  `wait` blocks until the result is there.
+pub struct MsmJob<'a, P: SWCurveConfig> {
+    job: *mut sys::ark_hip_msm_job,
+    _inputs: PhantomData<&'a P>, // the scalars (and bases) must outlive the job
+}
+impl<P: SWCurveConfig> MsmJob<'_, P> {
+    pub fn wait(mut self) -> Option<Projective<P>> {
+        let mut out = MaybeUninit::<Projective<P>>::uninit();
+        let rc = unsafe { sys::ark_hip_msm_wait(self.job, out.as_mut_ptr() as *mut u64) };
+        self.job = core::ptr::null_mut();
+        (rc == 0).then(|| unsafe { out.assume_init() })
+    }
+}
+impl<P: SWCurveConfig> Drop for MsmJob<'_, P> {
+    fn drop(&mut self) {
+        if !self.job.is_null() {
+            unsafe { sys::ark_hip_msm_wait(self.job, core::ptr::null_mut()) }; // never leak a device job slot
+        }
+    }
+}
+
+/// A base set (an SRS) kept in GPU memory across MSMs together with its per-window multiples (include/ark_hip.h,
+/// "prepared base sets"): uploaded and precomputed once, then every call moves only the scalars.  What a prover's
+/// commit loop holds in place of the `bases: &[Affine]` argument of `VariableBaseMSM::msm`.
+pub struct PreparedBases<P: SWCurveConfig> {
+    handle: *mut sys::ark_hip_msm_bases,
+    n: usize,
+    _p: PhantomData<P>,
+}
+unsafe impl<P: SWCurveConfig> Send for PreparedBases<P> {}
+unsafe impl<P: SWCurveConfig> Sync for PreparedBases<P> {} // the library locks per device
+impl<P: SWCurveConfig> PreparedBases<P> {
+    pub fn new(curve: c_int, bases: &[Affine<P>]) -> Option<Self> {
+        if !layout_ok::<P, P::ScalarField>(curve) {
+            return None;
+        }
+        let mut h = core::ptr::null_mut();
+        let rc = unsafe { sys::ark_hip_msm_bases_prepare(curve, bases.as_ptr() as *const u64, bases.len(), &mut h) };
+        (rc == 0).then(|| Self { handle: h, n: bases.len(), _p: PhantomData })
+    }
+    pub fn len(&self) -> usize {
+        self.n
+    }
+    pub fn is_empty(&self) -> bool {
+        self.n == 0
+    }
+    fn run<S>(&self, scalars: &[S], montgomery: bool) -> Option<Projective<P>> {
+        let n = self.n.min(scalars.len());
+        let mut out = MaybeUninit::<Projective<P>>::uninit();
+        let rc = unsafe {
+            sys::ark_hip_msm_prepared(self.handle, scalars.as_ptr() as *const u64, n, montgomery as c_int,
+                                      out.as_mut_ptr() as *mut u64)
+        };
+        (rc == 0).then(|| unsafe { out.assume_init() })
+    }
+    /// `msm`: `Err(min_len)` on a length mismatch (variable_base/mod.rs:73-77); `Ok(None)` on device error.
+    pub fn msm(&self, scalars: &[P::ScalarField]) -> Result<Option<Projective<P>>, usize> {
+        if scalars.len() != self.n {
+            return Err(scalars.len().min(self.n));
+        }
+        Ok(self.run(scalars, true))
+    }
+    pub fn msm_unchecked(&self, scalars: &[P::ScalarField]) -> Option<Projective<P>> {
+        self.run(scalars, true)
+    }
+    pub fn msm_bigint(&self, bigints: &[BigIntOf<P>]) -> Option<Projective<P>> {
+        self.run(bigints, false)
+    }
+    /// Enqueue and return: the scalars upload on the copy stream while the previous MSM computes.
+    pub fn msm_bigint_async<'a>(&'a self, bigints: &'a [BigIntOf<P>]) -> Option<MsmJob<'a, P>> {
+        let n = self.n.min(bigints.len());
+        let mut job = core::ptr::null_mut();
+        let rc = unsafe { sys::ark_hip_msm_prepared_async(self.handle, bigints.as_ptr() as *const u64, n, 0, &mut job) };
+        (rc == 0).then(|| MsmJob { job, _inputs: PhantomData })
+    }
+}
+impl<P: SWCurveConfig> Drop for PreparedBases<P> {
+    fn drop(&mut self) {
+        unsafe { sys::ark_hip_msm_bases_free(self.handle) };
+    }
+}
+
+/// Page-locked host buffer of scalars (ark_hip_host_alloc): uploads at full PCIe rate and truly asynchronously.
+pub struct PinnedScalars<S: Copy> {
+    ptr: *mut S,
+    len: usize,
+}
+impl<S: Copy> PinnedScalars<S> {
+    pub fn new(len: usize) -> Option<Self> {
+        let mut p: *mut c_void = core::ptr::null_mut();
+        let rc = unsafe { sys::ark_hip_host_alloc(len * size_of::<S>(), &mut p) };
+        (rc == 0).then(|| Self { ptr: p as *mut S, len })
+    }
+    pub fn as_mut_slice(&mut self) -> &mut [MaybeUninit<S>] {
+        unsafe { core::slice::from_raw_parts_mut(self.ptr as *mut MaybeUninit<S>, self.len) }
+    }
+    /// # Safety
+    /// every element must have been written
+    pub unsafe fn assume_init(&self) -> &[S] {
+        core::slice::from_raw_parts(self.ptr, self.len)
+    }
+}
+impl<S: Copy> Drop for PinnedScalars<S> {
+    fn drop(&mut self) {
+        unsafe { sys::ark_hip_host_free(self.ptr as *mut c_void) };
+    }
+}
+
+/// Declares `$name`, a drop-in `SWCurveConfig` equal to the upstream config `$up` -- EVERY item of the trait
+/// (short_weierstrass/mod.rs:34-203: the three constants, `ZeroFlag`, `mul_by_a`, `add_b`, the subgroup check,
+/// cofactor clearing, both scalar multiplications, serialisation) is delegated, so points serialise in the upstream
+/// format and keep the upstream's endomorphism-based checks -- except that `msm` (and, with patches/0001,
+/// `msm_bigint`) run on the MI355X.  For unmodified arkworks; with patches/0002 the upstream configs do this
+/// themselves and `G1Projective` stays the same type.
 #[macro_export]
 macro_rules! hip_sw_config {
-    ($name:ident, $up:ty, $id:expr, $words:expr) => {
+    ($name:ident, $up:ty, $id:expr) => {
         #[derive(Clone, Default, PartialEq, Eq)]
         pub struct $name;
+        impl $name {
+            #[inline]
+            fn to_up(p: &ark_ec::short_weierstrass::Affine<Self>) -> ark_ec::short_weierstrass::Affine<$up> {
+                if ark_ec::AffineRepr::is_zero(p) {
+                    <ark_ec::short_weierstrass::Affine<$up> as ark_ec::AffineRepr>::zero()
+                } else {
+                    ark_ec::short_weierstrass::Affine::<$up>::new_unchecked(p.x, p.y)
+                }
+            }
+            #[inline]
+            fn from_up(p: ark_ec::short_weierstrass::Affine<$up>) -> ark_ec::short_weierstrass::Affine<Self> {
+                if ark_ec::AffineRepr::is_zero(&p) {
+                    <ark_ec::short_weierstrass::Affine<Self> as ark_ec::AffineRepr>::zero()
+                } else {
+                    ark_ec::short_weierstrass::Affine::<Self>::new_unchecked(p.x, p.y)
+                }
+            }
+            #[inline]
+            fn proj_to_up(p: &ark_ec::short_weierstrass::Projective<Self>) -> ark_ec::short_weierstrass::Projective<$up> {
+                ark_ec::short_weierstrass::Projective::<$up>::new_unchecked(p.x, p.y, p.z)
+            }
+            #[inline]
+            fn proj_from_up(p: ark_ec::short_weierstrass::Projective<$up>) -> ark_ec::short_weierstrass::Projective<Self> {
+                ark_ec::short_weierstrass::Projective::<Self>::new_unchecked(p.x, p.y, p.z)
+            }
+        }
         impl ark_ec::CurveConfig for $name {
             type BaseField = <$up as ark_ec::CurveConfig>::BaseField;
             type ScalarField = <$up as ark_ec::CurveConfig>::ScalarField;
@@ -76,85 +280,57 @@ macro_rules! hip_sw_config {
                 <$up as ark_ec::short_weierstrass::SWCurveConfig>::GENERATOR.x,
                 <$up as ark_ec::short_weierstrass::SWCurveConfig>::GENERATOR.y,
             );
+            type ZeroFlag = <$up as ark_ec::short_weierstrass::SWCurveConfig>::ZeroFlag;
+
             #[inline(always)]
-            fn mul_by_a(e: Self::BaseField) -> Self::BaseField {
-                <$up as ark_ec::short_weierstrass::SWCurveConfig>::mul_by_a(e)
+            fn mul_by_a(elem: Self::BaseField) -> Self::BaseField {
+                <$up as ark_ec::short_weierstrass::SWCurveConfig>::mul_by_a(elem)
             }
-            /// short_weierstrass/mod.rs:112-119: length check stays here, the sum runs on the GPU,
-            /// any device error falls back to the reference's CPU path.
+            #[inline(always)]
+            fn add_b(elem: Self::BaseField) -> Self::BaseField {
+                <$up as ark_ec::short_weierstrass::SWCurveConfig>::add_b(elem)
+            }
+            fn is_in_correct_subgroup_assuming_on_curve(item: &ark_ec::short_weierstrass::Affine<Self>) -> bool {
+                <$up as ark_ec::short_weierstrass::SWCurveConfig>::is_in_correct_subgroup_assuming_on_curve(&Self::to_up(item))
+            }
+            fn clear_cofactor(item: &ark_ec::short_weierstrass::Affine<Self>) -> ark_ec::short_weierstrass::Affine<Self> {
+                Self::from_up(<$up as ark_ec::short_weierstrass::SWCurveConfig>::clear_cofactor(&Self::to_up(item)))
+            }
+            fn mul_projective(base: &ark_ec::short_weierstrass::Projective<Self>, scalar: &[u64])
+                              -> ark_ec::short_weierstrass::Projective<Self> {
+                Self::proj_from_up(<$up as ark_ec::short_weierstrass::SWCurveConfig>::mul_projective(&Self::proj_to_up(base), scalar))
+            }
+            fn mul_affine(base: &ark_ec::short_weierstrass::Affine<Self>, scalar: &[u64])
+                          -> ark_ec::short_weierstrass::Projective<Self> {
+                Self::proj_from_up(<$up as ark_ec::short_weierstrass::SWCurveConfig>::mul_affine(&Self::to_up(base), scalar))
+            }
+            /// short_weierstrass/mod.rs:112-119: the length check, then the sum on the GPU; any device error falls back
+            /// to the reference's CPU path.
             fn msm(bases: &[ark_ec::short_weierstrass::Affine<Self>], scalars: &[Self::ScalarField])
                    -> Result<ark_ec::short_weierstrass::Projective<Self>, usize> {
-                if bases.len() != scalars.len() {
-                    return Err(bases.len().min(scalars.len()));
-                }
-                Ok($crate::msm::msm_fr::<Self>(bases, scalars)
-                    .unwrap_or_else(|| ark_ec::scalar_mul::variable_base::VariableBaseMSM::msm_unchecked(bases, scalars)))
+                $crate::msm::sw_msm::<Self>($id, bases, scalars)
             }
-        }
-        impl $crate::msm::HipCurve for $name {
-            const CURVE_ID: core::ffi::c_int = $id;
-            const FE_WORDS: usize = $words;
+            #[cfg(feature = "ec-hook")]
+            fn msm_bigint(bases: &[ark_ec::short_weierstrass::Affine<Self>],
+                          bigints: &[<Self::ScalarField as ark_ff::PrimeField>::BigInt])
+                          -> ark_ec::short_weierstrass::Projective<Self> {
+                $crate::msm::sw_msm_bigint::<Self>($id, bases, bigints)
+            }
+            #[inline]
+            fn serialize_with_mode<W: ark_serialize::Write>(item: &ark_ec::short_weierstrass::Affine<Self>, writer: W,
+                                                            compress: ark_serialize::Compress)
+                                                            -> Result<(), ark_serialize::SerializationError> {
+                <$up as ark_ec::short_weierstrass::SWCurveConfig>::serialize_with_mode(&Self::to_up(item), writer, compress)
+            }
+            fn deserialize_with_mode<R: ark_serialize::Read>(reader: R, compress: ark_serialize::Compress,
+                                                             validate: ark_serialize::Validate)
+                                                             -> Result<ark_ec::short_weierstrass::Affine<Self>, ark_serialize::SerializationError> {
+                <$up as ark_ec::short_weierstrass::SWCurveConfig>::deserialize_with_mode(reader, compress, validate).map(Self::from_up)
+            }
+            #[inline]
+            fn serialized_size(compress: ark_serialize::Compress) -> usize {
+                <$up as ark_ec::short_weierstrass::SWCurveConfig>::serialized_size(compress)
+            }
         }
     };
-}
-
-#[cfg(feature = "bls12-381")]
-hip_sw_config!(HipBls12_381G1Config, ark_bls12_381::g1::Config, crate::sys::BLS12_381_G1, 6);
-#[cfg(feature = "bls12-381")]
-hip_sw_config!(HipBls12_381G2Config, ark_bls12_381::g2::Config, crate::sys::BLS12_381_G2, 12);
-#[cfg(feature = "bn254")]
-hip_sw_config!(HipBn254G1Config, ark_bn254::g1::Config, crate::sys::BN254_G1, 4);
-#[cfg(feature = "bls12-377")]
-hip_sw_config!(HipBls12_377G1Config, ark_bls12_377::g1::Config, crate::sys::BLS12_377_G1, 6);
-#[cfg(feature = "bls12-377")]
-hip_sw_config!(HipBls12_377G2Config, ark_bls12_377::g2::Config, crate::sys::BLS12_377_G2, 12);
-
-// So that `ark_ec::...` paths used above resolve without the user importing them.
-#[allow(unused_imports)]
-use {CurveConfig as _, VariableBaseMSM as _};
-
-/// A base set (an SRS) kept in GPU memory across MSMs: uploaded once, then every `msm_bigint` call moves only the
-/// scalars (what `ChunkedPippenger` / a prover's commit loop wants).
-pub struct ResidentBases<P: HipCurve> {
-    d_bases: *mut core::ffi::c_void,
-    d_scalars: *mut core::ffi::c_void,
-    n: usize,
-    _p: core::marker::PhantomData<P>,
-}
-impl<P: HipCurve> ResidentBases<P> {
-    pub fn upload(bases: &[Affine<P>]) -> Option<Self> {
-        if !layout_ok::<P>() {
-            return None;
-        }
-        let (mut db, mut ds) = (core::ptr::null_mut(), core::ptr::null_mut());
-        let bytes = core::mem::size_of_val(bases);
-        unsafe {
-            if sys::ark_hip_malloc(bytes, &mut db) != 0 || sys::ark_hip_malloc(bases.len() * 32, &mut ds) != 0 {
-                return None;
-            }
-            if sys::ark_hip_memcpy_h2d(db, bases.as_ptr() as *const _, bytes) != 0 {
-                return None;
-            }
-        }
-        Some(Self { d_bases: db, d_scalars: ds, n: bases.len(), _p: core::marker::PhantomData })
-    }
-    pub fn msm_bigint(&self, bigints: &[BigInt<4>]) -> Option<Projective<P>> {
-        let n = self.n.min(bigints.len());
-        let mut out = core::mem::MaybeUninit::<Projective<P>>::uninit();
-        let rc = unsafe {
-            if sys::ark_hip_memcpy_h2d(self.d_scalars, bigints.as_ptr() as *const _, n * 32) != 0 {
-                return None;
-            }
-            sys::ark_hip_msm_sw_device(P::CURVE_ID, self.d_bases, self.d_scalars, n, 0, out.as_mut_ptr() as *mut u64)
-        };
-        (rc == 0).then(|| unsafe { out.assume_init() })
-    }
-}
-impl<P: HipCurve> Drop for ResidentBases<P> {
-    fn drop(&mut self) {
-        unsafe {
-            sys::ark_hip_free(self.d_bases);
-            sys::ark_hip_free(self.d_scalars);
-        }
-    }
 }

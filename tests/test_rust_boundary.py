@@ -1,0 +1,139 @@
+"""The Rust side of the boundary cannot be compiled here (no rustc / cargo in the image), so it is checked statically:
+
+* patches/*.patch apply cleanly to the reference tree (`git apply --check`; skipped where /root/reference is absent);
+* `hip_sw_config!` (rust/ark-hip/src/msm.rs) provides EVERY item of the reference's `SWCurveConfig` trait
+  (ec/src/models/short_weierstrass/mod.rs:34-203) and `HipRadix2EvaluationDomain` every REQUIRED item of
+  `EvaluationDomain` (poly/src/domain/mod.rs:31-329) -- the item lists are parsed from the reference when it is
+  present and otherwise read from tests/golden/trait_items.json (kept equal to the parse by this very test);
+* every `extern "C"` declaration in rust/ark-hip-sys/src/lib.rs names a function of include/ark_hip.h with the same
+  number of parameters;
+* the crates target arkworks 0.6.0, the version of the reference workspace.
+"""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLDEN = os.path.join(ROOT, "tests", "golden", "trait_items.json")
+
+
+def _trait_body(src, name):
+    src = re.sub(r"//[^\n]*", "", src)  # doc comments talk about "a type that ..."
+    i = src.index("pub trait %s" % name)
+    j = src.index("{", i)
+    depth, k = 0, j
+    while True:
+        if src[k] == "{":
+            depth += 1
+        elif src[k] == "}":
+            depth -= 1
+            if depth == 0:
+                return src[j + 1:k]
+        k += 1
+
+
+def _items(body):
+    """(kind, name, has_default) of the trait's direct items"""
+    out = []
+    depth = 0
+    for m in re.finditer(r"[{}]|\b(fn|const|type)\s+([A-Za-z_][A-Za-z0-9_]*)", body):
+        if m.group(0) == "{":
+            depth += 1
+        elif m.group(0) == "}":
+            depth -= 1
+        elif depth == 0:
+            kind, name = m.group(1), m.group(2)
+            rest = body[m.end():]
+            # required item: the declaration ends with ';' before any '{' ... for consts/types a default has '='
+            semi, brace = rest.find(";"), rest.find("{")
+            if kind == "fn":
+                has_default = brace != -1 and (semi == -1 or brace < semi)
+            else:
+                has_default = "=" in rest[:semi]
+            out.append((kind, name, has_default))
+    return out
+
+
+def _reference_items():
+    sw = _items(_trait_body(open(os.path.join(REF, "ec/src/models/short_weierstrass/mod.rs")).read(), "SWCurveConfig"))
+    ed = _items(_trait_body(open(os.path.join(REF, "poly/src/domain/mod.rs")).read(), "EvaluationDomain"))
+    return {"SWCurveConfig": [list(x) for x in sw], "EvaluationDomain": [list(x) for x in ed]}
+
+
+def _trait_items():
+    golden = json.load(open(GOLDEN))
+    if os.path.isdir(REF):
+        assert _reference_items() == golden, "tests/golden/trait_items.json is stale: regenerate with tools/make_golden.py"
+    return golden
+
+
+def test_patches_apply_to_the_reference_tree():
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present on this box")
+    patches = sorted(p for p in os.listdir(os.path.join(ROOT, "patches")) if p.endswith(".patch"))
+    assert len(patches) >= 3
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", "-p1", os.path.join(ROOT, "patches", p)], cwd=REF,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stderr)
+
+
+def test_wrapper_config_macro_covers_every_trait_item():
+    items = _trait_items()["SWCurveConfig"]
+    names = {n for _, n, _ in items}
+    assert {"COEFF_A", "COEFF_B", "GENERATOR", "ZeroFlag", "msm", "mul_projective", "serialize_with_mode"} <= names
+    src = open(os.path.join(ROOT, "rust", "ark-hip", "src", "msm.rs")).read()
+    macro = src[src.index("macro_rules! hip_sw_config"):]
+    impl = macro[macro.index("impl ark_ec::short_weierstrass::SWCurveConfig for $name"):]
+    for kind, name, _ in items:
+        assert re.search(r"\b%s\s+%s\b" % (kind, name), impl), "hip_sw_config! does not provide `%s %s`" % (kind, name)
+    # and the hook patches/0001 adds
+    assert re.search(r"\bfn\s+msm_bigint\b", impl)
+
+
+def test_domain_newtype_covers_every_required_item():
+    items = _trait_items()["EvaluationDomain"]
+    src = open(os.path.join(ROOT, "rust", "ark-hip", "src", "domain.rs")).read()
+    impl = src[src.index("impl<F: FftField> EvaluationDomain<F> for HipRadix2EvaluationDomain<F>"):]
+    required = [(k, n) for k, n, d in items if not d]
+    assert ("fn", "fft_in_place") in required and ("fn", "elements") in required
+    for kind, name in required:
+        assert re.search(r"\b%s\s+%s\b" % (kind, name), impl), "HipRadix2EvaluationDomain lacks `%s %s`" % (kind, name)
+
+
+def _c_decls():
+    h = open(os.path.join(ROOT, "include", "ark_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|void|const char\*)\s+(ark_hip_\w+)\s*\(([^;]*?)\)\s*;", h, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def test_rust_ffi_declarations_match_the_header():
+    decl = _c_decls()
+    src = open(os.path.join(ROOT, "rust", "ark-hip-sys", "src", "lib.rs")).read()
+    ext = src[src.index('extern "C" {'):]
+    ext = ext[:ext.index("\n}\n")]
+    found = re.findall(r"pub fn (ark_hip_\w+)\s*\(([^;]*?)\)\s*(?:->\s*[^;]+)?;", ext, flags=re.S)
+    assert len(found) >= 35
+    for name, args in found:
+        assert name in decl, "%s is not declared in include/ark_hip.h" % name
+        n = 0 if not args.strip() else len([a for a in args.split(",") if a.strip()])
+        assert n == decl[name], "%s: %d parameters in Rust, %d in C" % (name, n, decl[name])
+
+
+def test_crates_target_the_reference_version():
+    if os.path.isdir(REF):
+        ws = open(os.path.join(REF, "Cargo.toml")).read()
+        assert re.search(r'\[workspace.package\]\s*version = "0.6.0"', ws)
+    for crate in ("ark-hip-sys", "ark-hip", "ark-hip-curves"):
+        toml = open(os.path.join(ROOT, "rust", crate, "Cargo.toml")).read()
+        deps = re.findall(r'^(ark-(?:ff|ec|poly|serialize|std|bls12-381|bls12-377|bn254)) = \{ version = "([^"]+)"', toml, flags=re.M)
+        assert deps, crate
+        assert all(v == "0.6.0" for _, v in deps), (crate, deps)

@@ -79,6 +79,14 @@ def main():
     arr = np.array(pts, dtype=np.uint64)
     np.savez_compressed(os.path.join(OUT, "bls12_377_g2_h2c_points.npz"), xy=arr)
     print("g1/g2 multiples + %d BLS12-377 G2 points written to %s" % (len(pts), OUT))
+    # item lists of the two traits the Rust binding implements (tests/test_rust_boundary.py checks the binding against
+    # them where the reference tree is not available)
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), ""))
+    sys.path.insert(0, os.path.dirname(OUT))
+    import test_rust_boundary as T
+    with open(T.GOLDEN, "w") as f:
+        json.dump(T._reference_items(), f, indent=1)
+    print("trait item lists written to %s" % T.GOLDEN)
 
 
 if __name__ == "__main__":
