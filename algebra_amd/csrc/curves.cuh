@@ -15,6 +15,8 @@ struct BN254_G1 {
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 0;
   typedef Fp<BN254_FQ> F;
+  typedef F FA;                           // field type of the bucket-accumulation kernels
+  static constexpr bool RELAXED_A = RELAXED;
   typedef BN254_FR S;
 };
 struct BLS12_381_G1 {
@@ -22,6 +24,8 @@ struct BLS12_381_G1 {
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 1;
   typedef Fp<BLS12_381_FQ> F;
+  typedef F FA;                           // field type of the bucket-accumulation kernels
+  static constexpr bool RELAXED_A = RELAXED;
   typedef BLS12_381_FR S;
 };
 struct BLS12_377_G1 {
@@ -29,20 +33,26 @@ struct BLS12_377_G1 {
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 2;
   typedef Fp<BLS12_377_FQ> F;
+  typedef F FA;                           // field type of the bucket-accumulation kernels
+  static constexpr bool RELAXED_A = RELAXED;
   typedef BLS12_377_FR S;
 };
 struct BLS12_377_G2 {
-  static constexpr int ACC_MIN_WAVES = 1;   // (2 = cap at 256 registers: measured slower, the extra spills cost more than the second wave hides)
+  static constexpr int ACC_MIN_WAVES = 1;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 3;
   typedef Fp2<BLS12_377_FQ, 5> F;
+  typedef Fp2Half<BLS12_377_FQ, 5> FA;    // bucket accumulation: one Fp2 element per lane PAIR (fp.cuh)
+  static constexpr bool RELAXED_A = true;
   typedef BLS12_377_FR S;
 };
 struct BLS12_381_G2 {
-  static constexpr int ACC_MIN_WAVES = 1;   // (2 = cap at 256 registers: measured slower, the extra spills cost more than the second wave hides)
+  static constexpr int ACC_MIN_WAVES = 1;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 4;
   typedef Fp2<BLS12_381_FQ, 1> F;
+  typedef Fp2Half<BLS12_381_FQ, 1> FA;    // bucket accumulation: one Fp2 element per lane PAIR (fp.cuh)
+  static constexpr bool RELAXED_A = true;
   typedef BLS12_381_FR S;
 };
 

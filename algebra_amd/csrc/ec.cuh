@@ -19,12 +19,20 @@ namespace arkhip {
 template <class F>
 struct Affine {
   F x, y;
-  static constexpr int BYTES = 2 * F::BYTES;
-  ARK_HD bool is_zero() const { return x.is_zero() && y.is_zero(); }  // affine.rs:91-104
+  static constexpr int BYTES = 2 * F::FULL_BYTES;   // in memory (an Fp2Half lane holds half of each coordinate)
+  ARK_HD bool is_zero() const {  // affine.rs:91-104
+    if constexpr (F::LANES == 2) {
+      const bool zx = x.is_zero();  // pair-wide tests: evaluated by both lanes, never short-circuited
+      const bool zy = y.is_zero();
+      return zx && zy;
+    } else {
+      return x.is_zero() && y.is_zero();
+    }
+  }
   ARK_HD static Affine load(const void* p) {
     Affine a;
     a.x = F::load(p);
-    a.y = F::load((const char*)p + F::BYTES);
+    a.y = F::load((const char*)p + F::FULL_BYTES);
     return a;
   }
 };
@@ -32,24 +40,24 @@ struct Affine {
 template <class F>
 struct XYZZ {
   F x, y, zz, zzz;
-  static constexpr int BYTES = 4 * F::BYTES;
+  static constexpr int BYTES = 4 * F::FULL_BYTES;
   ARK_HD static XYZZ zero() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }  // bucket.rs:78-83
   ARK_HD bool is_zero() const { return zz.is_zero(); }
   ARK_HD static XYZZ load(const void* p) {
     XYZZ r;
     const char* q = (const char*)p;
     r.x = F::load(q);
-    r.y = F::load(q + F::BYTES);
-    r.zz = F::load(q + 2 * F::BYTES);
-    r.zzz = F::load(q + 3 * F::BYTES);
+    r.y = F::load(q + F::FULL_BYTES);
+    r.zz = F::load(q + 2 * F::FULL_BYTES);
+    r.zzz = F::load(q + 3 * F::FULL_BYTES);
     return r;
   }
   ARK_HD void store(void* p) const {
     char* q = (char*)p;
     x.store(q);
-    y.store(q + F::BYTES);
-    zz.store(q + 2 * F::BYTES);
-    zzz.store(q + 3 * F::BYTES);
+    y.store(q + F::FULL_BYTES);
+    zz.store(q + 2 * F::FULL_BYTES);
+    zzz.store(q + 3 * F::FULL_BYTES);
   }
   ARK_HD static XYZZ from_affine(const Affine<F>& a) {
     if (a.is_zero()) return zero();
@@ -61,14 +69,14 @@ struct XYZZ {
 template <class F>
 struct Jac {
   F x, y, z;
-  static constexpr int BYTES = 3 * F::BYTES;
+  static constexpr int BYTES = 3 * F::FULL_BYTES;
   ARK_HD static Jac zero() { return Jac{F::one(), F::one(), F::zero()}; }  // group.rs:145-151
   ARK_HD bool is_zero() const { return z.is_zero(); }
   ARK_HD void store(void* p) const {
     char* q = (char*)p;
     x.store(q);
-    y.store(q + F::BYTES);
-    z.store(q + 2 * F::BYTES);
+    y.store(q + F::FULL_BYTES);
+    z.store(q + 2 * F::FULL_BYTES);
   }
 };
 
@@ -143,8 +151,10 @@ ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
   }
   F p = F::sub_r(F::mul_r(x2, acc.zz), acc.x);
   F r = F::sub_r(F::mul_r(y2, acc.zzz), acc.y);
-  if (p.is_zero_mod_p()) {
-    if (r.is_zero_mod_p()) acc = xyzz_mdbl<F>(x2, y2);   // canonical arithmetic; rare
+  const bool pz = p.is_zero_mod_p();  // evaluated unconditionally: over a lane pair (Fp2Half) a test is an exchange
+  const bool rz = r.is_zero_mod_p();
+  if (pz) {
+    if (rz) acc = xyzz_mdbl<F>(x2, y2);   // canonical arithmetic; rare
     else acc = XYZZ<F>::zero();
     return;
   }
@@ -152,7 +162,9 @@ ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
   F ppp = F::mul_r(p, pp);
   F q = F::mul_r(acc.x, pp);
   F x3 = F::sub_r(F::sub_r(F::mul_r(r, r), ppp), F::dbl_r(q));
-  F y3 = F::sop2_r(r, F::sub_r(q, x3), F::neg_r(acc.y), ppp);  // R (Q - X3) - Y1 PPP under one reduction
+  F y3;
+  if constexpr (F::FUSED_Y3) y3 = F::sop2_r(r, F::sub_r(q, x3), F::neg_r(acc.y), ppp);  // R (Q - X3) - Y1 PPP, one reduction
+  else y3 = F::sub_r(F::mul_r(r, F::sub_r(q, x3)), F::mul_r(acc.y, ppp));
   acc.x = x3;
   acc.y = y3;
   acc.zz = F::mul_r(acc.zz, pp);

@@ -169,6 +169,9 @@ struct Fp {
   static constexpr int N = P::N;        // 32-bit limbs
   static constexpr int WORDS64 = N / 2; // u64 words in memory
   static constexpr int BYTES = 4 * N;
+  static constexpr int LANES = 1;       // lanes an element is spread over (Fp2Half: 2)
+  static constexpr int FULL_BYTES = BYTES;
+  static constexpr bool FUSED_Y3 = true;  // has sop2_r (ec.cuh: Y3 of the mixed addition under one reduction)
   u32 l[N];
 
   ARK_HD static Fp zero() {
@@ -554,6 +557,9 @@ struct Fp2 {
   typedef P_ P;
   static constexpr int WORDS64 = 2 * B::WORDS64;
   static constexpr int BYTES = 2 * B::BYTES;
+  static constexpr int LANES = 1;
+  static constexpr int FULL_BYTES = BYTES;
+  static constexpr bool FUSED_Y3 = false;
   B c0, c1;
 
   ARK_HD static Fp2 zero() { return Fp2{B::zero(), B::zero()}; }
@@ -643,6 +649,97 @@ struct Fp2 {
     c0.store(p);
     c1.store((char*)p + B::BYTES);
   }
+};
+
+// ---- Fp2 element spread over a LANE PAIR: the even lane holds c0, the odd lane c1 --------------------------------
+// The bucket-accumulation kernel over Fp2 (G2) needs ~2x the registers of the G1 kernel when one lane owns a whole
+// element (XYZZ accumulator = 96 VGPRs alone): one wave per SIMD, and at one wave per SIMD the multiplier pipeline
+// runs at ~64% of its rate (profiles/r1_ubench_instruction_rates.txt, "mad+addc @1 waves/SIMD").  Splitting every
+// element over two adjacent lanes halves the register need per lane -- the G1 kernel's budget, two waves per SIMD --
+// for the same multiply work:   lane c0:  a0 b0 + (beta a1) b1      lane c1:  a0 b1 + a1 b0
+// each ONE sum of two products under one Montgomery reduction (Fp::sop2_r); the partner's operands arrive through
+// DPP quad_perm [1,0,3,2] (v_mov_dpp, full rate, no LDS).  Additions are component-wise.  Every branch condition is
+// made pair-uniform (a zero test is the AND of both lanes' tests), so the two lanes never diverge.
+// Values are "relaxed" residues (< 2p) as in the G1 kernel; `canonical()` folds them back below p.
+template <class P_, int NEG_BETA>
+struct Fp2Half {
+  typedef Fp<P_> B;
+  typedef P_ P;
+  static constexpr int N = B::N;
+  static constexpr int BYTES = B::BYTES;           // bytes this lane holds
+  static constexpr int FULL_BYTES = 2 * B::BYTES;  // bytes of the whole element in memory (c0 | c1)
+  static constexpr int LANES = 2;
+  static constexpr bool FUSED_Y3 = false;
+  B v;
+
+  // (device-only type; the bodies are visible to the host pass as well because kernel templates are parsed there)
+  ARK_DEV static bool odd() { return (threadIdx.x & 1u) != 0; }
+  ARK_DEV static u32 swap1(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]: the pair partner's value
+#else
+    return x;
+#endif
+  }
+  ARK_DEV static B partner(const B& x) {
+    B r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = swap1(x.l[i]);
+    return r;
+  }
+  ARK_DEV static bool both(bool mine) { return mine && (swap1(mine ? 1u : 0u) != 0); }
+  ARK_DEV static Fp2Half zero() { return Fp2Half{B::zero()}; }
+  ARK_DEV static Fp2Half one() { return Fp2Half{odd() ? B::zero() : B::one()}; }
+  ARK_DEV bool is_zero() const { return both(v.is_zero()); }
+  ARK_DEV bool is_zero_mod_p() const { return both(v.is_zero_mod_p()); }
+  ARK_DEV static Fp2Half add_r(const Fp2Half& a, const Fp2Half& b) { return Fp2Half{B::add_r(a.v, b.v)}; }
+  ARK_DEV static Fp2Half sub_r(const Fp2Half& a, const Fp2Half& b) { return Fp2Half{B::sub_r(a.v, b.v)}; }
+  ARK_DEV static Fp2Half dbl_r(const Fp2Half& a) { return Fp2Half{B::dbl_r(a.v)}; }
+  ARK_DEV static Fp2Half neg(const Fp2Half& a) { return Fp2Half{B::neg(a.v)}; }  // canonical input (a base's y)
+  ARK_DEV static Fp2Half cond_neg(const Fp2Half& a, bool n) { return n ? neg(a) : a; }
+  ARK_DEV Fp2Half canonical() const { return Fp2Half{v.canonical()}; }
+  // NEG_BETA * (2p - x) for a relaxed x: an N-limb representative (<= 2 NEG_BETA p) of beta * x, operand of sop2_r only
+  ARK_DEV static B beta_times(const B& x) {
+    static_assert((u64)(1 + 2 * NEG_BETA) * ((u64)P::P[N - 1] + 1) < (1ull << 32), "2 NEG_BETA p must fit N limbs");
+    B n = B::neg_r(x);
+    if constexpr (NEG_BETA == 1) return n;
+    B q;  // 4n + n
+#pragma unroll
+    for (int i = N - 1; i > 0; i--) q.l[i] = (n.l[i] << 2) | (n.l[i - 1] >> 30);
+    q.l[0] = n.l[0] << 2;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      u32 co;
+      q.l[i] = __builtin_addc(q.l[i], n.l[i], c, &co);
+      c = co;
+    }
+    return q;
+  }
+  // relaxed product: operands < 2p; the sum of products is < (4 + 4 NEG_BETA) p^2... (24 p^2 for beta = -5 over
+  // BLS12-377, 8 p^2 for beta = -1 over BLS12-381): (sum + m p) / R < 2p for both fields (p/R = 0.0063, 0.102)
+  ARK_DEV static Fp2Half mul_r(const Fp2Half& a, const Fp2Half& b) {
+    static_assert((P::P[N - 1] >> 29) == 0, "sop2_r without a final subtraction needs 8p <= R");
+    const B pa = partner(a.v), pb = partner(b.v);
+    const bool o = odd();
+    B X, Z;
+    const B bz = beta_times(pa);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      X.l[i] = o ? pa.l[i] : a.v.l[i];   // a0
+      Z.l[i] = o ? a.v.l[i] : bz.l[i];   // a1 (odd lane) / beta a1 (even lane)
+    }
+    return Fp2Half{B::sop2_r(X, b.v, Z, pb)};  // even: a0 b0 + beta a1 b1 ; odd: a0 b1 + a1 b0
+  }
+  // canonical forms (the rare doubling branch and point conversions): relaxed arithmetic + one fold
+  ARK_DEV static Fp2Half mul(const Fp2Half& a, const Fp2Half& b) { return mul_r(a, b).canonical(); }
+  ARK_DEV static Fp2Half sqr(const Fp2Half& a) { return mul_r(a, a).canonical(); }
+  ARK_DEV static Fp2Half add(const Fp2Half& a, const Fp2Half& b) { return Fp2Half{B::add(a.v, b.v)}; }
+  ARK_DEV static Fp2Half sub(const Fp2Half& a, const Fp2Half& b) { return Fp2Half{B::sub(a.v, b.v)}; }
+  ARK_DEV static Fp2Half dbl(const Fp2Half& a) { return Fp2Half{B::dbl(a.v)}; }
+  // this lane's component of the element stored at p (c0 | c1)
+  ARK_DEV static Fp2Half load(const void* p) { return Fp2Half{B::load((const char*)p + (odd() ? B::BYTES : 0))}; }
+  ARK_DEV void store(void* p) const { v.store((char*)p + (odd() ? B::BYTES : 0)); }
 };
 
 }  // namespace arkhip

@@ -269,8 +269,8 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
                                                              const u32* __restrict__ order, u32 nbuckets,
                                                              u32 heavy_thresh, int HB, int LB,
                                                              char* __restrict__ buckets) {
-  typedef typename C::F F;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef typename C::FA F;  // Fp, or Fp2Half: then a lane PAIR owns the bucket (both lanes run the same control flow)
+  u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / F::LANES;
   if (t >= nbuckets) return;
   u32 g = order ? order[t] : t;
   u32 j = offsets[g], end = offsets[g + 1];
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
         F y = F::cond_neg(p.y, (e >> 31) != 0);
-        if constexpr (C::RELAXED) xyzz_madd_relaxed<F>(acc, p.x, y);
+        if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
       }
       if (!more) break;
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
       j++;
     }
   }
-  if constexpr (C::RELAXED) acc = xyzz_canonical<F>(acc);
+  if constexpr (C::RELAXED_A) acc = xyzz_canonical<F>(acc);
   acc.store(buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES);  // g is a slot (msm_sort.cuh)
 }
 
@@ -318,9 +318,9 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
     const char* __restrict__ table, size_t wstride, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
     const u32* __restrict__ order, u32 nbuckets, int W, int B, u32 heavy_thresh, int HB, int LB,
     char* __restrict__ buckets) {
-  typedef typename C::F F;
+  typedef typename C::FA F;  // Fp, or Fp2Half: then a lane PAIR owns the bucket
   typedef XYZZ<F> Pt;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / F::LANES;
   if (t >= nbuckets) return;
   const u32 s = order ? order[t] : t;
   Pt acc = Pt::zero();
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
       }
       if (!p.is_zero()) {
         F y = F::cond_neg(p.y, (e >> 31) != 0);
-        if constexpr (C::RELAXED) xyzz_madd_relaxed<F>(acc, p.x, y);
+        if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
       }
       if (!have1) break;
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
       have1 = have2;
     }
   }
-  if constexpr (C::RELAXED) acc = xyzz_canonical<F>(acc);
+  if constexpr (C::RELAXED_A) acc = xyzz_canonical<F>(acc);
   acc.store(buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * Pt::BYTES);
 }
 
@@ -913,7 +913,13 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   int nbits = 0;
   while (((size_t)1 << nbits) < m) nbits++;
   const u32 Q = (u32)nbits + 1;
-  u32 chunk = 4096;
+  // chunk of the bit-sliced stage: a workgroup's 256 lanes stride over it (chunk/256 serial additions each) before the
+  // 8-step LDS tree -- both pure latency, so chunks are kept short once there are enough of them to fill the chip
+  u32 chunk = 4096;  // (512 / 1024 / 2048 measured no better at 2^24: profiles/r2_msm_sweeps.txt)
+  if (const char* ec = getenv("ARK_HIP_MSM_CHUNK")) {
+    int v = atoi(ec);
+    if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) chunk = (u32)v;
+  }
   if (chunk > m) chunk = (u32)m;
   const u32 nchunks = (u32)((m + chunk - 1) / chunk);
   const size_t npart = (size_t)Wr * Q * nchunks;
@@ -1025,7 +1031,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   }
   if (pl.shared)
   {
-    hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
                        (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, heavy_thresh, HB, LB,
                        (char*)ws.buckets.p);
     hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3((u32)((max_heavy + 63) / 64)), dim3(64), 0, stream,
@@ -1033,7 +1039,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                        Bbits, heavy_thresh, HB, LB, (char*)ws.buckets.p);
   }
   else
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
                        (const char*)d_points, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
 

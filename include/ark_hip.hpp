@@ -1,13 +1,17 @@
 // ark_hip.hpp -- C++17 host-side mirror of the two reference interfaces that libark_hip.so replaces, written over
 // the C ABI of ark_hip.h (header only).  The reference is Rust; this image has no Rust toolchain, so this header is
-// the compiled-language host side (the same surface exists as Rust source in rust/ark-hip/ and as a Python mirror
-// in algebra_amd/).  Names, argument meaning and error behaviour follow the reference:
+// the compiled-language host side (the same surface exists as Rust source in rust/ and as a Python mirror in
+// algebra_amd/).  Names, argument meaning and error behaviour follow the reference:
 //
 //   ark_hip::VariableBaseMSM<Curve>      <- ark_ec::VariableBaseMSM for Projective<P>
 //        msm(bases, scalars)   -> Result: Err(min_len) when the lengths differ   (ec/src/scalar_mul/variable_base/mod.rs:67-78,
 //                                                                                  short_weierstrass/mod.rs:112-119)
 //        msm_unchecked(...)    -> truncates to the shorter input                   (mod.rs:59-64)
 //        msm_bigint(...)       -> scalars are canonical BigInt<4>                  (mod.rs:80-85)
+//        msm_chunks(...)       -> streams aligned at their end, 2^20-pair steps    (mod.rs:119-150)
+//   ark_hip::ChunkedPippenger<Curve>, ark_hip::HashMapPippenger<Curve>             (stream_pippenger.rs:10-128)
+//   ark_hip::PreparedBases<Curve>        a fixed base set resident on the GPU (ark_hip_msm_bases_*): msm / msm_unchecked /
+//                                        msm_bigint over it, synchronous or as ark_hip::MsmJob (asynchronous)
 //   ark_hip::Radix2EvaluationDomain<F>   <- ark_poly::Radix2EvaluationDomain<F> / EvaluationDomain<F>
 //        new_(num_coeffs) -> optional (None when log2(size) > TWO_ADICITY)         (poly/src/domain/radix2/mod.rs:55-83)
 //        get_coset, size, log_size_of_group, size_inv, group_gen, group_gen_inv, coset_offset, coset_offset_inv,
@@ -18,8 +22,11 @@
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+#include <map>
 #include <optional>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 #include "ark_hip.h"
 
@@ -100,6 +107,24 @@ struct VariableBaseMSM {
     return run(bases.data(), reinterpret_cast<const uint64_t*>(bigints.data()),
                bases.size() < bigints.size() ? bases.size() : bigints.size(), 0);
   }
+  // msm_chunks: Fr scalars, streams aligned at their END, steps of 2^20 pairs (0) or `step`
+  static P msm_chunks(const std::vector<A>& bases, const std::vector<Fr>& scalars, size_t step = 0) {
+    if (scalars.size() > bases.size()) throw Error(ARK_HIP_ERR_ARG, "scalars_stream.len() <= bases_stream.len()");
+    P out;
+    check(ark_hip_msm_sw_chunks(Curve::ID, reinterpret_cast<const uint64_t*>(bases.data()), bases.size(),
+                                reinterpret_cast<const uint64_t*>(scalars.data()), scalars.size(), step,
+                                reinterpret_cast<uint64_t*>(&out)),
+          "ark_hip_msm_sw_chunks");
+    return out;
+  }
+  // Projective: Sum (group.rs:659-663)
+  static P sum(const std::vector<P>& pts) {
+    P out;
+    check(ark_hip_sw_sum(Curve::ID, reinterpret_cast<const uint64_t*>(pts.data()), pts.size(),
+                         reinterpret_cast<uint64_t*>(&out)),
+          "ark_hip_sw_sum");
+    return out;
+  }
   // CurveGroup::into_affine
   static A into_affine(const P& p) {
     A out;
@@ -116,6 +141,146 @@ struct VariableBaseMSM {
           "ark_hip_msm_sw");
     return out;
   }
+};
+
+// ---- an MSM in flight (ark_hip_msm_job) -------------------------------------------------------------------------------
+template <class Curve>
+class MsmJob {
+ public:
+  using P = typename Curve::ProjectiveT;
+  explicit MsmJob(ark_hip_msm_job* j) : j_(j) {}
+  MsmJob(MsmJob&& o) noexcept : j_(o.j_) { o.j_ = nullptr; }
+  MsmJob(const MsmJob&) = delete;
+  ~MsmJob() {
+    if (j_) (void)ark_hip_msm_wait(j_, nullptr);  // never leak a device job slot
+  }
+  P wait() {
+    P out;
+    ark_hip_msm_job* j = j_;
+    j_ = nullptr;
+    check(ark_hip_msm_wait(j, reinterpret_cast<uint64_t*>(&out)), "ark_hip_msm_wait");
+    return out;
+  }
+
+ private:
+  ark_hip_msm_job* j_;
+};
+
+// ---- a fixed base set (SRS) resident on the GPU with its per-window multiples -----------------------------------------
+template <class Curve>
+class PreparedBases {
+ public:
+  using A = typename Curve::AffineT;
+  using P = typename Curve::ProjectiveT;
+  explicit PreparedBases(const std::vector<A>& bases) : n_(bases.size()) {
+    check(ark_hip_msm_bases_prepare(Curve::ID, reinterpret_cast<const uint64_t*>(bases.data()), bases.size(), &h_),
+          "ark_hip_msm_bases_prepare");
+  }
+  PreparedBases(const PreparedBases&) = delete;
+  ~PreparedBases() { (void)ark_hip_msm_bases_free(h_); }
+  size_t size() const { return n_; }
+  MsmResult<P> msm(const std::vector<Fr>& scalars) const {
+    if (scalars.size() != n_) return {false, P{}, scalars.size() < n_ ? scalars.size() : n_};
+    return {true, run(reinterpret_cast<const uint64_t*>(scalars.data()), n_, 1), 0};
+  }
+  P msm_unchecked(const std::vector<Fr>& scalars) const {
+    return run(reinterpret_cast<const uint64_t*>(scalars.data()), scalars.size() < n_ ? scalars.size() : n_, 1);
+  }
+  P msm_bigint(const std::vector<BigInt4>& bigints) const {
+    return run(reinterpret_cast<const uint64_t*>(bigints.data()), bigints.size() < n_ ? bigints.size() : n_, 0);
+  }
+  // the scalars must outlive the job
+  MsmJob<Curve> msm_bigint_async(const std::vector<BigInt4>& bigints) const {
+    ark_hip_msm_job* j = nullptr;
+    check(ark_hip_msm_prepared_async(h_, reinterpret_cast<const uint64_t*>(bigints.data()),
+                                     bigints.size() < n_ ? bigints.size() : n_, 0, &j),
+          "ark_hip_msm_prepared_async");
+    return MsmJob<Curve>(j);
+  }
+
+ private:
+  P run(const uint64_t* scalars, size_t n, int montgomery) const {
+    P out;
+    check(ark_hip_msm_prepared(h_, scalars, n, montgomery, reinterpret_cast<uint64_t*>(&out)), "ark_hip_msm_prepared");
+    return out;
+  }
+  ark_hip_msm_bases* h_ = nullptr;
+  size_t n_;
+};
+
+// ---- streaming accumulators (stream_pippenger.rs) ---------------------------------------------------------------------
+template <class Curve>
+class ChunkedPippenger {  // stream_pippenger.rs:10-66
+ public:
+  using A = typename Curve::AffineT;
+  using P = typename Curve::ProjectiveT;
+  explicit ChunkedPippenger(size_t max_msm_buffer) : buf_size_(max_msm_buffer) {
+    bases_.reserve(max_msm_buffer);
+    scalars_.reserve(max_msm_buffer);
+  }
+  static ChunkedPippenger with_size(size_t buf_size) { return ChunkedPippenger(buf_size); }
+  void add(const A& base, const BigInt4& scalar) {
+    bases_.push_back(base);
+    scalars_.push_back(scalar);
+    if (scalars_.size() == buf_size_) flush();
+  }
+  P finalize() {
+    if (!scalars_.empty()) flush();
+    return VariableBaseMSM<Curve>::sum(partials_);  // empty -> identity
+  }
+
+ private:
+  void flush() {
+    partials_.push_back(VariableBaseMSM<Curve>::msm_bigint(bases_, scalars_));
+    bases_.clear();
+    scalars_.clear();
+  }
+  size_t buf_size_;
+  std::vector<A> bases_;
+  std::vector<BigInt4> scalars_;
+  std::vector<P> partials_;
+};
+
+// HashMapPippenger (stream_pippenger.rs:68-128): scalars of equal bases are added in Fr before the MSM.  The modular
+// addition is supplied by the host (`AddFr`: Fr x Fr -> Fr on Montgomery residues), as the reference uses its own
+// field type; a flush runs one MSM over the distinct bases with the Fr -> BigInt conversion on the device.
+template <class Curve, class AddFr>
+class HashMapPippenger {
+ public:
+  using A = typename Curve::AffineT;
+  using P = typename Curve::ProjectiveT;
+  HashMapPippenger(size_t max_msm_buffer, AddFr add) : buf_size_(max_msm_buffer), add_(std::move(add)) {}
+  void add(const A& base, const Fr& scalar) {
+    Key k;
+    std::memcpy(k.data(), &base, sizeof(A));
+    auto it = map_.find(k);
+    if (it == map_.end()) map_.emplace(k, scalar);
+    else it->second = add_(it->second, scalar);
+    if (map_.size() == buf_size_) flush();
+  }
+  P finalize() {
+    if (!map_.empty()) flush();
+    return VariableBaseMSM<Curve>::sum(partials_);
+  }
+
+ private:
+  using Key = std::array<unsigned char, sizeof(A)>;
+  void flush() {
+    std::vector<A> bases;
+    std::vector<Fr> scalars;
+    for (auto& kv : map_) {
+      A a;
+      std::memcpy(&a, kv.first.data(), sizeof(A));
+      bases.push_back(a);
+      scalars.push_back(kv.second);
+    }
+    partials_.push_back(VariableBaseMSM<Curve>::msm_unchecked(bases, scalars));
+    map_.clear();
+  }
+  size_t buf_size_;
+  AddFr add_;
+  std::map<Key, Fr> map_;
+  std::vector<P> partials_;
 };
 
 // ---- Radix2EvaluationDomain ------------------------------------------------------------------------------------------
@@ -153,9 +318,13 @@ class Radix2EvaluationDomain {
   Fr coset_offset_pow_size() const { return fe(s_.offset_pow_size); }
 
   // fft_in_place / ifft_in_place: the Vec is resized to the domain size (zero-extended) first, as in radix2/mod.rs:140-153
+  // (a vector of at most size/4 coefficients takes the degree-aware path, radix2/mod.rs:141: only the coefficients
+  // are uploaded and the leading butterfly stages are skipped)
   void fft_in_place(std::vector<Fr>& coeffs) const {
+    const size_t len = coeffs.size();
     resize(coeffs);
-    check(ark_hip_fft_in_place(FIELD_ID, &s_, reinterpret_cast<uint64_t*>(coeffs.data())), "ark_hip_fft_in_place");
+    check(ark_hip_fft_in_place_degree_aware(FIELD_ID, &s_, reinterpret_cast<uint64_t*>(coeffs.data()), len),
+          "ark_hip_fft_in_place_degree_aware");
   }
   void ifft_in_place(std::vector<Fr>& evals) const {
     resize(evals);

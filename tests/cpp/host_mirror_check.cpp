@@ -46,6 +46,47 @@ void check_msm(const char* name, size_t n) {
   EXPECT(M::into_affine(M::msm_unchecked(bases, shorter)) == ref2_aff, "msm_unchecked truncation");
   // empty -> identity
   EXPECT(M::into_affine(M::msm_bigint({}, {})).is_zero(), "empty msm");
+  // the same sums over a prepared (resident) base set, synchronous and as two jobs in flight
+  {
+    PreparedBases<Curve> pb(bases);
+    auto p1 = pb.msm(mont);
+    EXPECT(p1.ok && M::into_affine(p1.value) == ref_aff, "prepared msm");
+    EXPECT(M::into_affine(pb.msm_bigint(big)) == ref_aff, "prepared msm_bigint");
+    auto p2 = pb.msm(shorter);
+    EXPECT(!p2.ok && p2.min_len == n / 2, "prepared Err(min_len)");
+    EXPECT(M::into_affine(pb.msm_unchecked(shorter)) == ref2_aff, "prepared msm_unchecked truncation");
+    std::vector<BigInt4> half(big.begin(), big.begin() + n / 2);
+    auto j1 = pb.msm_bigint_async(big);
+    auto j2 = pb.msm_bigint_async(half);
+    EXPECT(M::into_affine(j2.wait()) == ref2_aff, "job 2");
+    EXPECT(M::into_affine(j1.wait()) == ref_aff, "job 1");
+  }
+  // msm_chunks == msm (test-templates style: streams of equal length), small steps
+  EXPECT(M::into_affine(M::msm_chunks(bases, mont, 300)) == ref_aff, "msm_chunks");
+  // ChunkedPippenger (test_chunked_pippenger, test-templates/src/msm.rs:112-133)
+  {
+    auto cp = ChunkedPippenger<Curve>::with_size(n / 7 + 1);
+    for (size_t i = 0; i < n; i++) cp.add(bases[i], big[i]);
+    EXPECT(M::into_affine(cp.finalize()) == ref_aff, "ChunkedPippenger");
+    EXPECT(M::into_affine(ChunkedPippenger<Curve>(4).finalize()).is_zero(), "empty ChunkedPippenger");
+  }
+  // HashMapPippenger (test_hashmap_pippenger, msm.rs:135-156): every base added twice with split scalars
+  {
+    auto add_fr = [](const Fr& a, const Fr& b) {
+      Fr r;
+      ark_oracle_field_op(Curve::SCALAR_FIELD, 0, a.limbs.data(), b.limbs.data(), r.limbs.data(), 1);  // host Fr addition
+      return r;
+    };
+    HashMapPippenger<Curve, decltype(add_fr)> hp(n / 3 + 1, add_fr);
+    std::vector<Fr> part(n);
+    ark_oracle_gen_scalars(Curve::SCALAR_FIELD, 99, n, 1, reinterpret_cast<uint64_t*>(part.data()));
+    std::vector<Fr> rest(n);
+    ark_oracle_field_op(Curve::SCALAR_FIELD, 1, reinterpret_cast<const uint64_t*>(mont.data()),
+                        reinterpret_cast<const uint64_t*>(part.data()), reinterpret_cast<uint64_t*>(rest.data()), n);  // mont - part
+    for (size_t i = 0; i < n; i++) hp.add(bases[i], part[i]);
+    for (size_t i = 0; i < n; i++) hp.add(bases[i], rest[i]);
+    EXPECT(M::into_affine(hp.finalize()) == ref_aff, "HashMapPippenger");
+  }
   std::printf("%s msm n=%zu checked\n", name, n);
 }
 
@@ -76,6 +117,12 @@ void check_fft(const char* name, unsigned log_n) {
   EXPECT(std::memcmp(cy.data(), cref.data(), n * 32) == 0, "coset fft");
   Fr zero;
   EXPECT(!dom->get_coset(zero).has_value(), "zero offset -> None");
+  // short input: degree-aware path (radix2/mod.rs:141), same output as the zero-padded transform
+  std::vector<Fr> sx(x.begin(), x.begin() + n / 8 + 1), spad(sx);
+  spad.resize(n);
+  ark_oracle_fft(FIELD, reinterpret_cast<uint64_t*>(spad.data()), log_n, nullptr, 0, 4);
+  auto sy = dom->fft(sx);
+  EXPECT(sy.size() == n && std::memcmp(sy.data(), spad.data(), n * 32) == 0, "degree-aware fft");
   std::printf("%s fft 2^%u checked\n", name, log_n);
 }
 
