@@ -11,7 +11,7 @@ include/ark_hip.h; this package holds no arithmetic and no CPU fallback.
 """
 from . import curves  # noqa: F401
 from ._lib import ArkHipError, LIB_PATH, lib  # noqa: F401
-from .msm import (ChunkedPippenger, HashMapPippenger, MsmJob, MsmLengthMismatch, PreparedBases, into_affine,  # noqa: F401
+from .msm import (BatchMulPreprocessing, batch_mul, ChunkedPippenger, HashMapPippenger, MsmJob, MsmLengthMismatch, PreparedBases, into_affine,  # noqa: F401
                   msm, msm_bigint, msm_bigint_async, msm_bigint_multi, msm_chunks, msm_u1, msm_u8, msm_u16, msm_u32,
                   msm_u64, msm_unchecked, normalize_batch, sum_projective)
 from .domain import Radix2EvaluationDomain  # noqa: F401

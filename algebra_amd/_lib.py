@@ -58,6 +58,10 @@ SYMBOLS = {
     "ark_hip_msm_sw_multi": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ark_hip_msm_sw_multi_device": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
+    "ark_hip_batch_mul_table_new": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ark_hip_batch_mul_table_free": (C.c_int, [C.c_void_p]),
+    "ark_hip_batch_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ark_hip_batch_mul_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ark_hip_fft_in_place_degree_aware": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_size_t]),
     "ark_hip_fft_in_place_degree_aware_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_size_t]),
     "ark_hip_shutdown": (None, []),

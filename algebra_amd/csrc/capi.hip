@@ -6,6 +6,7 @@
 #include <vector>
 #include "msm.cuh"
 #include "fft.cuh"
+#include "batchmul.cuh"
 #include "internal.hpp"
 #include "curve_consts.hpp"
 
@@ -145,6 +146,16 @@ int msm_finish_dispatch(int curve, MsmWorkspace& ws, int slot, uint64_t* out, Ms
 }
 int msm_prepare_dispatch(int curve, const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, hipStream_t st) {
 #define X(NAME) msm_prepare_##NAME(d_bases, n, pl, d_table, st)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int batchmul_build_dispatch(int curve, const void* d_base, void* d_scratch, void* d_table, hipStream_t st) {
+#define X(NAME) batchmul_build_##NAME(d_base, d_scratch, d_table, st)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int batchmul_run_dispatch(int curve, const void* d_table, const void* d_scalars, size_t n, int mont, void* d_out, hipStream_t st) {
+#define X(NAME) batchmul_run_##NAME(d_table, d_scalars, n, mont, d_out, st)
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
@@ -366,6 +377,11 @@ struct PreparedBases {   // ark_hip_msm_bases: a fixed base set with its table o
   size_t n = 0;
   MsmPlan plan{};
   DevBuf table;          // [plan.W][n] affine points
+};
+struct BatchMulTable {   // ark_hip_batch_mul_table: multiples of one base (batchmul.cuh)
+  int curve = -1;
+  int logical = -1;
+  DevBuf table;
 };
 struct MsmJobHandle {    // ark_hip_msm_job
   int logical;
@@ -804,6 +820,72 @@ int ark_hip_msm_sw_multi(int curve, int n_gpus, const uint64_t* bases, const uin
   for (int g = 0; g < n_gpus; g++)
     if (rcs[(size_t)g]) return rcs[(size_t)g];
   return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);
+}
+
+// ---- fixed-base batch multiplication (ScalarMul::batch_mul / BatchMulPreprocessing, ec/src/scalar_mul/mod.rs:104-251) ----
+int ark_hip_batch_mul_table_new(int curve, const uint64_t* base_xyz, size_t num_scalars, ark_hip_batch_mul_table** out) {
+  (void)num_scalars;  // the reference sizes its window from it (:222-228); the device table has a fixed geometry
+  if (curve < 0 || curve > 4 || !base_xyz || !out) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  const size_t ab = (size_t)CURVES[curve].fe_words * 16;
+  uint64_t aff[24];
+  int rc = ark_hip_sw_into_affine(curve, base_xyz, 1, aff);
+  if (rc) return rc;
+  BatchMulTable* t = new BatchMulTable();
+  t->curve = curve;
+  t->logical = c->logical;
+  const size_t entries = (size_t)BATCHMUL_OUTER << BATCHMUL_WINDOW;
+  if (t->table.ensure(entries * ab) || c->stage_c.ensure(ab + (size_t)BATCHMUL_OUTER * 2 * ab)) {
+    delete t;
+    return ARK_HIP_ERR_NOMEM;
+  }
+  rc = hipMemcpyAsync(c->stage_c.p, aff, ab, hipMemcpyHostToDevice, c->stream) == hipSuccess ? 0 : -1000;
+  if (rc == 0) rc = batchmul_build_dispatch(curve, c->stage_c.p, (char*)c->stage_c.p + ab, t->table.p, c->stream);
+  if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = -1000;
+  if (rc) {
+    t->table.release();
+    delete t;
+    return rc;
+  }
+  *out = (ark_hip_batch_mul_table*)t;
+  return 0;
+}
+int ark_hip_batch_mul_table_free(ark_hip_batch_mul_table* table) {
+  if (!table) return 0;
+  BatchMulTable* t = (BatchMulTable*)table;
+  Scope sc;
+  if (int rc = sc.enter(t->logical)) return rc;
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
+  t->table.release();
+  delete t;
+  return 0;
+}
+int ark_hip_batch_mul_device(const ark_hip_batch_mul_table* table, const void* d_scalars, size_t n, int mont, void* d_out_xy) {
+  if (!table || (n && (!d_scalars || !d_out_xy))) return ARK_HIP_ERR_ARG;
+  const BatchMulTable* t = (const BatchMulTable*)table;
+  Scope sc;
+  if (int rc = sc.enter(t->logical)) return rc;
+  int rc = batchmul_run_dispatch(t->curve, t->table.p, d_scalars, n, mont, d_out_xy, sc.c->stream);
+  if (rc) return rc;
+  ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
+  return 0;
+}
+int ark_hip_batch_mul(const ark_hip_batch_mul_table* table, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xy) {
+  if (!table || (n && (!scalars || !out_xy))) return ARK_HIP_ERR_ARG;
+  const BatchMulTable* t = (const BatchMulTable*)table;
+  Scope sc;
+  if (int rc = sc.enter(t->logical)) return rc;
+  Context* c = sc.c;
+  const size_t ab = (size_t)CURVES[t->curve].fe_words * 16;
+  if (n == 0) return 0;
+  if (c->stage_a.ensure(n * 32) || c->stage_b.ensure(n * ab)) return ARK_HIP_ERR_NOMEM;
+  ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  int rc = batchmul_run_dispatch(t->curve, t->table.p, c->stage_a.p, n, mont, c->stage_b.p, c->stream);
+  if (rc) return rc;
+  ARK_HIP_TRY(hipMemcpyAsync(out_xy, c->stage_b.p, n * ab, hipMemcpyDeviceToHost, c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 // ---- radix-2 domain / FFT --------------------------------------------------------------------------------

@@ -203,6 +203,40 @@ ARK_HD void xyzz_add(XYZZ<F>& acc, const XYZZ<F>& b) {
   acc.zzz = F::mul(F::mul(acc.zzz, b.zzz), ppp);
 }
 
+// The same full addition on relaxed residues (values in [0, 2p), infinity the exact (1, 1, 0, 0)): the bucket
+// reduction.  Both operands may be relaxed; the rare doubling branch goes through canonical arithmetic.
+template <class F>
+ARK_HD void xyzz_add_relaxed(XYZZ<F>& acc, const XYZZ<F>& b) {
+  const bool bz = b.is_zero();   // evaluated unconditionally (pair-wide exchanges over Fp2Half)
+  const bool az = acc.is_zero();
+  if (bz) return;
+  if (az) { acc = b; return; }
+  F u1 = F::mul_r(acc.x, b.zz);
+  F u2 = F::mul_r(b.x, acc.zz);
+  F s1 = F::mul_r(acc.y, b.zzz);
+  F s2 = F::mul_r(b.y, acc.zzz);
+  F p = F::sub_r(u2, u1);
+  F r = F::sub_r(s2, s1);
+  const bool pz = p.is_zero_mod_p();
+  const bool rz = r.is_zero_mod_p();
+  if (pz) {
+    if (rz) acc = xyzz_dbl<F>(xyzz_canonical<F>(acc));
+    else acc = XYZZ<F>::zero();
+    return;
+  }
+  F pp = F::mul_r(p, p);
+  F ppp = F::mul_r(p, pp);
+  F q = F::mul_r(u1, pp);
+  F x3 = F::sub_r(F::sub_r(F::mul_r(r, r), ppp), F::dbl_r(q));
+  F y3;
+  if constexpr (F::FUSED_Y3) y3 = F::sop2_r(r, F::sub_r(q, x3), F::neg_r(s1), ppp);
+  else y3 = F::sub_r(F::mul_r(r, F::sub_r(q, x3)), F::mul_r(s1, ppp));
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = F::mul_r(F::mul_r(acc.zz, b.zz), pp);
+  acc.zzz = F::mul_r(F::mul_r(acc.zzz, b.zzz), ppp);
+}
+
 // XYZZ -> Jacobian (X*ZZ, Y*ZZZ, ZZ): valid because ZZ^3 = ZZZ^2   bucket.rs:389-397
 template <class F>
 ARK_HD Jac<F> xyzz_to_jac(const XYZZ<F>& p) {

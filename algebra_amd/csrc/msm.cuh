@@ -434,8 +434,43 @@ static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* _
   for (u32 q = 0; q < k; q++) items[first + q] = make_uint2(g, q);
 }
 
-// one WAVE per chunk: 64 lanes stride over the chunk's entries, then a 6-step LDS tree inside the wave's own
-// LDS region.  All waves of a workgroup run the same number of rounds so the barriers stay uniform.
+// Point additions of the reduction / heavy-run kernels on the accumulate field C::FA: relaxed residues where the
+// curve's field allows it, one element per lane (Fp) or per lane PAIR (Fp2Half; index arithmetic below is in "slots"
+// = lanes / LANES, and every branch is uniform over a pair).
+template <class C>
+struct AccOps {
+  typedef typename C::FA F;
+  typedef XYZZ<F> Pt;
+  static constexpr u32 LANES = F::LANES;
+  ARK_DEV static void madd(Pt& acc, const F& x, const F& y) {
+    if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, x, y);
+    else xyzz_madd<F>(acc, x, y);
+  }
+  ARK_DEV static void add(Pt& acc, const Pt& b) {
+    if constexpr (C::RELAXED_A) xyzz_add_relaxed<F>(acc, b);
+    else xyzz_add<F>(acc, b);
+  }
+  ARK_DEV static Pt fin(const Pt& a) {  // canonical form for memory
+    if constexpr (C::RELAXED_A) return xyzz_canonical<F>(a);
+    else return a;
+  }
+  // sum over the `width` slots of an LDS array of per-slot partials (width a power of two); result in slot 0's acc
+  ARK_DEV static void tree(Pt& acc, char* sh, u32 slot, u32 width) {
+    acc.store(sh + (size_t)slot * Pt::BYTES);
+    __syncthreads();
+    for (u32 o = width / 2; o > 0; o >>= 1) {
+      if (slot < o) {
+        Pt other = Pt::load(sh + (size_t)(slot + o) * Pt::BYTES);
+        add(acc, other);
+        acc.store(sh + (size_t)slot * Pt::BYTES);
+      }
+      __syncthreads();
+    }
+  }
+};
+
+// one WAVE per chunk: its slots stride over the chunk's entries, then an LDS tree inside the wave's own LDS region.
+// All waves of a workgroup run the same number of rounds so the barriers stay uniform.
 template <class C>
 __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __restrict__ bases,
                                                                 const u32* __restrict__ sorted,
@@ -443,11 +478,13 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
                                                                 const u32* __restrict__ ctr,
                                                                 const uint2* __restrict__ items, size_t wstride, int B,
                                                                 char* __restrict__ partials) {
-  typedef typename C::F F;
-  typedef XYZZ<F> Pt;
+  typedef AccOps<C> Ops;
+  typedef typename Ops::F F;
+  typedef typename Ops::Pt Pt;
+  constexpr u32 NS = 64 / Ops::LANES;  // slots per wave
   extern __shared__ uint4 heavy_lds[];
-  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-  char* sh = (char*)heavy_lds + (size_t)wave * 64 * Pt::BYTES;
+  const u32 wave = threadIdx.x >> 6, slot = (threadIdx.x & 63) / Ops::LANES, wpb = blockDim.x >> 6;
+  char* sh = (char*)heavy_lds + (size_t)wave * NS * Pt::BYTES;
   const u32 nitems = ctr[0];
   for (u32 first = blockIdx.x * wpb; first < nitems; first += gridDim.x * wpb) {
     const u32 item = first + wave;
@@ -459,83 +496,66 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
       u32 hi = offsets[it.x + 1];
       if (hi > lo + HEAVY_CHUNK) hi = lo + HEAVY_CHUNK;
       const char* wb = bases + (size_t)(it.x >> B) * wstride * Affine<F>::BYTES;  // prepared set: the window's table
-      for (u32 j = lo + lane; j < hi; j += 64) {
+      for (u32 j = lo + slot; j < hi; j += NS) {
         u32 e = sorted[j];
         Affine<F> p = Affine<F>::load(wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
         if (!p.is_zero()) {
           F y = F::cond_neg(p.y, (e >> 31) != 0);
-          xyzz_madd<F>(acc, p.x, y);
+          Ops::madd(acc, p.x, y);
         }
       }
     }
-    acc.store(sh + (size_t)lane * Pt::BYTES);
-    __syncthreads();
-    for (u32 o = 32; o > 0; o >>= 1) {
-      if (lane < o) {
-        Pt other = Pt::load(sh + (size_t)(lane + o) * Pt::BYTES);
-        xyzz_add<F>(acc, other);
-        acc.store(sh + (size_t)lane * Pt::BYTES);
-      }
-      __syncthreads();
-    }
-    if (live && lane == 0) acc.store(partials + (size_t)item * Pt::BYTES);
+    Ops::tree(acc, sh, slot, NS);
+    if (live && slot == 0) Ops::fin(acc).store(partials + (size_t)item * Pt::BYTES);
     __syncthreads();
   }
 }
 
-// one wave per heavy bucket: lanes stride over its chunk partials, then a 6-step LDS tree
+// one wave per heavy bucket: its slots stride over the chunk partials, then an LDS tree
 // SHARED (prepared base set): the result goes to hfinal[slot] and its index into sorted[run start], where the lane
-// that owns the bucket picks it up (msm_accumulate_shared_kernel); else straight into the (window, bucket) cell.
+// that owns the bucket picks it up (msm_apply_heavy_kernel); else straight into the (window, bucket) cell.
 template <class C, bool SHARED>
 __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __restrict__ ctr,
                                                                const HeavyEntry* __restrict__ list,
                                                                const char* __restrict__ partials, int HB, int LB,
                                                                const u32* __restrict__ offsets, u32* __restrict__ sorted,
                                                                char* __restrict__ buckets) {
-  typedef typename C::F F;
-  typedef XYZZ<F> Pt;
+  typedef AccOps<C> Ops;
+  typedef typename Ops::Pt Pt;
+  constexpr u32 NS = 64 / Ops::LANES;
   extern __shared__ uint4 heavy_lds[];
   char* sh = (char*)heavy_lds;
-  const u32 slot = blockIdx.x, lane = threadIdx.x;
-  if (slot >= ctr[1]) return;  // uniform for the whole workgroup
-  HeavyEntry h = list[slot];
+  const u32 hslot = blockIdx.x, slot = threadIdx.x / Ops::LANES;
+  if (hslot >= ctr[1]) return;  // uniform for the whole workgroup
+  HeavyEntry h = list[hslot];
   Pt acc = Pt::zero();
-  for (u32 q = lane; q < h.items; q += 64) {
+  for (u32 q = slot; q < h.items; q += NS) {
     Pt x = Pt::load(partials + (size_t)(h.first_item + q) * Pt::BYTES);
-    xyzz_add<F>(acc, x);
+    Ops::add(acc, x);
   }
-  acc.store(sh + (size_t)lane * Pt::BYTES);
-  __syncthreads();
-  for (u32 o = 32; o > 0; o >>= 1) {
-    if (lane < o) {
-      Pt other = Pt::load(sh + (size_t)(lane + o) * Pt::BYTES);
-      xyzz_add<F>(acc, other);
-      acc.store(sh + (size_t)lane * Pt::BYTES);
-    }
-    __syncthreads();
-  }
-  if (lane == 0) {
+  Ops::tree(acc, sh, slot, NS);
+  if (slot == 0) {
     if constexpr (SHARED) {
-      acc.store(buckets + (size_t)slot * Pt::BYTES);  // `buckets` is the hfinal array here
-      sorted[offsets[h.bucket]] = slot;
+      Ops::fin(acc).store(buckets + (size_t)hslot * Pt::BYTES);  // `buckets` is the hfinal array here
+      if (threadIdx.x == 0) sorted[offsets[h.bucket]] = hslot;
     } else {
-      acc.store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
+      Ops::fin(acc).store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
     }
   }
 }
 
 // Prepared base set: adds the heavy runs' sums into their (shared) buckets after msm_accumulate_shared_kernel.  One
-// lane per heavy run (w, s); the lowest heavy window of bucket slot s owns the bucket and adds every heavy run of
-// that slot (their partial's index sits in sorted[run start]), so no two lanes touch one bucket.
+// slot per heavy run (w, s); the lowest heavy window of bucket slot s owns the bucket and adds every heavy run of
+// that slot (their partial's index sits in sorted[run start]), so no two slots touch one bucket.
 template <class C>
 __global__ void __launch_bounds__(64) msm_apply_heavy_kernel(const u32* __restrict__ ctr, const HeavyEntry* __restrict__ list,
                                                              const u32* __restrict__ offsets,
                                                              const u32* __restrict__ sorted,
                                                              const char* __restrict__ hfinal, int W, int B,
                                                              u32 heavy_thresh, int HB, int LB, char* __restrict__ buckets) {
-  typedef typename C::F F;
-  typedef XYZZ<F> Pt;
-  const u32 h = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef AccOps<C> Ops;
+  typedef typename Ops::Pt Pt;
+  const u32 h = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LANES;
   if (h >= ctr[1]) return;
   const u32 g = list[h].bucket;
   const u32 w0 = g >> B, s = g & ((1u << B) - 1u);
@@ -550,50 +570,32 @@ __global__ void __launch_bounds__(64) msm_apply_heavy_kernel(const u32* __restri
     const u32 a = offsets[gg];
     if (offsets[gg + 1] - a > heavy_thresh) {
       Pt x = Pt::load(hfinal + (size_t)sorted[a] * Pt::BYTES);
-      xyzz_add<F>(acc, x);
+      Ops::add(acc, x);
     }
   }
-  acc.store(cell);
+  Ops::fin(acc).store(cell);
 }
 
-// ---- K5: one level of the bucket reduction ---------------------------------------------------------
-// Input: per window m_in points X[0..m_in) (level 0: the buckets, weight of X[r] is r+1).
-// Chunk j of L consecutive inputs -> S_j = sum X, A_j = sum weight_in_chunk * X  (+ carried A's).
-//   level 0 :  A_j = sum_{r<L} (r+1) X[jL+r]
-//   level >0:  A_j = sum_{r<L} A_in[jL+r] + 2^log2M * sum_{r<L} r * S_in[jL+r]
-// so that  sum_k k*B_k = sum_j A_j + (M*L) * sum_j j*S_j  holds level after level; at m_out = 1 the
-// window sum is A_0.
+// ---- K5a: level 0 of the bucket reduction --------------------------------------------------------------
+// Per window the buckets X[0..mwin) carry weights 1..mwin.  A slot folds the chunk of L consecutive buckets
+// [tL, (t+1)L) with a running sum:  S_t = sum_r X[tL+r],  A_t = sum_r (r+1) X[tL+r], so that
+//   sum_k k B_k = sum_t A_t + L * sum_t t S_t          (parallel form of mod.rs:478-484)
 template <class C>
-__global__ void __launch_bounds__(128) msm_reduce_level_kernel(const char* __restrict__ inS,
-                                                               const char* __restrict__ inA, u32 L, int log2M,
-                                                               u32 total_out, char* __restrict__ outS,
-                                                               char* __restrict__ outA) {
-  typedef typename C::F F;
-  typedef XYZZ<F> Pt;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(128, 2) msm_reduce_level_kernel(const char* __restrict__ in, u32 L, u32 total_out,
+                                                               char* __restrict__ outS, char* __restrict__ outA) {
+  typedef AccOps<C> Ops;
+  typedef typename Ops::Pt Pt;
+  const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LANES;
   if (t >= total_out) return;
-  size_t base = (size_t)t * L;
+  const size_t base = (size_t)t * L;
   Pt running = Pt::zero(), acc = Pt::zero();
-  if (inA == nullptr) {
-    for (u32 r = L; r-- > 0;) {
-      Pt x = Pt::load(inS + (base + r) * Pt::BYTES);
-      xyzz_add<F>(running, x);
-      xyzz_add<F>(acc, running);
-    }
-  } else {
-    for (u32 r = L; r-- > 0;) {
-      xyzz_add<F>(acc, running);
-      Pt x = Pt::load(inS + (base + r) * Pt::BYTES);
-      xyzz_add<F>(running, x);
-    }
-    for (int k = 0; k < log2M; k++) acc = xyzz_dbl<F>(acc);
-    for (u32 r = 0; r < L; r++) {
-      Pt x = Pt::load(inA + (base + r) * Pt::BYTES);
-      xyzz_add<F>(acc, x);
-    }
+  for (u32 r = L; r-- > 0;) {
+    Pt x = Pt::load(in + (base + r) * Pt::BYTES);
+    Ops::add(running, x);
+    Ops::add(acc, running);
   }
-  running.store(outS + (size_t)t * Pt::BYTES);
-  acc.store(outA + (size_t)t * Pt::BYTES);
+  Ops::fin(running).store(outS + (size_t)t * Pt::BYTES);
+  Ops::fin(acc).store(outA + (size_t)t * Pt::BYTES);
 }
 
 // ---- K5b: the rest of the reduction, bit-sliced -------------------------------------------------------
@@ -606,64 +608,47 @@ __global__ void __launch_bounds__(128) msm_reduce_level_kernel(const char* __res
 template <class C>
 __global__ void __launch_bounds__(256) msm_reduce_bits_kernel(const char* __restrict__ S, const char* __restrict__ A,
                                                               u32 m, int nbits, u32 chunk, char* __restrict__ partial) {
-  typedef typename C::F F;
-  typedef XYZZ<F> Pt;
+  typedef AccOps<C> Ops;
+  typedef typename Ops::Pt Pt;
   extern __shared__ uint4 reduce_lds[];
   char* sh = (char*)reduce_lds;
   const u32 q = blockIdx.y, w = blockIdx.z, ch = blockIdx.x;
+  const u32 slot = threadIdx.x / Ops::LANES, nslots = blockDim.x / Ops::LANES;
   const bool plain = (int)q == nbits;
   const char* src = plain ? A : S;
   Pt acc = Pt::zero();
-  for (u32 e = threadIdx.x; e < chunk; e += blockDim.x) {
+  for (u32 e = slot; e < chunk; e += nslots) {
     u32 j = ch * chunk + e;
     if (j < m && (plain || ((j >> q) & 1u))) {
       Pt x = Pt::load(src + ((size_t)w * m + j) * Pt::BYTES);
-      xyzz_add<F>(acc, x);
+      Ops::add(acc, x);
     }
   }
-  acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
-  __syncthreads();
-  for (u32 o = blockDim.x / 2; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      Pt other = Pt::load(sh + (size_t)(threadIdx.x + o) * Pt::BYTES);
-      xyzz_add<F>(acc, other);
-      acc.store(sh + (size_t)threadIdx.x * Pt::BYTES);
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-    acc.store(partial + (((size_t)w * gridDim.y + q) * gridDim.x + ch) * Pt::BYTES);
+  Ops::tree(acc, sh, slot, nslots);
+  if (slot == 0) Ops::fin(acc).store(partial + (((size_t)w * gridDim.y + q) * gridDim.x + ch) * Pt::BYTES);
 }
 
-// sums the `nchunks` chunk partials of every (window, quantity) pair: one wave per pair, lanes stride over the
-// partials, then a 6-step LDS tree (a single lane walking 16-32 partials serially cost ~0.5 ms of pure latency)
+// sums the `nchunks` chunk partials of every (window, quantity) pair: one wave per pair, its slots stride over the
+// partials, then an LDS tree (a single lane walking 16-32 partials serially cost ~0.5 ms of pure latency)
 template <class C>
 __global__ void __launch_bounds__(64) msm_sum_chunks_kernel(const char* __restrict__ partial, u32 npairs, u32 nchunks,
                                                             char* __restrict__ out) {
-  typedef typename C::F F;
-  typedef XYZZ<F> Pt;
+  typedef AccOps<C> Ops;
+  typedef typename Ops::Pt Pt;
+  constexpr u32 NS = 64 / Ops::LANES;
   extern __shared__ uint4 chunk_lds[];
   char* sh = (char*)chunk_lds;
-  const u32 t = blockIdx.x, lane = threadIdx.x;
+  const u32 t = blockIdx.x, slot = threadIdx.x / Ops::LANES;
   if (t >= npairs) return;
   Pt acc = Pt::zero();
-  for (u32 k = lane; k < nchunks; k += 64) {
+  for (u32 k = slot; k < nchunks; k += NS) {
     Pt x = Pt::load(partial + ((size_t)t * nchunks + k) * Pt::BYTES);
-    xyzz_add<F>(acc, x);
+    Ops::add(acc, x);
   }
   u32 width = 1;
-  while (width < nchunks && width < 64) width <<= 1;
-  acc.store(sh + (size_t)lane * Pt::BYTES);
-  __syncthreads();
-  for (u32 o = width / 2; o > 0; o >>= 1) {
-    if (lane < o) {
-      Pt other = Pt::load(sh + (size_t)(lane + o) * Pt::BYTES);
-      xyzz_add<F>(acc, other);
-      acc.store(sh + (size_t)lane * Pt::BYTES);
-    }
-    __syncthreads();
-  }
-  if (lane == 0) acc.store(out + (size_t)t * Pt::BYTES);
+  while (width < nchunks && width < NS) width <<= 1;
+  Ops::tree(acc, sh, slot, width);
+  if (slot == 0) Ops::fin(acc).store(out + (size_t)t * Pt::BYTES);
 }
 
 // ---- host-side plan / workspace -----------------------------------------------------------------
@@ -952,10 +937,11 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   // throughput-bound duration (entries / 5.5e9 per s).  At 2^24 x 13 windows that is ~1400 entries, so the
   // sparse top window (1024 per bucket) still rides along; skewed scalar distributions do not.
   const size_t total_entries = (size_t)n * W;
-  size_t mean_load = total_entries / nbk;
+  size_t mean_load = total_entries / nbk;        // per lane (a lane of a prepared set walks W runs)
+  const size_t mean_run = total_entries / nb;    // per (window, bucket) run: what `heavy` is judged against
   u32 heavy_thresh = (u32)(total_entries / 154000);
   if (heavy_thresh < 64) heavy_thresh = 64;
-  if (heavy_thresh < 4 * mean_load) heavy_thresh = (u32)(4 * mean_load);
+  if (heavy_thresh < 4 * mean_run) heavy_thresh = (u32)(4 * mean_run);
   if (const char* hv = getenv("ARK_HIP_MSM_HEAVY")) {
     if (atoi(hv) >= 64) heavy_thresh = (u32)atoi(hv);
   }
@@ -1016,16 +1002,17 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     u32* hctr = (u32*)ws.hctr.p;
     hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
                        heavy_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
-    const u32 hthreads = Pt::BYTES > 192 ? 128 : 256;  // one 64-lane LDS tree per wave, 48 KiB per workgroup
-    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), hthreads * Pt::BYTES, stream,
+    constexpr u32 LN = C::FA::LANES;                        // lanes per element of the accumulate field
+    const u32 hthreads = Pt::BYTES * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
+    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * Pt::BYTES, stream,
                        (const char*)d_points, sorted, offsets, hctr, (const uint2*)ws.hitems.p, wstride, Bbits,
                        (char*)ws.hpart.p);
     if (pl.shared)
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3((u32)max_heavy), dim3(64), 64 * Pt::BYTES, stream, hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3((u32)max_heavy), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
                          (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
                          (char*)ws.hfinal.p);
     else
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3((u32)max_heavy), dim3(64), 64 * Pt::BYTES, stream, hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3((u32)max_heavy), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
                          (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
                          (char*)ws.buckets.p);
   }
@@ -1034,7 +1021,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
                        (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, heavy_thresh, HB, LB,
                        (char*)ws.buckets.p);
-    hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3((u32)((max_heavy + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3((u32)((max_heavy * C::FA::LANES + 63) / 64)), dim3(64), 0, stream,
                        (const u32*)ws.hctr.p, (const HeavyEntry*)ws.hlist.p, offsets, sorted, (const char*)ws.hfinal.p, W,
                        Bbits, heavy_thresh, HB, LB, (char*)ws.buckets.p);
   }
@@ -1043,17 +1030,17 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                        (const char*)d_points, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
 
-  hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * Wr + 127) / 128)), dim3(128), 0, stream,
-                     (const char*)ws.buckets.p, (const char*)nullptr, L0, 0, (u32)(m * Wr), (char*)ws.lvlS[0].p,
-                     (char*)ws.lvlA[0].p);
+  constexpr u32 LNr = C::FA::LANES;
+  hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * Wr * LNr + 127) / 128)), dim3(128), 0, stream,
+                     (const char*)ws.buckets.p, L0, (u32)(m * Wr), (char*)ws.lvlS[0].p, (char*)ws.lvlA[0].p);
   {
-    const u32 rthreads = Pt::BYTES > 192 ? 128 : 256;  // LDS tree within 48 KiB
-    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, Wr), dim3(rthreads), rthreads * Pt::BYTES, stream,
+    const u32 rthreads = Pt::BYTES * (256 / LNr) > 49152 ? 128 : 256;  // LDS tree within 48 KiB
+    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, Wr), dim3(rthreads), (rthreads / LNr) * Pt::BYTES, stream,
                        (const char*)ws.lvlS[0].p, (const char*)ws.lvlA[0].p, (u32)m, nbits, chunk, (char*)ws.lvlS[1].p);
   }
   const char* d_sums = (const char*)ws.lvlS[1].p;
   if (nchunks > 1) {
-    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)npairs), dim3(64), 64 * Pt::BYTES, stream,
+    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)npairs), dim3(64), (64 / LNr) * Pt::BYTES, stream,
                        (const char*)ws.lvlS[1].p, (u32)npairs, nchunks, (char*)ws.lvlA[1].p);
     d_sums = (const char*)ws.lvlA[1].p;
   }

@@ -316,6 +316,57 @@ def msm_bigint_multi(curve, n_gpus, bases, bigints, montgomery=False):
     return out
 
 
+class BatchMulPreprocessing:
+    """Host mirror of ark_ec::scalar_mul::BatchMulPreprocessing (ec/src/scalar_mul/mod.rs:156-251): the table of
+    multiples of one group element lives on the GPU; batch_mul(v) returns v[i] * base as Affine points."""
+
+    def __init__(self, curve, base, num_scalars=0):
+        """BatchMulPreprocessing::new(base, num_scalars); base: Projective limbs (x|y|z)."""
+        self.curve = cv.curve_id(curve)
+        b, bp = _host(base)
+        self._h = C.c_void_p()
+        check(lib().ark_hip_batch_mul_table_new(self.curve, bp, int(num_scalars), C.byref(self._h)),
+              "ark_hip_batch_mul_table_new")
+
+    def batch_mul(self, scalars, montgomery=True):
+        """v: Fr elements (Montgomery) as in the reference; montgomery=False for canonical BigInt<4>."""
+        L = lib()
+        if _is_torch(scalars):
+            import torch
+            assert scalars.is_cuda and scalars.is_contiguous()
+            n = _rows(scalars, cv.SCALAR_WORDS)
+            out = torch.empty((n, cv.affine_words(self.curve)), dtype=torch.int64, device=scalars.device)
+            torch.cuda.current_stream().synchronize()
+            check(L.ark_hip_batch_mul_device(self._h, scalars.data_ptr(), n, int(montgomery), out.data_ptr()),
+                  "ark_hip_batch_mul_device")
+            return out
+        s, sp = _host(scalars)
+        n = s.size // cv.SCALAR_WORDS
+        out = np.zeros((n, cv.affine_words(self.curve)), dtype=np.uint64)
+        check(L.ark_hip_batch_mul(self._h, sp, n, int(montgomery), out.ctypes.data_as(C.c_void_p)), "ark_hip_batch_mul")
+        return out
+
+    def free(self):
+        if self._h is not None and self._h.value:
+            check(lib().ark_hip_batch_mul_table_free(self._h), "ark_hip_batch_mul_table_free")
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def batch_mul(curve, base, scalars, montgomery=True):
+    """ScalarMul::batch_mul (ec/src/scalar_mul/mod.rs:104-107): table + batch_mul_with_preprocessing."""
+    t = BatchMulPreprocessing(curve, base, _rows(scalars, cv.SCALAR_WORDS))
+    try:
+        return t.batch_mul(scalars, montgomery)
+    finally:
+        t.free()
+
+
 def _small_to_bigint(values, signed_ok=False):
     v = np.asarray(values)
     if v.dtype == np.bool_:

@@ -65,10 +65,10 @@ def pmc_traffic(kernel, log_n):
                 d = json.load(f)
             e = d.get(kernel)
             if e and e.get("log_n") == log_n:
-                return {"hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "source": "profiles/" + name}
+                return e.get("hbm_bytes_per_launch"), "profiles/" + name
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def main():
@@ -287,7 +287,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fft_pass_kernel (x%d passes)" % int(ft[1]),
                          "achieved": 64.0 * nf / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": 64.0 * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic("fft_pass_kernel", kf)},
+                         "traffic": pmc_traffic("fft_pass_kernel", kf)[0],
+                         "traffic_source": pmc_traffic("fft_pass_kernel", kf)[1]},
         }
 
     # ---- sharded FFT leg (N > 1): 2^fft_log_n coefficients per GPU, all-to-all exchanges over RCCL ----------
@@ -374,7 +375,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic("msm_accumulate_%skernel" % ("" if args.no_prepare else "shared_"),
-                                                int(np.log2(n))),
+                                                int(np.log2(n)))[0],
+                         "traffic_source": pmc_traffic("msm_accumulate_%skernel" % ("" if args.no_prepare else "shared_"),
+                                                       int(np.log2(n)))[1],
                          "alu": {"what": "v_mad_u64_u32 lane-ops/s issued by the mixed additions the accumulate kernel "
                                          "executes (%d per addition: 8 Montgomery products + one two-product sum) vs the "
                                          "instruction's measured issue rate on this chip" % MADS_PER_MIXED_ADD,

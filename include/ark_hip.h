@@ -139,6 +139,20 @@ int ark_hip_msm_sw_multi_device(int curve, int n_gpus, const void* const* d_base
 int ark_hip_msm_set_timing(int enable);
 int ark_hip_msm_last_timing(double out[8]);
 
+/* ---- fixed-base batch multiplication ----
+ * ScalarMul::batch_mul / BatchMulPreprocessing (ec/src/scalar_mul/mod.rs:104-251): out[i] = v[i] * g for ONE group element
+ * g, results affine (the reference's Vec<MulBase>).  table_new = BatchMulPreprocessing::new(base, num_scalars): builds the
+ * table of multiples on the device (base_xyz: Projective; num_scalars only sizes the reference's window and is accepted
+ * for signature parity); batch_mul = BatchMulPreprocessing::batch_mul.  Scalars: n x 4 limbs, Fr (Montgomery) when
+ * scalars_are_montgomery != 0 as in the reference, or canonical BigInt<4> (any 256-bit value is multiplied exactly). */
+typedef struct ark_hip_batch_mul_table ark_hip_batch_mul_table;
+int ark_hip_batch_mul_table_new(int curve, const uint64_t* base_xyz, size_t num_scalars, ark_hip_batch_mul_table** out);
+int ark_hip_batch_mul_table_free(ark_hip_batch_mul_table* table);
+int ark_hip_batch_mul(const ark_hip_batch_mul_table* table, const uint64_t* scalars, size_t n, int scalars_are_montgomery,
+                      uint64_t* out_xy);
+int ark_hip_batch_mul_device(const ark_hip_batch_mul_table* table, const void* d_scalars, size_t n,
+                             int scalars_are_montgomery, void* d_out_xy);
+
 /* ---- host-side group helpers (run on the CPU; tiny) ----
  * Sum of n Projective points: the multi-GPU combine of per-rank partial MSMs (the reference's
  * chunk sum, ec/src/scalar_mul/variable_base/mod.rs:542-557).  The reduction operator is

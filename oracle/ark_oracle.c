@@ -322,6 +322,17 @@ int ark_oracle_scalar_mul(int curve, const u64 *base_xy, const u64 *scalar4, u64
     return 0;
 }
 
+/* ScalarMul::batch_mul (ec/src/scalar_mul/mod.rs:104-107): out[i] = scalars[i] * base, affine */
+int ark_oracle_batch_mul(int curve, const u64 *base_jac, const u64 *scalars, size_t n, u64 *out_xy) {
+    ark_curve_ctx C;
+    int fw = get_curve(curve, &C);
+    if (fw < 0) return -1;
+    const int bits = ARK_FIELDS[ARK_CURVES[curve].scalar_field].bits;
+    BY_FW(fw, g4_batch_mul(&C, out_xy, base_jac, scalars, n, bits), g6_batch_mul(&C, out_xy, base_jac, scalars, n, bits),
+          g12_batch_mul(&C, out_xy, base_jac, scalars, n, bits));
+    return 0;
+}
+
 /* y^2 == x^3 + b (a = 0); identity (0,0) counts as on-curve  (affine.rs is_on_curve) */
 int ark_oracle_is_on_curve(int curve, const u64 *xy) {
     ark_curve_ctx C;

@@ -40,6 +40,9 @@ int ark_oracle_point_op(int curve, int kind, uint64_t* acc, const uint64_t* othe
 int ark_oracle_to_affine(int curve, const uint64_t* jac, uint64_t* out_xy, size_t n);
 int ark_oracle_scalar_mul(int curve, const uint64_t* base_xy, const uint64_t* scalar4, uint64_t* out_jac);
 int ark_oracle_is_on_curve(int curve, const uint64_t* xy);
+/* ScalarMul::batch_mul through BatchMulPreprocessing (ec/src/scalar_mul/mod.rs:104-251): out[i] = scalars[i] * base
+ * as affine points; scalars = n x 4 canonical limbs; base = Projective x|y|z */
+int ark_oracle_batch_mul(int curve, const uint64_t* base_jac, const uint64_t* scalars, size_t n, uint64_t* out_xy);
 
 /* MSM. variant: 0 naive sum of double-and-add, 1 msm_bigint_wnaf (threads/2 chunks x 2 threads),
  * 2 msm_signed (full reference dispatch). scalars = n x 4 canonical limbs. out = Jacobian x|y|z. */

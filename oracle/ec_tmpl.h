@@ -605,6 +605,53 @@ static void ECN(normalize_batch)(const ark_curve_ctx *C, u64 *out_aff, const u64
     free(prod);
 }
 
+/* ec/src/scalar_mul/mod.rs:156-245 BatchMulPreprocessing::new(base, num_scalars) + batch_mul: the table of
+ * multiples inner * 2^(window*outer) * base (window = compute_window_size, :222-228), windowed_mul (:235-251) per scalar
+ * (canonical bigints here: the reference's into_bigint() is the caller's), batch_convert_to_mul_base at the end. */
+static void ECN(batch_mul)(const ark_curve_ctx *C, u64 *out_aff, const u64 *base_jac, const u64 *scalars, size_t n,
+                           int max_scalar_size) {
+    const size_t window = n < 32 ? 3 : ln_without_floats(n);
+    const size_t in_window = (size_t)1 << window;
+    const size_t outerc = ((size_t)max_scalar_size + window - 1) / window;
+    const size_t last_in_window = (size_t)1 << ((size_t)max_scalar_size - (outerc - 1) * window);
+    u64 *table = (u64 *)malloc(outerc * in_window * 2 * FW * 8); /* affine (batch_convert_to_mul_base) */
+    u64 g_outer[3 * FW];
+    memcpy(g_outer, base_jac, 3 * FW * 8);
+    for (size_t outer = 0; outer < outerc; outer++) {
+        const size_t cur = outer == outerc - 1 ? last_in_window : in_window;
+        u64 g_inner[3 * FW];
+        ECN(jac_set_zero)(C, g_inner);
+        for (size_t inner = 0; inner < in_window; inner++) {
+            u64 *cell = table + (outer * in_window + inner) * 2 * FW;
+            if (inner < cur) {
+                ECN(jac_to_aff)(C, cell, g_inner);
+                ECN(jac_add)(C, g_inner, g_outer);
+            } else {
+                memset(cell, 0, 2 * FW * 8); /* T::zero() */
+            }
+        }
+        for (size_t k = 0; k < window; k++) ECN(jac_double)(C, g_outer);
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        const u64 *sc = scalars + i * SCALAR_LIMBS;
+        u64 res[3 * FW];
+        ECN(jac_set_zero)(C, res); /* T::from(table[0][0]) = zero */
+        for (size_t outer = 0; outer < outerc; outer++) {
+            size_t inner = 0;
+            for (size_t k = 0; k < window; k++) {
+                const size_t bit = outer * window + k;
+                if (bit < (size_t)max_scalar_size && ((sc[bit / 64] >> (bit % 64)) & 1)) inner |= (size_t)1 << k;
+            }
+            u64 t[3 * FW];
+            ECN(aff_to_jac)(C, t, table + (outer * in_window + inner) * 2 * FW);
+            ECN(jac_add)(C, res, t);
+        }
+        ECN(jac_to_aff)(C, out_aff + i * 2 * FW, res);
+    }
+    free(table);
+}
+
 /* bases P_i = (a + i*b) * G, i = 0..n-1, as affine points (SURVEY.md section 8d synthetic inputs) */
 static void ECN(gen_bases)(const ark_curve_ctx *C, u64 *out_aff, const u64 *a, const u64 *b, size_t n) {
     u64 g[2 * FW], cur[3 * FW], step[3 * FW];

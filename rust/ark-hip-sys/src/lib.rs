@@ -44,6 +44,10 @@ pub struct ark_hip_msm_bases {
 pub struct ark_hip_msm_job {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct ark_hip_batch_mul_table {
+    _private: [u8; 0],
+}
 
 extern "C" {
     pub fn ark_hip_device_count() -> c_int;
@@ -87,6 +91,13 @@ extern "C" {
     pub fn ark_hip_msm_sw_multi_device(curve: c_int, n_gpus: c_int, d_bases: *const *const c_void,
                                        d_scalars: *const *const c_void, n_per_gpu: *const usize,
                                        scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_batch_mul_table_new(curve: c_int, base_xyz: *const u64, num_scalars: usize,
+                                       out: *mut *mut ark_hip_batch_mul_table) -> c_int;
+    pub fn ark_hip_batch_mul_table_free(table: *mut ark_hip_batch_mul_table) -> c_int;
+    pub fn ark_hip_batch_mul(table: *const ark_hip_batch_mul_table, scalars: *const u64, n: usize,
+                             scalars_are_montgomery: c_int, out_xy: *mut u64) -> c_int;
+    pub fn ark_hip_batch_mul_device(table: *const ark_hip_batch_mul_table, d_scalars: *const c_void, n: usize,
+                                    scalars_are_montgomery: c_int, d_out_xy: *mut c_void) -> c_int;
     pub fn ark_hip_sw_sum(curve: c_int, jac_points: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_sw_normalize_batch_device(curve: c_int, d_jac: *const c_void, d_out_xy: *mut c_void, n: usize) -> c_int;
     pub fn ark_hip_fft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;

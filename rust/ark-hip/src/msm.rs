@@ -204,6 +204,39 @@ impl<P: SWCurveConfig> Drop for PreparedBases<P> {
     }
 }
 
+/// `BatchMulPreprocessing` (ec/src/scalar_mul/mod.rs:156-251) on the device: the table of multiples of one group
+/// element is built and kept in GPU memory; `batch_mul(v)` returns `v[i] * base` as affine points.
+pub struct BatchMulTable<P: SWCurveConfig> {
+    handle: *mut sys::ark_hip_batch_mul_table,
+    _p: PhantomData<P>,
+}
+impl<P: SWCurveConfig> BatchMulTable<P> {
+    /// `BatchMulPreprocessing::new(base, num_scalars)`
+    pub fn new(curve: c_int, base: Projective<P>, num_scalars: usize) -> Option<Self> {
+        if !layout_ok::<P, P::ScalarField>(curve) {
+            return None;
+        }
+        let mut h = core::ptr::null_mut();
+        let rc = unsafe { sys::ark_hip_batch_mul_table_new(curve, &base as *const _ as *const u64, num_scalars, &mut h) };
+        (rc == 0).then(|| Self { handle: h, _p: PhantomData })
+    }
+    /// `BatchMulPreprocessing::batch_mul`
+    pub fn batch_mul(&self, v: &[P::ScalarField]) -> Option<Vec<Affine<P>>> {
+        let mut out: Vec<Affine<P>> = Vec::with_capacity(v.len());
+        let rc = unsafe { sys::ark_hip_batch_mul(self.handle, v.as_ptr() as *const u64, v.len(), 1, out.as_mut_ptr() as *mut u64) };
+        if rc != 0 {
+            return None;
+        }
+        unsafe { out.set_len(v.len()) }; // every element written by the library (x | y, identity = (0, 0))
+        Some(out)
+    }
+}
+impl<P: SWCurveConfig> Drop for BatchMulTable<P> {
+    fn drop(&mut self) {
+        unsafe { sys::ark_hip_batch_mul_table_free(self.handle) };
+    }
+}
+
 /// Page-locked host buffer of scalars (ark_hip_host_alloc): uploads at full PCIe rate and truly asynchronously.
 pub struct PinnedScalars<S: Copy> {
     ptr: *mut S,

@@ -99,6 +99,17 @@ def scalar_mul(curve, base_xy, scalar4):
     return out
 
 
+def batch_mul(curve, base_jac, scalars):
+    """ScalarMul::batch_mul restatement: scalars canonical [n, 4]; returns affine [n, 2*fw]."""
+    fw = fe_words(curve)
+    b = np.ascontiguousarray(base_jac, dtype=np.uint64)
+    s = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = s.size // 4
+    out = np.zeros((n, 2 * fw), dtype=np.uint64)
+    assert _lib.ark_oracle_batch_mul(curve, _p(b), _p(s), C.c_size_t(n), _p(out)) == 0
+    return out
+
+
 def is_on_curve(curve, xy):
     xy = np.ascontiguousarray(xy, dtype=np.uint64)
     return _lib.ark_oracle_is_on_curve(curve, _p(xy)) == 1

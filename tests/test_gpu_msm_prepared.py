@@ -275,3 +275,31 @@ def test_hashmap_pippenger_matches_naive_sum():
     exp = oracle_aff(cid, bases[idx], mont, montgomery_scalars=True)
     assert np.array_equal(aff(cid, p.finalize()), exp)
     assert np.array_equal(aff(cid, A.HashMapPippenger(cid, 4).finalize()), np.zeros(2 * O.fe_words(cid), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("cname", O.CURVES)
+def test_batch_mul_matches_oracle(cname):
+    # ScalarMul::batch_mul / BatchMulPreprocessing (ec/src/scalar_mul/mod.rs:104-251; the doc-test there computes
+    # g, s g, s^2 g, ...): v[i] * g for one base, affine results, against the oracle's restatement
+    import torch
+    cid = O.CID[cname]
+    fid = sf(cid)
+    n = 300 if cname.endswith("G2") else 2000
+    k = np.array([0xC0FFEE, 7, 0, 0], dtype=np.uint64)
+    base = O.scalar_mul(cid, O.generator(cid), k)                     # a Projective with z != 1
+    canon = O.gen_scalars(fid, 61, n)
+    r = S.R[O.FIELDS[fid]]
+    canon[0] = 0
+    canon[1] = [1, 0, 0, 0]
+    canon[2] = P.to_limbs(r - 1, 4)
+    mont = O.field_op(fid, "from_bigint", canon).reshape(n, 4)
+    exp = O.batch_mul(cid, base, canon)
+    t = A.BatchMulPreprocessing(cid, base, n)
+    assert np.array_equal(t.batch_mul(mont), exp)                                  # Fr entry (the reference's)
+    assert np.array_equal(t.batch_mul(canon, montgomery=False), exp)               # canonical entry
+    d = t.batch_mul(torch.from_numpy(mont.view(np.int64)).cuda())
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), exp)                    # device-resident entry
+    t.free()
+    assert np.array_equal(A.batch_mul(cid, base, mont[:5]), exp[:5])
+    ident = O.scalar_mul(cid, O.generator(cid), np.zeros(4, dtype=np.uint64))      # base = identity -> all identity
+    assert not A.batch_mul(cid, ident, mont[:7]).any()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 --pmc result databases (one pass with FETCH_SIZE, one with WRITE_SIZE -- the TCC block cannot
-hold both, MI355X_MICROARCH.md "rocprofv3 PMC slots") into profiles/r1_pmc_traffic.json: HBM bytes per launch of the
+hold both, MI355X_MICROARCH.md "rocprofv3 PMC slots") into profiles/r<N>_pmc_traffic.json: HBM bytes per launch of the
 dominant kernels, as bench.py's roofline.traffic reads them.
 
 Units / corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
@@ -12,7 +12,7 @@ calls uncalibrated: the raw counter equals 2 x 64 B per gathered point almost ex
 two 64-byte lines), i.e. 64-byte requests counted at face value, so the raw figure is used there and the doubled one
 is recorded as an upper bound.
 
-usage: tools/pmc_traffic.py FETCH_DB WRITE_DB LOG_N_MSM LOG_N_FFT > profiles/r1_pmc_traffic.json
+usage: tools/pmc_traffic.py FETCH_DB WRITE_DB LOG_N_MSM LOG_N_FFT > profiles/r2_pmc_traffic.json
 """
 import json
 import sqlite3
@@ -38,7 +38,8 @@ def main():
     fetch = per_kernel(fdb, "FETCH_SIZE")
     write = per_kernel(wdb, "WRITE_SIZE")
     out = {}
-    for frag, logn in (("msm_accumulate_kernel", log_msm), ("fft_pass_kernel", log_fft)):
+    for frag, logn in (("msm_accumulate_shared_kernel", log_msm), ("msm_accumulate_kernel", log_msm),
+                       ("fft_pass_kernel", log_fft)):
         f, w = pick(fetch, frag), pick(write, frag)
         if not f or not w:
             continue

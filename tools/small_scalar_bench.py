@@ -1,26 +1,90 @@
-import sys, time, ctypes as C, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
-import torch, algebra_amd as A
+#!/usr/bin/env python3
+"""The scalar distributions of the reference's MSM bench (bench-templates/src/macros/ec.rs:222-372) at its size
+(2^20 points): random, bool, u8, i8, u16, i16, u32, i32, u64, i64 through msm_bigint, the `-direct` forms through
+msm_u1/u8/u16/u32/u64, and the 11-way mixed vector -- each result checked against k*G (tools/synth.py).
+    python tools/small_scalar_bench.py [LOG_N]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+import algebra_amd as A
+import synth as S
 from algebra_amd import curves as cv
-from algebra_amd._lib import check, lib
-import bench
-L=lib(); cid=cv.curve_id("BLS12_381_G1"); n=1<<20; ab=cv.affine_bytes(cid)
-gen=np.zeros(cv.affine_words(cid),dtype=np.uint64); check(L.ark_hip_curve_generator(cid, gen.ctypes.data_as(C.c_void_p)),"g")
-mul_gen=lambda k: A.into_affine(cid, A.msm_bigint(cid, gen.reshape(1,-1), bench.limbs4(k%bench.R_MOD).reshape(1,4)))
-bases=torch.zeros(n*ab,dtype=torch.uint8,device="cuda"); bases[:ab]=torch.from_numpy(mul_gen(12345).view(np.uint8)).cuda(); torch.cuda.synchronize()
-m=1
-while m<n:
-    cnt=min(m,n-m); d=np.ascontiguousarray(mul_gen(m*777)); check(L.ark_hip_sw_add_affine_device(cid,bases.data_ptr(),bases.data_ptr()+m*ab,cnt,d.ctypes.data_as(C.c_void_p)),"e"); m+=cnt
-rng=np.random.default_rng(1)
-def run(name, vals):
-    sc=np.zeros((n,4),dtype=np.uint64); sc[:,0]=vals
-    s=torch.from_numpy(sc.view(np.int64)).cuda(); torch.cuda.synchronize()
-    A.msm_bigint(cid,bases,s); t=time.perf_counter()
-    for _ in range(3): A.msm_bigint(cid,bases,s)
-    print("%-10s 2^20: %.2f ms" % (name,(time.perf_counter()-t)/3*1e3))
-run("bool", rng.integers(0,2,size=n,dtype=np.uint64))
-run("u8", rng.integers(0,256,size=n,dtype=np.uint64))
-run("u16", rng.integers(0,1<<16,size=n,dtype=np.uint64))
-run("u32", rng.integers(0,1<<32,size=n,dtype=np.uint64))
-run("u64", rng.integers(0,1<<63,size=n,dtype=np.uint64))
-run("all-equal", np.full(n, 0x1234567, dtype=np.uint64))
+
+
+def to_limbs(vals):
+    """list/array of python ints (mod r already) -> [n, 4] uint64"""
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for k in range(4):
+        out[:, k] = [(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for v in vals]
+    return out
+
+
+def main():
+    logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    curve = "BLS12_381_G1"
+    cid = cv.curve_id(curve)
+    r = S.R[cv.scalar_field(cid)]
+    n = 1 << logn
+    bases = S.grow_bases(cid, n, S.A0, S.B0, r)
+    pb = A.PreparedBases(cid, bases)
+    rng = np.random.default_rng(1)
+
+    def small(bits, signed):
+        v = rng.integers(0, 1 << bits, size=n, dtype=np.uint64)
+        sc = np.zeros((n, 4), dtype=np.uint64)
+        sc[:, 0] = v
+        if not signed:
+            return sc
+        # iN::rand: two's complement value, Scalar::from(negative) = r - |x|
+        neg = (v >> np.uint64(bits - 1)) == 1
+        mag = np.where(neg, (np.uint64(1) << np.uint64(bits)) - v if bits < 64 else (~v + np.uint64(1)), v)
+        vals = [int(m) if not ng else (r - int(m)) % r for m, ng in zip(mag, neg)]
+        return to_limbs(vals)
+
+    def mixed():
+        s = n // 11
+        parts = []
+        for bits in (1, 8, 16, 32, 64):
+            v = rng.integers(0, 1 << min(bits, 63), size=s, dtype=np.uint64)
+            pos = np.zeros((s, 4), dtype=np.uint64)
+            pos[:, 0] = v
+            parts.append(pos)
+            parts.append(to_limbs([(r - int(x)) % r for x in v]))
+        parts.append(S.gen_scalars(n - 10 * s, 99, r))
+        allv = np.concatenate(parts)
+        return allv[rng.permutation(allv.shape[0])]
+
+    cases = [("random", S.gen_scalars(n, 5, r), None), ("bool", small(1, False), A.msm_u1), ("u8", small(8, False), A.msm_u8),
+             ("i8", small(8, True), None), ("u16", small(16, False), A.msm_u16), ("i16", small(16, True), None),
+             ("u32", small(32, False), A.msm_u32), ("i32", small(32, True), None), ("u64", small(63, False), A.msm_u64),
+             ("i64", small(64, True), None), ("mixed", mixed(), None)]
+    print("# %s 2^%d, device-resident inputs; ms per MSM, every result == k*G" % (curve, logn))
+    for name, sc, direct in cases:
+        d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+        kg = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
+        line = "%-8s" % name
+        for label, fn in (("msm_bigint", lambda: A.msm_bigint(cid, bases, d)), ("prepared", lambda: pb.msm_bigint(d))):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                res = fn()
+            dt = (time.perf_counter() - t0) / 3
+            line += "  %s %6.2f ms (exact=%s)" % (label, dt * 1e3, bool(np.array_equal(A.into_affine(cid, res), kg)))
+        if direct is not None:
+            small_vals = sc[:, 0].astype(bool) if name == "bool" else sc[:, 0]
+            hb = bases.cpu().numpy().view(np.uint64).reshape(n, -1)
+            res = direct(cid, hb, small_vals)
+            line += "  %s-direct (host arrays) exact=%s" % (name, bool(np.array_equal(A.into_affine(cid, res), kg)))
+        print(line, flush=True)
+    pb.free()
+
+
+if __name__ == "__main__":
+    main()
