@@ -75,6 +75,7 @@ SYMBOLS = {
     "ark_hip_curve_generator": (C.c_int, [C.c_int, C.c_void_p]),
     "ark_hip_msm_sw": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ark_hip_msm_sw_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ark_hip_msm_plan": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ark_hip_msm_set_timing": (C.c_int, [C.c_int]),
     "ark_hip_msm_last_timing": (C.c_int, [C.POINTER(C.c_double)]),
     "ark_hip_sw_sum": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

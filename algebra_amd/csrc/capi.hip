@@ -599,6 +599,15 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
   return msm_finish_ctx(c, curve, slot, out_xyz);
 }
 
+// the window plan the library would use (host arithmetic only: no GPU needed)
+int ark_hip_msm_plan(int curve, size_t n, int prepared, int* window_bits, int* windows) {
+  if (curve < 0 || curve > 4) return ARK_HIP_ERR_ARG;
+  const MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve), prepared != 0);
+  if (window_bits) *window_bits = pl.c;
+  if (windows) *windows = pl.W;
+  return 0;
+}
+
 int ark_hip_msm_set_timing(int enable) {
   ARK_SCOPE(sc);
   sc.c->msm_timing = enable != 0;

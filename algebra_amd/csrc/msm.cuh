@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <mutex>
+#include <math.h>
 #include "curves.cuh"
 #include "msm_sort.cuh"
 
@@ -713,9 +714,21 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       if (shared) nbk = (double)(1u << (c - 1));
       const double entries = (double)n * W;
       const double madd = 1.0 / 5.5e9 * mul_cost, fadd = 1.4 / 5.5e9 * mul_cost;
+      // accumulate: throughput-bound when the buckets make several rounds over the chip's resident lanes (2 waves x 4
+      // SIMDs x 256 CUs x 64 lanes; a G2 bucket takes a lane pair); with a single round the kernel lasts as long as
+      // its most loaded lane (Poisson tail): ~24 us per addition on a fully occupied SIMD, ~14 us with one wave per SIMD
+      // (profiles/r2_small_n_sweep.txt)
       double acc = entries * madd;
-      const double chain = (entries / nbk) * 14e-6 * mul_cost;  // one lane walks one bucket
-      if (chain > acc) acc = chain;
+      if (shared) {
+        const double lanes = 131072.0 / (mul_cost > 2.0 ? 2.0 : 1.0);
+        const double load = entries / nbk, lmax = load + 3.0 * sqrt(load) + 2.0;
+        const double per_add = (nbk <= lanes / 2 ? 14e-6 : 24e-6) * mul_cost;  // one wave per SIMD runs a chain faster
+        const double walk = lmax * per_add + W * 5e-6;                          // + run switches of a shared bucket
+        if (nbk <= lanes || walk > acc) acc = walk;
+      } else {
+        const double chain = (entries / nbk) * 14e-6 * mul_cost;  // one lane walks one (window, bucket) run
+        if (chain > acc) acc = chain;
+      }
       double red0 = nbk * 2.0 * fadd;
       const double red0_lat = 2.0 * 8.0 * 21e-6 * mul_cost;     // >= 8 buckets per lane at level 0
       if (red0_lat > red0) red0 = red0_lat;
@@ -884,7 +897,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     size_t want = (mwin * (size_t)Wr) >> 17;  // keep ~1e5 (S, A) pairs for the bit-sliced stage
     u32 p2 = 1;
     while (p2 < want) p2 <<= 1;
-    if (p2 < 8) p2 = 8;
+    const u32 l0_min = (mwin * (size_t)Wr) <= ((size_t)1 << 17) ? 4 : 8;  // few buckets: short chains beat fewer pairs
+    if (p2 < l0_min) p2 = l0_min;
     if (p2 < L0) L0 = p2;
     if (const char* e0 = getenv("ARK_HIP_MSM_L0")) {  // tuning knob
       int v = atoi(e0);
@@ -900,7 +914,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   const u32 Q = (u32)nbits + 1;
   // chunk of the bit-sliced stage: a workgroup's 256 lanes stride over it (chunk/256 serial additions each) before the
   // 8-step LDS tree -- both pure latency, so chunks are kept short once there are enough of them to fill the chip
-  u32 chunk = 4096;  // (512 / 1024 / 2048 measured no better at 2^24: profiles/r2_msm_sweeps.txt)
+  // (few workgroups, e.g. one window of a prepared set at small n: latency only, 2^16 1.39 -> 1.11 ms; many: throughput)
+  u32 chunk = (size_t)Wr * Q * ((m + 4095) / 4096) < 512 ? 1024 : 4096;
   if (const char* ec = getenv("ARK_HIP_MSM_CHUNK")) {
     int v = atoi(ec);
     if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) chunk = (u32)v;

@@ -133,6 +133,9 @@ int ark_hip_msm_sw_multi(int curve, int n_gpus, const uint64_t* bases, const uin
 int ark_hip_msm_sw_multi_device(int curve, int n_gpus, const void* const* d_bases, const void* const* d_scalars,
                                 const size_t* n_per_gpu, int scalars_are_montgomery, uint64_t* out_xyz);
 
+/* The window plan (widest window in bits, number of windows) the library picks for an MSM of n pairs on `curve`, plain
+ * (prepared = 0) or over a prepared base set; pure host arithmetic. */
+int ark_hip_msm_plan(int curve, size_t n, int prepared, int* window_bits, int* windows);
 /* Per-phase device times of the last MSM finished on this device with timing enabled (ms):
  * [digits, partition histogram + scan, partition scatter + finish + bucket order, accumulate (incl. heavy
  *  buckets), reduce, total, window_bits, windows] */

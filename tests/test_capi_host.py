@@ -141,3 +141,27 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "oracle")], timeout=300)
     if _lib.lib().ark_hip_device_count() == 0:
         assert subprocess.run([exe], capture_output=True, timeout=120).returncode == 2
+
+
+def test_msm_plan_is_host_only_and_sane():
+    # ark_hip_msm_plan: pure host arithmetic (no GPU): the widths of the W windows must cover the scalar, wider windows
+    # for larger inputs, and a prepared base set never plans more windows than the plain path
+    import ctypes as C
+    from algebra_amd._lib import lib
+    L = lib()
+    bits = {0: 254, 1: 255, 2: 253, 3: 253, 4: 255}
+    for curve in range(5):
+        prev = 0
+        for logn in (0, 4, 10, 16, 20, 24, 26):
+            got = {}
+            for prepared in (0, 1):
+                c, w = C.c_int(), C.c_int()
+                assert L.ark_hip_msm_plan(curve, 1 << logn, prepared, C.byref(c), C.byref(w)) == 0
+                assert 3 <= c.value <= 26 and w.value >= 1
+                assert c.value * w.value >= bits[curve], (curve, logn, prepared, c.value, w.value)
+                got[prepared] = (c.value, w.value)
+            assert got[1][1] <= got[0][1] + 1
+            if logn >= 16:
+                assert got[0][0] >= prev
+                prev = got[0][0]
+    assert L.ark_hip_msm_plan(7, 100, 0, None, None) == -1
