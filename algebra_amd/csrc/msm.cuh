@@ -268,14 +268,14 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
                                                              const u32* __restrict__ sorted,
                                                              const u32* __restrict__ offsets,
                                                              const u32* __restrict__ order, u32 nbuckets,
-                                                             u32 heavy_thresh, int HB, int LB,
+                                                             const u32* __restrict__ d_thresh, int HB, int LB,
                                                              char* __restrict__ buckets) {
   typedef typename C::FA F;  // Fp, or Fp2Half: then a lane PAIR owns the bucket (both lanes run the same control flow)
   u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / F::LANES;
   if (t >= nbuckets) return;
   u32 g = order ? order[t] : t;
   u32 j = offsets[g], end = offsets[g + 1];
-  if (end - j > heavy_thresh) return;  // left to the heavy-bucket kernels
+  if (end - j > *d_thresh) return;  // left to the heavy-bucket kernels
   XYZZ<F> acc = XYZZ<F>::zero();
   if (j < end) {
     // software pipeline, two deep on the indices: the gather of point t+1 (whose index arrived an iteration ago) and
@@ -317,13 +317,14 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
 template <class C>
 __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_kernel(
     const char* __restrict__ table, size_t wstride, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
-    const u32* __restrict__ order, u32 nbuckets, int W, int B, u32 heavy_thresh, int HB, int LB,
+    const u32* __restrict__ order, u32 nbuckets, int W, int B, const u32* __restrict__ d_thresh, int HB, int LB,
     char* __restrict__ buckets) {
   typedef typename C::FA F;  // Fp, or Fp2Half: then a lane PAIR owns the bucket
   typedef XYZZ<F> Pt;
   u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / F::LANES;
   if (t >= nbuckets) return;
   const u32 s = order ? order[t] : t;
+  const u32 heavy_thresh = *d_thresh;
   Pt acc = Pt::zero();
   int w = 0;                    // next window to open
   u32 na = offsets[s], nb2 = offsets[s + 1];  // bounds of window w's run, fetched one window ahead
@@ -420,14 +421,29 @@ __global__ void __launch_bounds__(128) msm_table_step_kernel(const char* __restr
 static constexpr u32 HEAVY_CHUNK = 2048;
 struct HeavyEntry { u32 bucket, first_item, items; };
 
+// A run is "heavy" when one lane walking it (~28 us per entry) would outlast the whole accumulate kernel, whose
+// throughput-bound duration is (non-zero entries) / 5.5e9 s: threshold = entries / 154 000, at least 64 and at least
+// 4 x the mean run.  The entry count is only known after the sort (zero digits are dropped: small scalars leave most
+// windows empty), so the threshold is computed on the device.  ctr[2] <- threshold.
+static __global__ void msm_thresh_kernel(const u32* __restrict__ offsets, u32 nslots, u32 forced, u32* __restrict__ ctr) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const u32 total = offsets[nslots];
+  u32 t = total / 154000u;
+  if (t < 64u) t = 64u;
+  const u32 mr = 4u * (total / nslots);
+  if (t < mr) t = mr;
+  if (forced) t = forced;
+  ctr[2] = t;
+}
+
 static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* __restrict__ offsets, u32 nbuckets,
-                                                                    u32 thresh, u32* __restrict__ ctr /*[2]*/,
+                                                                    u32* __restrict__ ctr /*[3]*/,
                                                                     HeavyEntry* __restrict__ list,
                                                                     uint2* __restrict__ items) {
   u32 g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nbuckets) return;
   u32 cnt = offsets[g + 1] - offsets[g];
-  if (cnt <= thresh) return;
+  if (cnt <= ctr[2]) return;
   u32 k = (cnt + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
   u32 first = atomicAdd(&ctr[0], k);
   u32 slot = atomicAdd(&ctr[1], 1u);
@@ -526,22 +542,25 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __rest
   constexpr u32 NS = 64 / Ops::LANES;
   extern __shared__ uint4 heavy_lds[];
   char* sh = (char*)heavy_lds;
-  const u32 hslot = blockIdx.x, slot = threadIdx.x / Ops::LANES;
-  if (hslot >= ctr[1]) return;  // uniform for the whole workgroup
-  HeavyEntry h = list[hslot];
-  Pt acc = Pt::zero();
-  for (u32 q = slot; q < h.items; q += NS) {
-    Pt x = Pt::load(partials + (size_t)(h.first_item + q) * Pt::BYTES);
-    Ops::add(acc, x);
-  }
-  Ops::tree(acc, sh, slot, NS);
-  if (slot == 0) {
-    if constexpr (SHARED) {
-      Ops::fin(acc).store(buckets + (size_t)hslot * Pt::BYTES);  // `buckets` is the hfinal array here
-      if (threadIdx.x == 0) sorted[offsets[h.bucket]] = hslot;
-    } else {
-      Ops::fin(acc).store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
+  const u32 slot = threadIdx.x / Ops::LANES;
+  const u32 nheavy = ctr[1];
+  for (u32 hslot = blockIdx.x; hslot < nheavy; hslot += gridDim.x) {  // uniform for the whole workgroup
+    HeavyEntry h = list[hslot];
+    Pt acc = Pt::zero();
+    for (u32 q = slot; q < h.items; q += NS) {
+      Pt x = Pt::load(partials + (size_t)(h.first_item + q) * Pt::BYTES);
+      Ops::add(acc, x);
     }
+    Ops::tree(acc, sh, slot, NS);
+    if (slot == 0) {
+      if constexpr (SHARED) {
+        Ops::fin(acc).store(buckets + (size_t)hslot * Pt::BYTES);  // `buckets` is the hfinal array here
+        if (threadIdx.x == 0) sorted[offsets[h.bucket]] = hslot;
+      } else {
+        Ops::fin(acc).store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -553,28 +572,32 @@ __global__ void __launch_bounds__(64) msm_apply_heavy_kernel(const u32* __restri
                                                              const u32* __restrict__ offsets,
                                                              const u32* __restrict__ sorted,
                                                              const char* __restrict__ hfinal, int W, int B,
-                                                             u32 heavy_thresh, int HB, int LB, char* __restrict__ buckets) {
+                                                             int HB, int LB, char* __restrict__ buckets) {
   typedef AccOps<C> Ops;
   typedef typename Ops::Pt Pt;
-  const u32 h = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LANES;
-  if (h >= ctr[1]) return;
-  const u32 g = list[h].bucket;
-  const u32 w0 = g >> B, s = g & ((1u << B) - 1u);
-  for (u32 w = 0; w < w0; w++) {
-    const u32 gg = (w << B) | s;
-    if (offsets[gg + 1] - offsets[gg] > heavy_thresh) return;  // a lower window owns this bucket
-  }
-  char* cell = buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * Pt::BYTES;
-  Pt acc = Pt::load(cell);
-  for (u32 w = w0; w < (u32)W; w++) {
-    const u32 gg = (w << B) | s;
-    const u32 a = offsets[gg];
-    if (offsets[gg + 1] - a > heavy_thresh) {
-      Pt x = Pt::load(hfinal + (size_t)sorted[a] * Pt::BYTES);
-      Ops::add(acc, x);
+  const u32 nheavy = ctr[1], heavy_thresh = ctr[2];
+  const u32 stride = gridDim.x * blockDim.x / Ops::LANES;
+  for (u32 h = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LANES; h < nheavy; h += stride) {
+    const u32 g = list[h].bucket;
+    const u32 w0 = g >> B, s = g & ((1u << B) - 1u);
+    bool owner = true;
+    for (u32 w = 0; w < w0; w++) {
+      const u32 gg = (w << B) | s;
+      if (offsets[gg + 1] - offsets[gg] > heavy_thresh) owner = false;  // a lower window owns this bucket
     }
+    if (!owner) continue;
+    char* cell = buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * Pt::BYTES;
+    Pt acc = Pt::load(cell);
+    for (u32 w = w0; w < (u32)W; w++) {
+      const u32 gg = (w << B) | s;
+      const u32 a2 = offsets[gg];
+      if (offsets[gg + 1] - a2 > heavy_thresh) {
+        Pt x = Pt::load(hfinal + (size_t)sorted[a2] * Pt::BYTES);
+        Ops::add(acc, x);
+      }
+    }
+    Ops::fin(acc).store(cell);
   }
-  Ops::fin(acc).store(cell);
 }
 
 // ---- K5a: level 0 of the bucket reduction --------------------------------------------------------------
@@ -953,14 +976,11 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   // sparse top window (1024 per bucket) still rides along; skewed scalar distributions do not.
   const size_t total_entries = (size_t)n * W;
   size_t mean_load = total_entries / nbk;        // per lane (a lane of a prepared set walks W runs)
-  const size_t mean_run = total_entries / nb;    // per (window, bucket) run: what `heavy` is judged against
-  u32 heavy_thresh = (u32)(total_entries / 154000);
-  if (heavy_thresh < 64) heavy_thresh = 64;
-  if (heavy_thresh < 4 * mean_run) heavy_thresh = (u32)(4 * mean_run);
+  u32 forced_thresh = 0;  // 0: computed on the device from the number of non-zero entries (msm_thresh_kernel)
   if (const char* hv = getenv("ARK_HIP_MSM_HEAVY")) {
-    if (atoi(hv) >= 64) heavy_thresh = (u32)atoi(hv);
+    if (atoi(hv) >= 64) forced_thresh = (u32)atoi(hv);
   }
-  const size_t max_heavy = total_entries / heavy_thresh + 1;
+  const size_t max_heavy = total_entries / 64 + 1;  // the threshold is never below 64
   const size_t max_items = total_entries / HEAVY_CHUNK + max_heavy + 1;
   if (ws.hctr.ensure(16) || ws.hlist.ensure(max_heavy * sizeof(HeavyEntry)) || ws.hitems.ensure(max_items * 8) ||
       ws.hpart.ensure(max_items * Pt::BYTES))
@@ -1015,34 +1035,37 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   {
     // runs too long for one lane: chunk partials by one wave each, combined per run (empty for uniform scalars)
     u32* hctr = (u32*)ws.hctr.p;
+    hipLaunchKernelGGL(msm_thresh_kernel, dim3(1), dim3(64), 0, stream, offsets, (u32)nb, forced_thresh, hctr);
     hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
-                       heavy_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
+                       hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
     constexpr u32 LN = C::FA::LANES;                        // lanes per element of the accumulate field
     const u32 hthreads = Pt::BYTES * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
     hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * Pt::BYTES, stream,
                        (const char*)d_points, sorted, offsets, hctr, (const uint2*)ws.hitems.p, wstride, Bbits,
                        (char*)ws.hpart.p);
+    const u32 combine_grid = max_heavy < 16384 ? (u32)max_heavy : 16384u;  // grid-stride over the heavy runs
     if (pl.shared)
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3((u32)max_heavy), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
                          (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
                          (char*)ws.hfinal.p);
     else
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3((u32)max_heavy), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
                          (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
                          (char*)ws.buckets.p);
   }
   if (pl.shared)
   {
     hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
-                       (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, heavy_thresh, HB, LB,
+                       (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, (const u32*)ws.hctr.p + 2, HB, LB,
                        (char*)ws.buckets.p);
-    hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3((u32)((max_heavy * C::FA::LANES + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3(1024), dim3(64), 0, stream,
                        (const u32*)ws.hctr.p, (const HeavyEntry*)ws.hlist.p, offsets, sorted, (const char*)ws.hfinal.p, W,
-                       Bbits, heavy_thresh, HB, LB, (char*)ws.buckets.p);
+                       Bbits, HB, LB, (char*)ws.buckets.p);
   }
   else
     hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
-                       (const char*)d_points, sorted, offsets, order, (u32)nb, heavy_thresh, HB, LB, (char*)ws.buckets.p);
+                       (const char*)d_points, sorted, offsets, order, (u32)nb, (const u32*)ws.hctr.p + 2, HB, LB,
+                       (char*)ws.buckets.p);
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
 
   constexpr u32 LNr = C::FA::LANES;
