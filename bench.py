@@ -250,6 +250,37 @@ def main():
         del bb, bs
         torch.cuda.empty_cache()
 
+    # ---- the other BASELINE configurations, one line each (rank 0, single GPU) --------------------------------
+    others = None
+    if world == 1 and not args.no_extras:
+        others = {}
+        for cname, lg, st in (("BN254_G1", 16, 20), ("BLS12_381_G1", 20, 10), ("BLS12_377_G2", 22, 3)):
+            try:
+                c2 = cv.curve_id(cname)
+                r2 = S.R[cv.scalar_field(c2)]
+                n2 = 1 << lg
+                b2 = S.grow_bases(c2, n2, A0, B0, r2)
+                sh2 = S.gen_scalars(n2, 0xC0DE + lg, r2)
+                s2 = torch.from_numpy(sh2.view(np.int64)).cuda()
+                torch.cuda.synchronize()
+                kg2 = S.mul_gen(c2, S.dlog_of_msm(sh2, A0, B0, r2), r2)
+                p2 = A.PreparedBases(c2, b2)
+                entry = {}
+                for label, fn in (("plain", lambda: A.msm_bigint(c2, b2, s2)), ("prepared", p2.msm_bigint)):
+                    res2 = fn(s2) if label == "prepared" else fn()
+                    t1 = time.perf_counter()
+                    for _ in range(st):
+                        res2 = fn(s2) if label == "prepared" else fn()
+                    dt2 = (time.perf_counter() - t1) / st
+                    entry[label] = {"ms_per_step": dt2 * 1e3, "value": n2 / dt2,
+                                    "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(c2, res2), kg2))}
+                others["%s MSM 2^%d" % (cname, lg)] = entry
+                p2.free()
+                del b2, s2
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001 -- side measurements never cost the headline line
+                others["%s MSM 2^%d" % (cname, lg)] = {"error": repr(e)[:200]}
+
     # ---- FFT leg (rank 0's GPU; the FFT config is single-GPU) ---------------------------------------
     fft = None
     if rank == 0 and args.fft_steps > 0:
@@ -389,6 +420,7 @@ def main():
             "plain": plain,
             "weak_scaling": weak,
             "msm_2_26_one_gpu": big,
+            "other_configs": others,
             "fft": fft,
             "fft_sharded": fft_sharded,
         }
