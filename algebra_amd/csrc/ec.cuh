@@ -158,10 +158,10 @@ ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
     else acc = XYZZ<F>::zero();
     return;
   }
-  F pp = F::mul_r(p, p);
+  F pp = F::sqr_r(p);
   F ppp = F::mul_r(p, pp);
   F q = F::mul_r(acc.x, pp);
-  F x3 = F::sub_r(F::sub_r(F::mul_r(r, r), ppp), F::dbl_r(q));
+  F x3 = F::sub_r(F::sub_r(F::sqr_r(r), ppp), F::dbl_r(q));
   F y3;
   if constexpr (F::FUSED_Y3) y3 = F::sop2_r(r, F::sub_r(q, x3), F::neg_r(acc.y), ppp);  // R (Q - X3) - Y1 PPP, one reduction
   else y3 = F::sub_r(F::mul_r(r, F::sub_r(q, x3)), F::mul_r(acc.y, ppp));
@@ -224,10 +224,10 @@ ARK_HD void xyzz_add_relaxed(XYZZ<F>& acc, const XYZZ<F>& b) {
     else acc = XYZZ<F>::zero();
     return;
   }
-  F pp = F::mul_r(p, p);
+  F pp = F::sqr_r(p);
   F ppp = F::mul_r(p, pp);
   F q = F::mul_r(u1, pp);
-  F x3 = F::sub_r(F::sub_r(F::mul_r(r, r), ppp), F::dbl_r(q));
+  F x3 = F::sub_r(F::sub_r(F::sqr_r(r), ppp), F::dbl_r(q));
   F y3;
   if constexpr (F::FUSED_Y3) y3 = F::sop2_r(r, F::sub_r(q, x3), F::neg_r(s1), ppp);
   else y3 = F::sub_r(F::mul_r(r, F::sub_r(q, x3)), F::mul_r(s1, ppp));

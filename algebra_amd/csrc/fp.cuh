@@ -162,6 +162,33 @@ ARK_DEV void mont2_cols_hi(Acc96& c, const u32* a, const u32* b, const u32* a2, 
   if constexpr (K + 1 < 2 * N - 1) mont2_cols_hi<P, K + 1>(c, a, b, a2, b2, m, t);
 }
 
+// ... and of four products (an Fp2 sum of two products, per component): up to 5N products per column, < 2^71
+template <class P, int K>
+ARK_DEV void mont4_cols_lo(Acc96& c, const u32* const* x, const u32* const* y, u32* m) {
+  constexpr int N = P::N;
+  col_vv<0, K, K>(c, x[0], y[0]);
+  col_vv<0, K, K>(c, x[1], y[1]);
+  col_vv<0, K, K>(c, x[2], y[2]);
+  col_vv<0, K, K>(c, x[3], y[3]);
+  col_vp<P, 0, K - 1, K>(c, m);
+  m[K] = (u32)c.lo * P::INV;
+  mac_vs(c, m[K], PL<P, 0>::v);
+  acc_shift(c);
+  if constexpr (K + 1 < N) mont4_cols_lo<P, K + 1>(c, x, y, m);
+}
+template <class P, int K>
+ARK_DEV void mont4_cols_hi(Acc96& c, const u32* const* x, const u32* const* y, const u32* m, u32* t) {
+  constexpr int N = P::N;
+  col_vv<K - N + 1, N - 1, K>(c, x[0], y[0]);
+  col_vv<K - N + 1, N - 1, K>(c, x[1], y[1]);
+  col_vv<K - N + 1, N - 1, K>(c, x[2], y[2]);
+  col_vv<K - N + 1, N - 1, K>(c, x[3], y[3]);
+  col_vp<P, K - N + 1, N - 1, K>(c, m);
+  t[K - N] = (u32)c.lo;
+  acc_shift(c);
+  if constexpr (K + 1 < 2 * N - 1) mont4_cols_hi<P, K + 1>(c, x, y, m, t);
+}
+
 // ---- the field element ----------------------------------------------------------------------
 template <class P_>
 struct Fp {
@@ -348,6 +375,7 @@ struct Fp {
     return mul(a, b);  // canonical is a valid relaxed representative
 #endif
   }
+  ARK_HD static Fp sqr_r(const Fp& a) { return mul_r(a, a); }
   // t (< 4p) -> t or t - 2p, whichever lies in [0, 2p)
   ARK_HD static Fp reduce_2p(const u32* t) {
     u32 d[N];
@@ -438,6 +466,28 @@ struct Fp {
 #else
     return add(mul(a.canonical(), b.canonical()), mul(c2.canonical(), d.canonical()));
 #endif
+  }
+  // x0*y0 + x1*y1 + x2*y2 + x3*y3 under one reduction (device only).  The caller guarantees sum < R*p * (1 or 3):
+  // FOLD = false: sum <= R p, result < 2p as it stands; FOLD = true: sum <= 3 R p, one conditional -2p follows.
+  template <bool FOLD>
+  ARK_DEV static Fp sop4_r(const Fp& x0, const Fp& y0, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2, const Fp& x3,
+                           const Fp& y3) {
+    const u32* xs[4] = {x0.l, x1.l, x2.l, x3.l};
+    const u32* ys[4] = {y0.l, y1.l, y2.l, y3.l};
+    Acc96 c{0, 0};
+    u32 m[N];
+    u32 t[N];
+    mont4_cols_lo<P, 0>(c, xs, ys, m);
+    mont4_cols_hi<P, N>(c, xs, ys, m, t);
+    t[N - 1] = (u32)c.lo;
+    if constexpr (FOLD) {
+      return reduce_2p(t);
+    } else {
+      Fp r;
+#pragma unroll
+      for (int i = 0; i < N; i++) r.l[i] = t[i];
+      return r;
+    }
   }
   // canonical form: a*b + c*d for operands < p, except that `c2` may be any N-limb value up to 6p (a small multiple
   // of a negated element: the -beta*a1 term of an Fp2 product); (p^2 + 6p^2 + m p)/R < p (7p/R + 1) < 2p.
@@ -669,7 +719,7 @@ struct Fp2Half {
   static constexpr int BYTES = B::BYTES;           // bytes this lane holds
   static constexpr int FULL_BYTES = 2 * B::BYTES;  // bytes of the whole element in memory (c0 | c1)
   static constexpr int LANES = 2;
-  static constexpr bool FUSED_Y3 = false;
+  static constexpr bool FUSED_Y3 = true;
   B v;
 
   // (device-only type; the bodies are visible to the host pass as well because kernel templates are parsed there)
@@ -731,9 +781,65 @@ struct Fp2Half {
     }
     return Fp2Half{B::sop2_r(X, b.v, Z, pb)};  // even: a0 b0 + beta a1 b1 ; odd: a0 b1 + a1 b0
   }
+  ARK_DEV static Fp2Half neg_r(const Fp2Half& a) { return Fp2Half{B::neg_r(a.v)}; }
+  // a*b + c*d over Fp2 (relaxed operands; c is typically a neg_r): FOUR base products per lane under one reduction,
+  //   even: a0 b0 + beta a1 b1 + c0 d0 + beta c1 d1        odd: a0 b1 + a1 b0 + c0 d1 + c1 d0
+  // bound (8 + 8 NEG_BETA) p^2: within R p over BLS12-377 (48 p < R); over BLS12-381 (16 p^2 > R p) one fold follows.
+  ARK_DEV static Fp2Half sop2_r(const Fp2Half& a, const Fp2Half& b, const Fp2Half& c, const Fp2Half& d) {
+    constexpr bool FOLD = ((u64)(8 + 8 * NEG_BETA) * ((u64)P::P[N - 1] + 1)) > (1ull << 32);
+    static_assert(((u64)(8 + 8 * NEG_BETA) * ((u64)P::P[N - 1] + 1)) <= 3 * (1ull << 32), "sum of four products exceeds 3 R p");
+    const B pa = partner(a.v), pb = partner(b.v), pc = partner(c.v), pd = partner(d.v);
+    const B ba = beta_times(pa), bc = beta_times(pc);
+    const bool o = odd();
+    B X0, X1, X2, X3;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      X0.l[i] = o ? pa.l[i] : a.v.l[i];
+      X1.l[i] = o ? a.v.l[i] : ba.l[i];
+      X2.l[i] = o ? pc.l[i] : c.v.l[i];
+      X3.l[i] = o ? c.v.l[i] : bc.l[i];
+    }
+    return Fp2Half{B::template sop4_r<FOLD>(X0, b.v, X1, pb, X2, d.v, X3, pd)};
+  }
+  // relaxed square by complex squaring: with t = a0 a1,  a0^2 + beta a1^2 = (a0 + a1)(a0 + beta a1) - (1 + beta) t.
+  // even lane: s = (a0 + a1)(a0 + beta a1); odd lane: t = a0 a1 -- ONE plain product per lane (288 multiplies instead
+  // of the 432 of mul_r(a, a)); then c0 = s + (NEG_BETA - 1) t, c1 = 2 t.
+  ARK_DEV static Fp2Half sqr_r(const Fp2Half& a) {
+    static_assert((u64)(4 + 4 * NEG_BETA) * ((u64)P::P[N - 1] + 1) < (1ull << 32), "2p * (2 + 2 NEG_BETA) p must stay below R p");
+    const B pa = partner(a.v);
+    const bool o = odd();
+    const B sum = B::add_r(a.v, pa);   // a0 + a1 (used by the even lane)
+    const B bz = beta_times(pa);       // even lane: NEG_BETA (2p - a1) = beta a1 (mod p), <= 2 NEG_BETA p
+    B wide;                            // a0 + beta a1, unreduced (<= (2 + 2 NEG_BETA) p < 2^(32N)): a product operand only
+    {
+      u32 cy = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        u32 co;
+        wide.l[i] = __builtin_addc(a.v.l[i], bz.l[i], cy, &co);
+        cy = co;
+      }
+    }
+    B X, Y;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      X.l[i] = o ? pa.l[i] : sum.l[i];
+      Y.l[i] = o ? a.v.l[i] : wide.l[i];
+    }
+    const B prod = B::mul_r(X, Y);     // even: s ; odd: t
+    const B pt = partner(prod);        // even lane receives t
+    B even;
+    if constexpr (NEG_BETA == 1) even = prod;
+    else even = B::add_r(prod, B::dbl_r(B::dbl_r(pt)));  // NEG_BETA == 5: s + 4 t
+    const B oddv = B::dbl_r(prod);
+    Fp2Half r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v.l[i] = o ? oddv.l[i] : even.l[i];
+    return r;
+  }
   // canonical forms (the rare doubling branch and point conversions): relaxed arithmetic + one fold
   ARK_DEV static Fp2Half mul(const Fp2Half& a, const Fp2Half& b) { return mul_r(a, b).canonical(); }
-  ARK_DEV static Fp2Half sqr(const Fp2Half& a) { return mul_r(a, a).canonical(); }
+  ARK_DEV static Fp2Half sqr(const Fp2Half& a) { return sqr_r(a).canonical(); }
   ARK_DEV static Fp2Half add(const Fp2Half& a, const Fp2Half& b) { return Fp2Half{B::add(a.v, b.v)}; }
   ARK_DEV static Fp2Half sub(const Fp2Half& a, const Fp2Half& b) { return Fp2Half{B::sub(a.v, b.v)}; }
   ARK_DEV static Fp2Half dbl(const Fp2Half& a) { return Fp2Half{B::dbl(a.v)}; }
