@@ -16,13 +16,16 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(12345)
 A4 = np.array([0xA11CE, 1, 2, 0], dtype=np.uint64)
 B4 = np.array([0xB0B, 3, 0, 0], dtype=np.uint64)
-bases = {c: O.gen_bases(O.CID[c], A4, B4, 1 << 15) for c in ("BLS12_381_G1", "BN254_G1")}
+CURVES = ("BLS12_381_G1", "BN254_G1", "BLS12_377_G2")
+bases = {c: O.gen_bases(O.CID[c], A4, B4, (1 << 12) if c.endswith("G2") else (1 << 15)) for c in CURVES}
+prepared = {}  # (curve, off, n) windows re-prepared every few iterations
 bad = 0
 for it in range(iters):
-    cname = ("BLS12_381_G1", "BN254_G1")[it % 2]
+    cname = CURVES[it % 3]
     cid = O.CID[cname]
-    n = int(rng.integers(1, 1 << 15))
-    off = int(rng.integers(0, (1 << 15) - n + 1))
+    cap = bases[cname].shape[0]
+    n = int(rng.integers(1, cap))
+    off = int(rng.integers(0, cap - n + 1))
     sc = O.gen_scalars(O.curve_info(cid)[1], 5000 + it, n)
     kind = it % 5
     if kind == 3:  # skewed: many small scalars
@@ -35,6 +38,20 @@ for it in range(iters):
     if not np.array_equal(got, exp):
         bad += 1
         print("MSM MISMATCH", cname, n, it)
+    # the same sum over a prepared base set (random forced window size now and then), synchronous and as a job
+    if it % 4 == 0:
+        os.environ["ARK_HIP_MSM_C_PREPARED"] = str(int(rng.integers(3, 18)))
+    else:
+        os.environ.pop("ARK_HIP_MSM_C_PREPARED", None)
+    pb = A.PreparedBases(cid, bases[cname][off:off + n])
+    os.environ.pop("ARK_HIP_MSM_C_PREPARED", None)
+    job = pb.msm_bigint_async(sc)
+    got_p = A.into_affine(cid, pb.msm_bigint(sc))
+    got_j = A.into_affine(cid, job.wait())
+    pb.free()
+    if not (np.array_equal(got_p, exp) and np.array_equal(got_j, exp)):
+        bad += 1
+        print("PREPARED MSM MISMATCH", cname, n, it, pb)
     log_n = int(rng.integers(1, 17))
     fname = ("BLS12_381_FR", "BN254_FR", "BLS12_377_FR")[it % 3]
     fid = O.FID[fname]
@@ -48,5 +65,12 @@ for it in range(iters):
     if not np.array_equal(got, exp):
         bad += 1
         print("FFT MISMATCH", fname, log_n, it)
+    if not inv and log_n >= 3:  # ragged short input: degree-aware path
+        ln = int(rng.integers(1, (1 << log_n) // 4 + 1))
+        full = np.zeros((1 << log_n, 4), dtype=np.uint64)
+        full[:ln] = x[:ln]
+        if not np.array_equal(d.fft(x[:ln]).reshape(-1), O.fft(fid, full, log_n, O.field_const(fid, 3) if it % 2 else None, False, 8)):
+            bad += 1
+            print("DEGREE-AWARE FFT MISMATCH", fname, log_n, ln, it)
 print("soak: %d iterations, %d mismatches" % (iters, bad))
 sys.exit(1 if bad else 0)
