@@ -277,6 +277,9 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
   u32 j = offsets[g], end = offsets[g + 1];
   if (end - j > *d_thresh) return;  // left to the heavy-bucket kernels
   XYZZ<F> acc = XYZZ<F>::zero();
+  __shared__ uint4 park_lds[C::ACC_PARK ? 256 * (C::ACC_PARK + 1) * (F::N / 4) : 1];  // ACC_PARK: see ParkedZ (ec.cuh)
+  const ParkedZ<F> parked{park_lds + threadIdx.x, 256};
+  bool inf = true;
   if (j < end) {
     // software pipeline, two deep on the indices: the gather of point t+1 (whose index arrived an iteration ago) and
     // the index of point t+2 are both in flight during the ~10 multiplications of addition t
@@ -293,7 +296,8 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
         F y = F::cond_neg(p.y, (e >> 31) != 0);
-        if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
+        if constexpr (C::ACC_PARK != 0) xyzz_madd_relaxed_parked<F, C::ACC_PARK == 2>(acc.x, acc.y, inf, parked, p.x, y);
+        else if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
       }
       if (!more) break;
@@ -301,6 +305,14 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
       e1 = e2;
       p = p_next;
       j++;
+    }
+  }
+  if constexpr (C::ACC_PARK != 0) {
+    if (inf) acc = XYZZ<F>::zero();
+    else {
+      acc.zz = parked.get(0);
+      acc.zzz = parked.get(1);
+      if constexpr (C::ACC_PARK == 2) acc.y = parked.get(2);
     }
   }
   if constexpr (C::RELAXED_A) acc = xyzz_canonical<F>(acc);
@@ -326,6 +338,9 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
   const u32 s = order ? order[t] : t;
   const u32 heavy_thresh = *d_thresh;
   Pt acc = Pt::zero();
+  __shared__ uint4 park_lds[C::ACC_PARK ? 256 * (C::ACC_PARK + 1) * (F::N / 4) : 1];  // ACC_PARK: ZZ / ZZZ of every lane's accumulator
+  const ParkedZ<F> parked{park_lds + threadIdx.x, 256};
+  bool inf = true;
   int w = 0;                    // next window to open
   u32 na = offsets[s], nb2 = offsets[s + 1];  // bounds of window w's run, fetched one window ahead
   u32 j = 0, end = 0;
@@ -375,7 +390,8 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
       }
       if (!p.is_zero()) {
         F y = F::cond_neg(p.y, (e >> 31) != 0);
-        if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
+        if constexpr (C::ACC_PARK != 0) xyzz_madd_relaxed_parked<F, C::ACC_PARK == 2>(acc.x, acc.y, inf, parked, p.x, y);
+        else if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
       }
       if (!have1) break;
@@ -384,6 +400,14 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
       e1 = e2;
       wb1 = wb2;
       have1 = have2;
+    }
+  }
+  if constexpr (C::ACC_PARK != 0) {
+    if (inf) acc = Pt::zero();
+    else {
+      acc.zz = parked.get(0);
+      acc.zzz = parked.get(1);
+      if constexpr (C::ACC_PARK == 2) acc.y = parked.get(2);
     }
   }
   if constexpr (C::RELAXED_A) acc = xyzz_canonical<F>(acc);
@@ -756,7 +780,12 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       const double red0_lat = 2.0 * 8.0 * 21e-6 * mul_cost;     // >= 8 buckets per lane at level 0
       if (red0_lat > red0) red0 = red0_lat;
       const double bits_stage = 0.5e-3 * mul_cost;              // bit-sliced stage + host tail
-      const double sort = entries * 2.0e-11 + (double)W * (double)(1u << (c - 1)) * 1.0e-10;
+      // partition sort: per entry, plus a per-(window, bucket) term.  On the shared path at n >= 2^23 the latter is
+      // measured nearly flat up to c = 22 (9 super-bucket bits + 12 bits finished in LDS, msm_part_split); beyond that the
+      // super-bucket histogram grows and so do both sort passes (2^25: c = 24 costs +2.8 ms of sort and +7 ms of
+      // reduction for -4.7 ms of accumulation; BN254 2^23 / 2^24: c = 22 beats 20 by 6-7 %; profiles/r2_msm_sweeps.txt)
+      const double per_bucket = (shared && n >= ((size_t)1 << 23) && c <= 22) ? 1.5e-11 : 1.0e-10;
+      const double sort = entries * 2.0e-11 + (double)W * (double)(1u << (c - 1)) * per_bucket;
       double cost = acc + red0 + bits_stage + sort;
       if (narrow == 0 && !shared) {
         // uniform widths: a top window with only a few significant bits funnels n/2^tb points into each of 2^tb
