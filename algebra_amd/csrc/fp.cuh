@@ -27,92 +27,99 @@ typedef uint64_t u64;
 #define ARK_HD __host__ __device__ __forceinline__
 
 // ---- 96-bit column accumulator --------------------------------------------------------------
+// One product step: {lo64, hi32} += A * B.  FIRST opens a column: the carry initialises the top word (0 + 0 + carry),
+// so the shift between columns needs no zeroing move.
+#define ARK_S(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+#define ARK_F(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc\n\t"
+// N steps in ONE asm statement (hipcc pads every asm statement boundary with wait states; a column of the product is
+// two statements: its a*b terms, its m*p terms).  Operands: %0 lo64, %1 hi32, then the N (x, y) pairs.
+#define ARK_T1 ARK_S(2, 3)
+#define ARK_T2 ARK_T1 ARK_S(4, 5)
+#define ARK_T3 ARK_T2 ARK_S(6, 7)
+#define ARK_T4 ARK_T3 ARK_S(8, 9)
+#define ARK_T5 ARK_T4 ARK_S(10, 11)
+#define ARK_T6 ARK_T5 ARK_S(12, 13)
+#define ARK_T7 ARK_T6 ARK_S(14, 15)
+#define ARK_T8 ARK_T7 ARK_S(16, 17)
+#define ARK_T9 ARK_T8 ARK_S(18, 19)
+#define ARK_T10 ARK_T9 ARK_S(20, 21)
+#define ARK_T11 ARK_T10 ARK_S(22, 23)
+#define ARK_T12 ARK_T11 ARK_S(24, 25)
+#define ARK_T13 ARK_T12 ARK_S(26, 27)
+#define ARK_I1 ARK_F(2, 3)
+#define ARK_I2 ARK_I1 ARK_S(4, 5)
+#define ARK_I3 ARK_I2 ARK_S(6, 7)
+#define ARK_I4 ARK_I3 ARK_S(8, 9)
+#define ARK_I5 ARK_I4 ARK_S(10, 11)
+#define ARK_I6 ARK_I5 ARK_S(12, 13)
+#define ARK_I7 ARK_I6 ARK_S(14, 15)
+#define ARK_I8 ARK_I7 ARK_S(16, 17)
+#define ARK_I9 ARK_I8 ARK_S(18, 19)
+#define ARK_I10 ARK_I9 ARK_S(20, 21)
+#define ARK_I11 ARK_I10 ARK_S(22, 23)
+#define ARK_I12 ARK_I11 ARK_S(24, 25)
+#define ARK_I13 ARK_I12 ARK_S(26, 27)
+// operand lists: x[LO + i] * y[K - LO - i] (both in VGPRs) / m[LO + i] * p[K - LO - i] (modulus limbs: SGPRs)
+#define ARK_OV(i) "v"(x[LO + i]), "v"(y[K - LO - i])
+#define ARK_OV1 ARK_OV(0)
+#define ARK_OV2 ARK_OV1, ARK_OV(1)
+#define ARK_OV3 ARK_OV2, ARK_OV(2)
+#define ARK_OV4 ARK_OV3, ARK_OV(3)
+#define ARK_OV5 ARK_OV4, ARK_OV(4)
+#define ARK_OV6 ARK_OV5, ARK_OV(5)
+#define ARK_OV7 ARK_OV6, ARK_OV(6)
+#define ARK_OV8 ARK_OV7, ARK_OV(7)
+#define ARK_OV9 ARK_OV8, ARK_OV(8)
+#define ARK_OV10 ARK_OV9, ARK_OV(9)
+#define ARK_OV11 ARK_OV10, ARK_OV(10)
+#define ARK_OV12 ARK_OV11, ARK_OV(11)
+#define ARK_OV13 ARK_OV12, ARK_OV(12)
+#define ARK_OP(i) "v"(x[LO + i]), "s"(PL<P, K - LO - i>::v)
+#define ARK_OP1 ARK_OP(0)
+#define ARK_OP2 ARK_OP1, ARK_OP(1)
+#define ARK_OP3 ARK_OP2, ARK_OP(2)
+#define ARK_OP4 ARK_OP3, ARK_OP(3)
+#define ARK_OP5 ARK_OP4, ARK_OP(4)
+#define ARK_OP6 ARK_OP5, ARK_OP(5)
+#define ARK_OP7 ARK_OP6, ARK_OP(6)
+#define ARK_OP8 ARK_OP7, ARK_OP(7)
+#define ARK_OP9 ARK_OP8, ARK_OP(8)
+#define ARK_OP10 ARK_OP9, ARK_OP(9)
+#define ARK_OP11 ARK_OP10, ARK_OP(10)
+#define ARK_OP12 ARK_OP11, ARK_OP(11)
+#define ARK_OP13 ARK_OP12, ARK_OP(12)
+#define ARK_STMT(n, STR, HI, OPS) \
+  if constexpr (HIX - LO + 1 == n) asm(STR##n : "+v"(c.lo), HI(c.hi) : OPS##n : "vcc")
+#define ARK_HI_RW "+v"
+#define ARK_HI_W "=&v"
+#define ARK_ALL(STR, HI, OPS)                                                                                         \
+  ARK_STMT(1, STR, HI, OPS); ARK_STMT(2, STR, HI, OPS); ARK_STMT(3, STR, HI, OPS); ARK_STMT(4, STR, HI, OPS);         \
+  ARK_STMT(5, STR, HI, OPS); ARK_STMT(6, STR, HI, OPS); ARK_STMT(7, STR, HI, OPS); ARK_STMT(8, STR, HI, OPS);         \
+  ARK_STMT(9, STR, HI, OPS); ARK_STMT(10, STR, HI, OPS); ARK_STMT(11, STR, HI, OPS); ARK_STMT(12, STR, HI, OPS);      \
+  ARK_STMT(13, STR, HI, OPS)
+
 struct Acc96 { u64 lo; u32 hi; };
-
-#define ARK_MAC "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-#define ARK_MAC2 ARK_MAC "\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-#define ARK_MAC3 ARK_MAC2 "\n\tv_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-#define ARK_MAC4 ARK_MAC3 "\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-#define ARK_MAC5 ARK_MAC4 "\n\tv_mad_u64_u32 %0, vcc, %10, %11, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-#define ARK_MAC6 ARK_MAC5 "\n\tv_mad_u64_u32 %0, vcc, %12, %13, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-#define ARK_MAC7 ARK_MAC6 "\n\tv_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-#define ARK_MAC8 ARK_MAC7 "\n\tv_mad_u64_u32 %0, vcc, %16, %17, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-
-ARK_DEV void mac_vv(Acc96& c, u32 a0, u32 b0) {
-  asm(ARK_MAC : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "v"(b0) : "vcc");
-}
-ARK_DEV void mac_vv2(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1) {
-  asm(ARK_MAC2 : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
-}
-ARK_DEV void mac_vv4(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3) {
-  asm(ARK_MAC4 : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3) : "vcc");
-}
-// eight products per statement: hipcc pads every asm statement boundary with an s_nop, so longer
-// statements mean fewer wait states in the multiply (61 -> ~35 per Fp384 product)
-ARK_DEV void mac_vv8(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3, u32 a4, u32 b4, u32 a5,
-                     u32 b5, u32 a6, u32 b6, u32 a7, u32 b7) {
-  asm(ARK_MAC8 : "+v"(c.lo), "+v"(c.hi)
-      : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
-        "v"(a6), "v"(b6), "v"(a7), "v"(b7)
-      : "vcc");
-}
-ARK_DEV void mac_vs8(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3, u32 a4, u32 b4, u32 a5,
-                     u32 b5, u32 a6, u32 b6, u32 a7, u32 b7) {
-  asm(ARK_MAC8 : "+v"(c.lo), "+v"(c.hi)
-      : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3), "v"(a4), "s"(b4), "v"(a5), "s"(b5),
-        "v"(a6), "s"(b6), "v"(a7), "s"(b7)
-      : "vcc");
-}
-// second operand wave-uniform (modulus limb) -> SGPR
-ARK_DEV void mac_vs(Acc96& c, u32 a0, u32 b0) {
-  asm(ARK_MAC : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "s"(b0) : "vcc");
-}
-ARK_DEV void mac_vs2(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1) {
-  asm(ARK_MAC2 : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "s"(b0), "v"(a1), "s"(b1) : "vcc");
-}
-ARK_DEV void mac_vs4(Acc96& c, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3) {
-  asm(ARK_MAC4 : "+v"(c.lo), "+v"(c.hi) : "v"(a0), "s"(b0), "v"(a1), "s"(b1), "v"(a2), "s"(b2), "v"(a3), "s"(b3) : "vcc");
-}
 ARK_DEV void acc_shift(Acc96& c) { c.lo = (c.lo >> 32) | ((u64)c.hi << 32); c.hi = 0; }
 
 // compile-time access to modulus limbs (keeps them immediates -> s_mov)
 template <class P, int I> struct PL { static constexpr u32 v = P::P[I]; };
 
-// c += sum_{i=LO..HI} x[i] * y[K-i]   (both operands in VGPRs)
-template <int LO, int HI, int K>
+// c += sum_{i=LO..HIX} x[i] * y[K-i]   (both operands in VGPRs); FIRST: these are the first terms of the column
+template <int LO, int HIX, int K, bool FIRST = false>
 ARK_DEV void col_vv(Acc96& c, const u32* x, const u32* y) {
-  if constexpr (HI - LO + 1 >= 8) {
-    mac_vv8(c, x[LO], y[K - LO], x[LO + 1], y[K - LO - 1], x[LO + 2], y[K - LO - 2], x[LO + 3], y[K - LO - 3], x[LO + 4],
-            y[K - LO - 4], x[LO + 5], y[K - LO - 5], x[LO + 6], y[K - LO - 6], x[LO + 7], y[K - LO - 7]);
-    col_vv<LO + 8, HI, K>(c, x, y);
-  } else if constexpr (HI - LO + 1 >= 4) {
-    mac_vv4(c, x[LO], y[K - LO], x[LO + 1], y[K - LO - 1], x[LO + 2], y[K - LO - 2], x[LO + 3], y[K - LO - 3]);
-    col_vv<LO + 4, HI, K>(c, x, y);
-  } else if constexpr (HI - LO + 1 >= 2) {
-    mac_vv2(c, x[LO], y[K - LO], x[LO + 1], y[K - LO - 1]);
-    col_vv<LO + 2, HI, K>(c, x, y);
-  } else if constexpr (HI - LO + 1 == 1) {
-    mac_vv(c, x[LO], y[K - LO]);
+  static_assert(HIX - LO + 1 <= 13, "one asm statement takes at most 13 products (30 operands)");
+  if constexpr (FIRST) {
+    static_assert(HIX >= LO, "a column opens with at least one product");
+    ARK_ALL(ARK_I, ARK_HI_W, ARK_OV);
+  } else {
+    ARK_ALL(ARK_T, ARK_HI_RW, ARK_OV);
   }
 }
-// c += sum_{i=LO..HI} m[i] * p[K-i]   (p = modulus, SGPR operands)
-template <class P, int LO, int HI, int K>
-ARK_DEV void col_vp(Acc96& c, const u32* m) {
-  if constexpr (HI - LO + 1 >= 8) {
-    mac_vs8(c, m[LO], PL<P, K - LO>::v, m[LO + 1], PL<P, K - LO - 1>::v, m[LO + 2], PL<P, K - LO - 2>::v, m[LO + 3],
-            PL<P, K - LO - 3>::v, m[LO + 4], PL<P, K - LO - 4>::v, m[LO + 5], PL<P, K - LO - 5>::v, m[LO + 6],
-            PL<P, K - LO - 6>::v, m[LO + 7], PL<P, K - LO - 7>::v);
-    col_vp<P, LO + 8, HI, K>(c, m);
-  } else if constexpr (HI - LO + 1 >= 4) {
-    mac_vs4(c, m[LO], PL<P, K - LO>::v, m[LO + 1], PL<P, K - LO - 1>::v, m[LO + 2], PL<P, K - LO - 2>::v, m[LO + 3],
-            PL<P, K - LO - 3>::v);
-    col_vp<P, LO + 4, HI, K>(c, m);
-  } else if constexpr (HI - LO + 1 >= 2) {
-    mac_vs2(c, m[LO], PL<P, K - LO>::v, m[LO + 1], PL<P, K - LO - 1>::v);
-    col_vp<P, LO + 2, HI, K>(c, m);
-  } else if constexpr (HI - LO + 1 == 1) {
-    mac_vs(c, m[LO], PL<P, K - LO>::v);
-  }
+// c += sum_{i=LO..HIX} m[i] * p[K-i]   (p = modulus, SGPR operands)
+template <class P, int LO, int HIX, int K>
+ARK_DEV void col_vp(Acc96& c, const u32* x) {
+  static_assert(HIX - LO + 1 <= 13, "one asm statement takes at most 13 products (30 operands)");
+  ARK_ALL(ARK_T, ARK_HI_RW, ARK_OP);
 }
 // squaring column: c += sum_{i+j=K, i<j} 2*a[i]*a[j] + (K even ? a[K/2]^2 : 0), done as doubled operand d[] = 2a
 // (not used yet: mul(a,a) is the square in this round)
@@ -120,17 +127,17 @@ ARK_DEV void col_vp(Acc96& c, const u32* m) {
 template <class P, int K>
 ARK_DEV void mont_cols_lo(Acc96& c, const u32* a, const u32* b, u32* m) {
   constexpr int N = P::N;
-  col_vv<0, K, K>(c, a, b);
+  col_vv<0, K, K, true>(c, a, b);
   col_vp<P, 0, K - 1, K>(c, m);
   m[K] = (u32)c.lo * P::INV;
-  mac_vs(c, m[K], PL<P, 0>::v);
+  col_vp<P, K, K, K>(c, m);
   acc_shift(c);
   if constexpr (K + 1 < N) mont_cols_lo<P, K + 1>(c, a, b, m);
 }
 template <class P, int K>
 ARK_DEV void mont_cols_hi(Acc96& c, const u32* a, const u32* b, const u32* m, u32* t) {
   constexpr int N = P::N;
-  col_vv<K - N + 1, N - 1, K>(c, a, b);
+  col_vv<K - N + 1, N - 1, K, true>(c, a, b);
   col_vp<P, K - N + 1, N - 1, K>(c, m);
   t[K - N] = (u32)c.lo;
   acc_shift(c);
@@ -143,18 +150,18 @@ ARK_DEV void mont_cols_hi(Acc96& c, const u32* a, const u32* b, const u32* m, u3
 template <class P, int K>
 ARK_DEV void mont2_cols_lo(Acc96& c, const u32* a, const u32* b, const u32* a2, const u32* b2, u32* m) {
   constexpr int N = P::N;
-  col_vv<0, K, K>(c, a, b);
+  col_vv<0, K, K, true>(c, a, b);
   col_vv<0, K, K>(c, a2, b2);
   col_vp<P, 0, K - 1, K>(c, m);
   m[K] = (u32)c.lo * P::INV;
-  mac_vs(c, m[K], PL<P, 0>::v);
+  col_vp<P, K, K, K>(c, m);
   acc_shift(c);
   if constexpr (K + 1 < N) mont2_cols_lo<P, K + 1>(c, a, b, a2, b2, m);
 }
 template <class P, int K>
 ARK_DEV void mont2_cols_hi(Acc96& c, const u32* a, const u32* b, const u32* a2, const u32* b2, const u32* m, u32* t) {
   constexpr int N = P::N;
-  col_vv<K - N + 1, N - 1, K>(c, a, b);
+  col_vv<K - N + 1, N - 1, K, true>(c, a, b);
   col_vv<K - N + 1, N - 1, K>(c, a2, b2);
   col_vp<P, K - N + 1, N - 1, K>(c, m);
   t[K - N] = (u32)c.lo;
@@ -166,20 +173,20 @@ ARK_DEV void mont2_cols_hi(Acc96& c, const u32* a, const u32* b, const u32* a2, 
 template <class P, int K>
 ARK_DEV void mont4_cols_lo(Acc96& c, const u32* const* x, const u32* const* y, u32* m) {
   constexpr int N = P::N;
-  col_vv<0, K, K>(c, x[0], y[0]);
+  col_vv<0, K, K, true>(c, x[0], y[0]);
   col_vv<0, K, K>(c, x[1], y[1]);
   col_vv<0, K, K>(c, x[2], y[2]);
   col_vv<0, K, K>(c, x[3], y[3]);
   col_vp<P, 0, K - 1, K>(c, m);
   m[K] = (u32)c.lo * P::INV;
-  mac_vs(c, m[K], PL<P, 0>::v);
+  col_vp<P, K, K, K>(c, m);
   acc_shift(c);
   if constexpr (K + 1 < N) mont4_cols_lo<P, K + 1>(c, x, y, m);
 }
 template <class P, int K>
 ARK_DEV void mont4_cols_hi(Acc96& c, const u32* const* x, const u32* const* y, const u32* m, u32* t) {
   constexpr int N = P::N;
-  col_vv<K - N + 1, N - 1, K>(c, x[0], y[0]);
+  col_vv<K - N + 1, N - 1, K, true>(c, x[0], y[0]);
   col_vv<K - N + 1, N - 1, K>(c, x[1], y[1]);
   col_vv<K - N + 1, N - 1, K>(c, x[2], y[2]);
   col_vv<K - N + 1, N - 1, K>(c, x[3], y[3]);

@@ -44,6 +44,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # (profiles/r1_ubench_instruction_rates.txt, line 1); a Montgomery Fp384 product needs 2 * 12^2 = 288 of them
 MAD_U64_U32_PER_S = 27.73e12
 MADS_PER_MIXED_ADD = 8 * 288 + 432  # 8 products + one sum of two products under a single reduction (ec.cuh)
+# the same Montgomery product (fp.cuh's Comba with its carry chains) run back to back in a loop: the rate the multiplier
+# pipeline sustains for THIS instruction mix (profiles/r1_ubench_instruction_rates.txt, "Fp384 Comba (asm mac)")
+COMBA384_GMUL_S_2_WAVES = 53.99   # 2 waves per SIMD -- the accumulate kernel's occupancy (204-208 VGPRs)
+COMBA384_GMUL_S_PEAK = 58.72      # 8 waves per SIMD
 limbs4 = S.limbs4
 
 
@@ -414,7 +418,15 @@ def main():
                                          "instruction's measured issue rate on this chip" % MADS_PER_MIXED_ADD,
                                  "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
                                  "frac": mads_per_s / MAD_U64_U32_PER_S,
-                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32)"},
+                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32)",
+                                 "montgomery_products": {
+                                     "what": "the same work in Fp384 Montgomery products (288 multiply-adds each) vs the "
+                                             "rate of that product alone in a tight loop: what is left above the kernel "
+                                             "is the product's own carry handling, not the kernel around it",
+                                     "achieved_gmul_s": mads_per_s / 288.0 / 1e9,
+                                     "loop_rate_at_kernel_occupancy_gmul_s": COMBA384_GMUL_S_2_WAVES,
+                                     "loop_rate_peak_gmul_s": COMBA384_GMUL_S_PEAK,
+                                     "frac_of_peak": mads_per_s / 288.0 / 1e9 / COMBA384_GMUL_S_PEAK}},
                          "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
             "cpu_baseline": cpu,
             "plain": plain,
