@@ -142,7 +142,8 @@ ARK_HD void xyzz_madd(XYZZ<F>& acc, const F& x2, const F& y2) {
 }
 
 // The same mixed addition on relaxed residues (Fp::mul_r & co., values in [0, 2p)): the bucket-accumulation loop
-// of the MSM.  (x2, y2) canonical; acc's coordinates relaxed, except that infinity is the exact (1, 1, 0, 0).
+// of the MSM.  x2 canonical, y2 canonical or the relaxed negation 2p - y (F::neg_r); acc's coordinates relaxed, except
+// that infinity is the exact (1, 1, 0, 0).
 template <class F>
 ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
   if (acc.is_zero()) {
@@ -154,7 +155,7 @@ ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
   const bool pz = p.is_zero_mod_p();  // evaluated unconditionally: over a lane pair (Fp2Half) a test is an exchange
   const bool rz = r.is_zero_mod_p();
   if (pz) {
-    if (rz) acc = xyzz_mdbl<F>(x2, y2);   // canonical arithmetic; rare
+    if (rz) acc = xyzz_mdbl<F>(x2, y2.canonical());   // canonical arithmetic (y2 may be the relaxed 2p - y); rare
     else acc = XYZZ<F>::zero();
     return;
   }
@@ -210,7 +211,7 @@ ARK_DEV void xyzz_madd_relaxed_parked(F& ax, F& ay, bool& inf, const ParkedZ<F>&
   const bool rz = r.is_zero_mod_p();
   if (pz) {
     if (rz) {
-      XYZZ<F> d = xyzz_mdbl<F>(x2, y2);
+      XYZZ<F> d = xyzz_mdbl<F>(x2, y2.canonical());
       ax = d.x; z.put(0, d.zz); z.put(1, d.zzz);
       if constexpr (PARK_Y) z.put(2, d.y); else ay = d.y;
       inf = d.is_zero();

@@ -530,6 +530,7 @@ struct Fp {
     return r;
   }
   ARK_HD bool is_zero_mod_p() const {  // relaxed value: 0 or p
+    if (l[0] != 0 && l[0] != (u32)P::P[0]) return false;  // almost always decided by the low limb (2 compares, not 2N)
     u32 o = 0, q = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -538,7 +539,9 @@ struct Fp {
     }
     return o == 0 || q == 0;
   }
-  ARK_HD Fp canonical() const { return reduce_once(l); }
+  // relaxed value in [0, 2p] -> [0, p).  Two conditional subtractions: 2p itself occurs (neg_r of a zero component of
+  // an Fp2 coordinate); only used where residues leave the relaxed domain (end of a kernel, the rare doubling branch)
+  ARK_HD Fp canonical() const { return reduce_once(reduce_once(l).l); }
   // Out-of-line copy for the extension-field formulas: an XYZZ addition over Fp2 would otherwise inline ~40 copies
   // of this 700-instruction sequence (minutes of compile time per kernel, scratch spills).  Operands travel by value
   // so the AMDGPU calling convention keeps them in VGPRs.

@@ -295,7 +295,9 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
         if (j + 2 < end) e2 = sorted[j + 2];
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
-        F y = F::cond_neg(p.y, (e >> 31) != 0);
+        F y = p.y;  // negative digit: -P.  On relaxed residues 2p - y serves (a multiplication operand; no zero test)
+        if constexpr (C::RELAXED_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
+        else y = F::cond_neg(p.y, (e >> 31) != 0);
         if constexpr (C::ACC_PARK != 0) xyzz_madd_relaxed_parked<F, C::ACC_PARK == 2>(acc.x, acc.y, inf, parked, p.x, y);
         else if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
@@ -389,7 +391,9 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
         have2 = next_entry(e2, wb2);
       }
       if (!p.is_zero()) {
-        F y = F::cond_neg(p.y, (e >> 31) != 0);
+        F y = p.y;  // negative digit: -P.  On relaxed residues 2p - y serves (a multiplication operand; no zero test)
+        if constexpr (C::RELAXED_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
+        else y = F::cond_neg(p.y, (e >> 31) != 0);
         if constexpr (C::ACC_PARK != 0) xyzz_madd_relaxed_parked<F, C::ACC_PARK == 2>(acc.x, acc.y, inf, parked, p.x, y);
         else if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
@@ -541,7 +545,9 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
         u32 e = sorted[j];
         Affine<F> p = Affine<F>::load(wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
         if (!p.is_zero()) {
-          F y = F::cond_neg(p.y, (e >> 31) != 0);
+          F y = p.y;  // negative digit: -P.  On relaxed residues 2p - y serves (a multiplication operand; no zero test)
+          if constexpr (C::RELAXED_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
+          else y = F::cond_neg(p.y, (e >> 31) != 0);
           Ops::madd(acc, p.x, y);
         }
       }
@@ -970,7 +976,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   u32 chunk = (size_t)Wr * Q * ((m + 4095) / 4096) < 512 ? 1024 : 4096;
   if (const char* ec = getenv("ARK_HIP_MSM_CHUNK")) {
     int v = atoi(ec);
-    if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) chunk = (u32)v;
+    if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096 || v == 8192 || v == 16384) chunk = (u32)v;
   }
   if (chunk > m) chunk = (u32)m;
   const u32 nchunks = (u32)((m + chunk - 1) / chunk);

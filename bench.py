@@ -45,9 +45,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MAD_U64_U32_PER_S = 27.73e12
 MADS_PER_MIXED_ADD = 8 * 288 + 432  # 8 products + one sum of two products under a single reduction (ec.cuh)
 # the same Montgomery product (fp.cuh's Comba with its carry chains) run back to back in a loop: the rate the multiplier
-# pipeline sustains for THIS instruction mix (profiles/r1_ubench_instruction_rates.txt, "Fp384 Comba (asm mac)")
-COMBA384_GMUL_S_2_WAVES = 53.99   # 2 waves per SIMD -- the accumulate kernel's occupancy (204-208 VGPRs)
-COMBA384_GMUL_S_PEAK = 58.72      # 8 waves per SIMD
+# pipeline sustains for THIS instruction mix (profiles/r2_ubench_product_rate.txt, algebra_amd/csrc/ubench/mulbench.hip)
+COMBA384_GMUL_S_2_WAVES = 54.73   # 2 waves per SIMD -- the accumulate kernel's occupancy (214-220 VGPRs)
+COMBA384_GMUL_S_PEAK = 61.78      # 8 waves per SIMD
 limbs4 = S.limbs4
 
 
