@@ -1132,6 +1132,29 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   return slot;
 }
 
+// The caller sits on the critical path of its prover: poll the completion event instead of sleeping on it (a blocked
+// host thread was measured to wake up ~1 ms after a 38 ms job on some hosts; short jobs never sleep anyway).
+// ARK_HIP_WAIT=block restores hipEventSynchronize (frees the core while the GPU works).
+static inline hipError_t msm_wait_event(hipEvent_t ev) {
+  static const bool block = [] {
+    const char* e = getenv("ARK_HIP_WAIT");
+    return e && e[0] == 'b';
+  }();
+  if (block) return hipEventSynchronize(ev);
+  bool polled = false;
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) {
+      if (polled) (void)hipGetLastError();  // "not ready" is not an error: do not leave it behind as the thread's last one
+      return e;
+    }
+    polled = true;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
+
 // Wait for job `slot` and finish it on the host: out_xyz = Jacobian x|y|z Montgomery limbs (group.rs:34-41);
 // identity = (R, R, 0) (group.rs:145-151).  Releases the slot.
 template <class C>
@@ -1153,7 +1176,7 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     Jac<F>::zero().store(out_xyz);
     return 0;
   }
-  ARK_HIP_TRY(hipEventSynchronize(job.done));
+  ARK_HIP_TRY(msm_wait_event(job.done));
   const MsmPlan& pl = job.pl;
   const int c = pl.c, W = pl.W, Wr = pl.red_windows(), nbits = job.nbits;
   const u32 Q = job.Q;
