@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(128) batchmul_table_kernel(const char* __restr
   y.store(table + (size_t)t * Affine<F>::BYTES + F::BYTES);
 }
 
-// out[i] = scalars[i] * g: windowed_mul (mod.rs:235-251) + into_affine
+// tmp[i] = scalars[i] * g in XYZZ form: windowed_mul (mod.rs:235-251); batchmul_run normalises the batch afterwards
+// (normalize_batch, :226 -- lane-batched inversion, ec.cuh)
 template <class C>
 __global__ void __launch_bounds__(128) batchmul_kernel(const char* __restrict__ table, const u32* __restrict__ scalars, size_t n,
                                                        int mont, char* __restrict__ out) {
@@ -75,15 +76,7 @@ __global__ void __launch_bounds__(128) batchmul_kernel(const char* __restrict__ 
       xyzz_madd<F>(acc, p.x, p.y);
     }
   }
-  F x = F::zero(), y = F::zero();
-  if (!acc.is_zero()) {
-    F zzzi = F::inverse(acc.zzz);
-    F zzi = F::sqr(F::mul(acc.zz, zzzi));
-    x = F::mul(acc.x, zzi);
-    y = F::mul(acc.y, zzzi);
-  }
-  x.store(out + i * Affine<F>::BYTES);
-  y.store(out + i * Affine<F>::BYTES + F::BYTES);
+  acc.store(out + i * XYZZ<F>::BYTES);
 }
 
 // table: BATCHMUL_OUTER << BATCHMUL_WINDOW affine entries; scratch: BATCHMUL_OUTER XYZZ points
@@ -97,10 +90,12 @@ int batchmul_build(const void* d_base_affine, void* d_scratch, void* d_table, hi
   return 0;
 }
 template <class C>
-int batchmul_run(const void* d_table, const void* d_scalars, size_t n, int mont, void* d_out, hipStream_t stream) {
+int batchmul_run(const void* d_table, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out,
+                 hipStream_t stream) {  // d_tmp: n XYZZ points of scratch
   if (n == 0) return 0;
   hipLaunchKernelGGL((batchmul_kernel<C>), dim3((u32)((n + 127) / 128)), dim3(128), 0, stream, (const char*)d_table,
-                     (const u32*)d_scalars, n, mont, (char*)d_out);
+                     (const u32*)d_scalars, n, mont, (char*)d_tmp);
+  xyzz_to_affine_batched_launch<typename C::F>(d_tmp, d_out, n, stream);
   ARK_HIP_TRY(hipGetLastError());
   return 0;
 }

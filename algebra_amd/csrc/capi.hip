@@ -144,8 +144,8 @@ int msm_finish_dispatch(int curve, MsmWorkspace& ws, int slot, uint64_t* out, Ms
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
-int msm_prepare_dispatch(int curve, const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, hipStream_t st) {
-#define X(NAME) msm_prepare_##NAME(d_bases, n, pl, d_table, st)
+int msm_prepare_dispatch(int curve, const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t st) {
+#define X(NAME) msm_prepare_##NAME(d_bases, n, pl, d_table, d_tmp, st)
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
@@ -154,8 +154,8 @@ int batchmul_build_dispatch(int curve, const void* d_base, void* d_scratch, void
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
-int batchmul_run_dispatch(int curve, const void* d_table, const void* d_scalars, size_t n, int mont, void* d_out, hipStream_t st) {
-#define X(NAME) batchmul_run_##NAME(d_table, d_scalars, n, mont, d_out, st)
+int batchmul_run_dispatch(int curve, const void* d_table, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t st) {
+#define X(NAME) batchmul_run_##NAME(d_table, d_scalars, n, mont, d_tmp, d_out, st)
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
@@ -638,8 +638,12 @@ int ark_hip_msm_bases_prepare_device(int curve, const void* d_bases, size_t n, a
       delete pb;
       return ARK_HIP_ERR_NOMEM;
     }
-    int rc = msm_prepare_dispatch(curve, d_bases, n, pb->plan, pb->table.p, c->stream);
+    DevBuf tmp;  // one unnormalised (XYZZ) row: twice an affine row, released once the table stands
+    int rc = tmp.ensure(2 * row) ? ARK_HIP_ERR_NOMEM : 0;
+    if (rc == 0) rc = msm_prepare_dispatch(curve, d_bases, n, pb->plan, pb->table.p, tmp.p, c->stream);
     if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = -1000;
+    else if (rc) (void)hipStreamSynchronize(c->stream);
+    tmp.release();
     if (rc) {
       pb->table.release();
       delete pb;
@@ -875,7 +879,9 @@ int ark_hip_batch_mul_device(const ark_hip_batch_mul_table* table, const void* d
   const BatchMulTable* t = (const BatchMulTable*)table;
   Scope sc;
   if (int rc = sc.enter(t->logical)) return rc;
-  int rc = batchmul_run_dispatch(t->curve, t->table.p, d_scalars, n, mont, d_out_xy, sc.c->stream);
+  if (n == 0) return 0;
+  if (sc.c->stage_c.ensure(n * 2 * (size_t)CURVES[t->curve].fe_words * 16)) return ARK_HIP_ERR_NOMEM;  // XYZZ scratch
+  int rc = batchmul_run_dispatch(t->curve, t->table.p, d_scalars, n, mont, sc.c->stage_c.p, d_out_xy, sc.c->stream);
   if (rc) return rc;
   ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
   return 0;
@@ -888,9 +894,9 @@ int ark_hip_batch_mul(const ark_hip_batch_mul_table* table, const uint64_t* scal
   Context* c = sc.c;
   const size_t ab = (size_t)CURVES[t->curve].fe_words * 16;
   if (n == 0) return 0;
-  if (c->stage_a.ensure(n * 32) || c->stage_b.ensure(n * ab)) return ARK_HIP_ERR_NOMEM;
+  if (c->stage_a.ensure(n * 32) || c->stage_b.ensure(n * ab) || c->stage_c.ensure(n * 2 * ab)) return ARK_HIP_ERR_NOMEM;
   ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  int rc = batchmul_run_dispatch(t->curve, t->table.p, c->stage_a.p, n, mont, c->stage_b.p, c->stream);
+  int rc = batchmul_run_dispatch(t->curve, t->table.p, c->stage_a.p, n, mont, c->stage_c.p, c->stage_b.p, c->stream);
   if (rc) return rc;
   ARK_HIP_TRY(hipMemcpyAsync(out_xy, c->stage_b.p, n * ab, hipMemcpyDeviceToHost, c->stream));
   ARK_HIP_TRY(hipStreamSynchronize(c->stream));

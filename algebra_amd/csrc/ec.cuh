@@ -80,6 +80,78 @@ struct Jac {
   }
 };
 
+// ---- Montgomery's trick inside one lane (ff/src/fields/mod.rs:358-385 batch_inversion) -----------------------------
+// A lane owns the B values z_j = get_z(t + j * stride), j < B (index < n): one pass multiplies them up (zeros skipped,
+// as the reference does), ONE Fermat inversion (~1.5 N log2(p) products) inverts the product, a second pass in reverse
+// order peels off the individual inverses: 3 products per value + 1/B of an inversion instead of one inversion each.
+// Consecutive lanes own consecutive indices (stride = number of lanes), so every pass is a coalesced sweep.
+// emit(index, z_inverse, nonzero) is called once per owned index, in descending j.
+template <class F, int B, class GetZ, class Emit>
+ARK_DEV void lane_batch_inverse(size_t t, size_t stride, size_t n, GetZ get_z, Emit emit) {
+  F pre[B];
+  u32 nzmask = 0;
+  F run = F::one();
+#pragma unroll
+  for (int j = 0; j < B; j++) {
+    const size_t i = t + (size_t)j * stride;
+    if (i < n) {
+      const F z = get_z(i);
+      if (!z.is_zero()) {
+        run = F::mul(run, z);
+        nzmask |= 1u << j;
+      }
+    }
+    pre[j] = run;
+  }
+  F inv = F::inverse(run);
+#pragma unroll
+  for (int j = B - 1; j >= 0; j--) {
+    const size_t i = t + (size_t)j * stride;
+    if (i < n) {
+      if ((nzmask >> j) & 1u) {
+        const F z = get_z(i);
+        const F zi = j > 0 ? F::mul(inv, pre[j > 0 ? j - 1 : 0]) : inv;
+        inv = F::mul(inv, z);
+        emit(i, zi, true);
+      } else {
+        emit(i, F::zero(), false);
+      }
+    }
+  }
+}
+// values per lane: bounded by the registers the B running products take (B * limbs)
+template <class F> struct LaneBatch { static constexpr int B = F::BYTES > 64 ? 4 : 8; };
+
+// XYZZ (x, y, zz, zzz) -> affine (x / zz, y / zzz), identity -> (0, 0), with the lane-batched inversion above
+// (ZZ^-1 = (ZZ * ZZZ^-1)^2 since ZZ^3 = ZZZ^2).  in: n * XYZZ::BYTES, out: n * Affine::BYTES.
+template <class F>
+__global__ void __launch_bounds__(128) xyzz_to_affine_batched_kernel(const char* __restrict__ in, char* __restrict__ out,
+                                                                     size_t n, size_t lanes) {
+  constexpr int B = LaneBatch<F>::B;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lanes) return;
+  lane_batch_inverse<F, B>(
+      t, lanes, n, [&](size_t i) { return F::load(in + i * XYZZ<F>::BYTES + 3 * F::BYTES); },
+      [&](size_t i, const F& zzzi, bool nonzero) {
+        F x = F::zero(), y = F::zero();
+        if (nonzero) {
+          const char* p = in + i * XYZZ<F>::BYTES;
+          const F zzi = F::sqr(F::mul(F::load(p + 2 * F::BYTES), zzzi));
+          x = F::mul(F::load(p), zzi);
+          y = F::mul(F::load(p + F::BYTES), zzzi);
+        }
+        x.store(out + i * Affine<F>::BYTES);
+        y.store(out + i * Affine<F>::BYTES + F::BYTES);
+      });
+}
+template <class F>
+static inline void xyzz_to_affine_batched_launch(const void* d_xyzz, void* d_affine, size_t n, hipStream_t stream) {
+  constexpr int B = LaneBatch<F>::B;
+  const size_t lanes = (n + B - 1) / B;
+  hipLaunchKernelGGL((xyzz_to_affine_batched_kernel<F>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, stream,
+                     (const char*)d_xyzz, (char*)d_affine, n, lanes);
+}
+
 // affine doubling into XYZZ (mdbl-2008-s-1, a = 0)            affine.rs:169-201
 template <class F>
 ARK_HD XYZZ<F> xyzz_mdbl(const F& x1, const F& y1) {

@@ -418,7 +418,8 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
   acc.store(buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * Pt::BYTES);
 }
 
-// T_{w+1}[i] = 2^width * T_w[i], affine in / affine out (one Fermat inversion per point; a one-time cost per base set)
+// T_{w+1}[i] = 2^width * T_w[i]: affine in, XYZZ out (msm_prepare_table normalises a whole row with the lane-batched
+// inversion of ec.cuh -- one Fermat inversion per 8 points instead of one per point; a one-time cost per base set)
 template <class C>
 __global__ void __launch_bounds__(128) msm_table_step_kernel(const char* __restrict__ in, char* __restrict__ out, size_t n,
                                                              int width) {
@@ -426,19 +427,12 @@ __global__ void __launch_bounds__(128) msm_table_step_kernel(const char* __restr
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> p = Affine<F>::load(in + i * Affine<F>::BYTES);
-  F x = F::zero(), y = F::zero();
+  XYZZ<F> acc = XYZZ<F>::zero();
   if (!p.is_zero()) {
-    XYZZ<F> acc = xyzz_mdbl<F>(p.x, p.y);
+    acc = xyzz_mdbl<F>(p.x, p.y);
     for (int k = 1; k < width; k++) acc = xyzz_dbl<F>(acc);
-    if (!acc.is_zero()) {
-      F zzzi = F::inverse(acc.zzz);
-      F zzi = F::sqr(F::mul(acc.zz, zzzi));  // ZZ^-1 = (ZZ * ZZZ^-1)^2 since ZZ^3 = ZZZ^2
-      x = F::mul(acc.x, zzi);
-      y = F::mul(acc.y, zzzi);
-    }
   }
-  x.store(out + i * Affine<F>::BYTES);
-  y.store(out + i * Affine<F>::BYTES + F::BYTES);
+  acc.store(out + i * XYZZ<F>::BYTES);
 }
 
 // ---- K4h: heavy buckets --------------------------------------------------------------------------
@@ -1222,15 +1216,16 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
 // Build the table of per-window multiples for a fixed base set: table[w][i] = 2^(offset_w) * bases[i], affine,
 // w < pl.W, row stride n.  `table` must hold pl.W * n affine points.  Asynchronous on `stream`.
 template <class C>
-int msm_prepare_table(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, hipStream_t stream) {
-  typedef typename C::F F;
+int msm_prepare_table(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream) {
+  typedef typename C::F F;  // d_tmp: n * XYZZ<F>::BYTES of scratch (one unnormalised row)
   const size_t row = n * Affine<F>::BYTES;
   if (n == 0) return 0;
   ARK_HIP_TRY(hipMemcpyAsync(d_table, d_bases, row, hipMemcpyDeviceToDevice, stream));
   for (int w = 0; w + 1 < pl.W; w++) {
     const int width = msm_window_width(w, pl.c, pl.W, pl.narrow);
     hipLaunchKernelGGL((msm_table_step_kernel<C>), dim3((u32)((n + 127) / 128)), dim3(128), 0, stream,
-                       (const char*)d_table + (size_t)w * row, (char*)d_table + (size_t)(w + 1) * row, n, width);
+                       (const char*)d_table + (size_t)w * row, (char*)d_tmp, n, width);
+    xyzz_to_affine_batched_launch<F>(d_tmp, (char*)d_table + (size_t)(w + 1) * row, n, stream);
   }
   ARK_HIP_TRY(hipGetLastError());
   return 0;

@@ -103,31 +103,34 @@ int sw_add_affine_launch(const void* in, void* out, size_t n, const void* d_delt
 }
 
 // CurveGroup::normalize_batch on the device (group.rs:302-319): Jacobian (x, y, z) -> affine (x/z^2, y/z^3), identity
-// -> (0, 0).  One Fermat inversion per point (the reference amortises one inversion over the batch with
-// Montgomery's trick on the CPU; per-lane exponentiation is the data-parallel equivalent).
+// -> (0, 0).  The reference amortises ONE inversion over the whole batch with Montgomery's trick
+// (ff/src/fields/mod.rs:358-385); here every lane does the same over its own 8 (Fp2: 4) points -- lane_batch_inverse, ec.cuh.
 template <class C>
 __global__ void __launch_bounds__(128) sw_normalize_batch_kernel(const char* __restrict__ in, char* __restrict__ out,
-                                                                 size_t n) {
+                                                                 size_t n, size_t lanes) {
   typedef typename C::F F;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const char* p = in + i * 3 * F::BYTES;
-  F x = F::load(p), y = F::load(p + F::BYTES), z = F::load(p + 2 * F::BYTES);
-  F ax = F::zero(), ay = F::zero();
-  if (!z.is_zero()) {
-    F zi = F::inverse(z);
-    F zi2 = F::sqr(zi);
-    ax = F::mul(x, zi2);
-    ay = F::mul(y, F::mul(zi2, zi));
-  }
-  ax.store(out + i * 2 * F::BYTES);
-  ay.store(out + i * 2 * F::BYTES + F::BYTES);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lanes) return;
+  lane_batch_inverse<F, LaneBatch<F>::B>(
+      t, lanes, n, [&](size_t i) { return F::load(in + i * 3 * F::BYTES + 2 * F::BYTES); },
+      [&](size_t i, const F& zi, bool nonzero) {
+        F ax = F::zero(), ay = F::zero();
+        if (nonzero) {
+          const char* p = in + i * 3 * F::BYTES;
+          const F zi2 = F::sqr(zi);
+          ax = F::mul(F::load(p), zi2);
+          ay = F::mul(F::load(p + F::BYTES), F::mul(zi2, zi));
+        }
+        ax.store(out + i * 2 * F::BYTES);
+        ay.store(out + i * 2 * F::BYTES + F::BYTES);
+      });
 }
 template <class C>
 int sw_normalize_batch_launch(const void* in, void* out, size_t n, hipStream_t s) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL((sw_normalize_batch_kernel<C>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s,
-                     (const char*)in, (char*)out, n);
+  const size_t lanes = (n + LaneBatch<typename C::F>::B - 1) / LaneBatch<typename C::F>::B;
+  hipLaunchKernelGGL((sw_normalize_batch_kernel<C>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, s,
+                     (const char*)in, (char*)out, n, lanes);
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
