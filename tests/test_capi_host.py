@@ -165,3 +165,11 @@ def test_msm_plan_is_host_only_and_sane():
                 assert got[0][0] >= prev
                 prev = got[0][0]
     assert L.ark_hip_msm_plan(7, 100, 0, None, None) == -1
+    # window sizes that were measured to be the fastest on MI355X (profiles/r2_msm_sweeps.txt): a change of the planner's
+    # cost model must not silently move them
+    measured = {(1, 24, 0): (20, 13), (1, 24, 1): (22, 12), (1, 25, 1): (22, 12), (1, 26, 1): (24, 11), (1, 23, 1): (22, 12),
+                (1, 20, 1): (19, 14), (1, 16, 1): (17, 15), (0, 24, 1): (22, 12), (0, 23, 1): (22, 12), (3, 22, 1): (20, 13)}
+    for (curve, logn, prepared), want in measured.items():
+        c, w = C.c_int(), C.c_int()
+        assert L.ark_hip_msm_plan(curve, 1 << logn, prepared, C.byref(c), C.byref(w)) == 0
+        assert (c.value, w.value) == want, (curve, logn, prepared, c.value, w.value)
