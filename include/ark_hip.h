@@ -20,7 +20,7 @@
  * and holds that context's lock for its whole body, so any number of host threads (rayon workers) may call
  * concurrently: calls on one GPU serialise, calls on different GPUs overlap.  One process per GPU
  * (torch.distributed / RCCL) and one process driving all GPUs (ark_hip_msm_sw_multi) are both supported.
- * Limits: MSM n < 2^31 and n * windows < 2^32 (n <= 2^27 for 255-bit scalars); FFT log2(size) <= 30.
+ * Limits: MSM n < 2^31 and n * windows < 2^32 (n <= 2^28 for 255-bit scalars; 2^28 is tested); FFT log2(size) <= 30.
  * Environment: ARK_HIP_WAIT=block makes an MSM wait for the GPU with a blocking hipEventSynchronize; by default the
  * calling thread polls the completion event (the MSM is on its caller's critical path; a sleeping thread was measured
  * to add up to 1 ms per call on some hosts).  ARK_HIP_MSM_C / ARK_HIP_MSM_C_PREPARED force the window size (tuning).

@@ -50,25 +50,26 @@ def gen_scalars(n, seed, r):
     return out
 
 
-def _exact_sum(x):
-    """exact integer sum of a uint64 array whose entries are < 2^58 (chunks of 32 stay < 2^63)."""
-    pad = (-x.size) % 32
+def _exact_sum(x, chunk=32):
+    """exact integer sum of a uint64 array whose entries are < 2^63 / chunk (a chunk's sum stays < 2^63)."""
+    pad = (-x.size) % chunk
     if pad:
         x = np.concatenate([x, np.zeros(pad, dtype=np.uint64)])
-    return int(x.reshape(-1, 32).sum(axis=1, dtype=np.uint64).astype(object).sum())
+    return int(x.reshape(-1, chunk).sum(axis=1, dtype=np.uint64).astype(object).sum())
 
 
 def dlog_of_msm(scalars, a, b, r, first_index=0):
     """k = sum_i s_i (a + (first_index + i) b) mod r, exact: the discrete log of the MSM of P_i = (a + i b)G."""
     n = scalars.shape[0]
-    idx = np.arange(n, dtype=np.uint64)  # n <= 2^26: idx * 32-bit half < 2^58
+    assert n <= 1 << 29
+    idx = np.arange(n, dtype=np.uint64)  # idx * 32-bit half < 2^61: summed in chunks of 4 (2^28 pairs overflowed chunks of 32)
     s_sum = 0
     is_sum = 0
     for k in range(4):
         for half, sh in ((scalars[:, k] & np.uint64(0xFFFFFFFF), 0), (scalars[:, k] >> np.uint64(32), 32)):
             w = 1 << (64 * k + sh)
             s_sum += w * _exact_sum(half)
-            is_sum += w * _exact_sum(half * idx)
+            is_sum += w * _exact_sum(half * idx, 32 if n <= (1 << 26) else 4)
     return (s_sum * (a + first_index * b) + is_sum * b) % r
 
 
