@@ -62,7 +62,8 @@ def main():
     run("serial, pinned host scalars", lambda k: pb.msm_bigint(pinned[k % nvec]))
     run("serial, pageable host scalars", lambda k: pb.msm_bigint(pageable[k % nvec]))
     # pipelined: two jobs in flight
-    for label, src in (("pipelined x2, pinned host scalars", pinned), ("pipelined x2, pageable host scalars", pageable)):
+    for label, src in (("pipelined x2, resident scalars (HBM)", dev), ("pipelined x2, pinned host scalars", pinned),
+                       ("pipelined x2, pageable host scalars", pageable)):
         pb.msm_bigint_async(src[0]).wait()
         t0 = time.perf_counter()
         pend, res = [], []
