@@ -204,6 +204,28 @@ def main():
                      "ms_per_step": e2 * 1e3 / st, "window_bits": int(ph2[6]), "windows": int(ph2[7]),
                      "accumulate_ms": ph2[3], "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, r2), want))}
 
+    # ---- the same MSMs with two jobs in flight (asynchronous entry): job k+1's digits / sort / reduction run under
+    # job k's accumulate kernel on the library's second MSM lane -- steady-state throughput of a prover that commits to
+    # one polynomial after another.  Never the headline: `value` above is one job at a time. ----------------------------
+    pipelined = None
+    if world == 1 and pb is not None and not args.no_extras:
+        st = max(args.steps, 4)
+        pb.msm_bigint_async(scalars).wait()
+        barrier()
+        t0 = time.perf_counter()
+        pend, last = [], None
+        for _ in range(st):
+            pend.append(pb.msm_bigint_async(scalars))
+            if len(pend) == 2:
+                last = pend.pop(0).wait()
+        while pend:
+            last = pend.pop(0).wait()
+        barrier()
+        ep = time.perf_counter() - t0
+        pipelined = {"what": "same MSM, two asynchronous jobs in flight (ark_hip_msm_prepared_device_async)",
+                     "value": n_total * st / ep, "ms_per_step": ep * 1e3 / st, "steps": st,
+                     "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, last), want))}
+
     # ---- N > 1: weak scaling on the side (2^24 pairs per GPU) ----------------------------------------------
     weak = None
     if world > 1 and not args.no_extras and n != (1 << 24):
@@ -430,6 +452,7 @@ def main():
                          "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
             "cpu_baseline": cpu,
             "plain": plain,
+            "pipelined": pipelined,
             "weak_scaling": weak,
             "msm_2_26_one_gpu": big,
             "other_configs": others,

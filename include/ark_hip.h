@@ -92,7 +92,10 @@ int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars,
                           uint64_t* out_xyz);
 /* Asynchronous form: the device work is enqueued and the call returns; ark_hip_msm_wait blocks until the result is
  * there, finishes it (window combine, a few hundred point operations on the host) and frees the job.  Up to 4 jobs
- * may be in flight per device (ARK_HIP_ERR_BUSY beyond).  Inputs must stay valid until the wait returns. */
+ * may be in flight per device (ARK_HIP_ERR_BUSY beyond).  Inputs must stay valid until the wait returns.
+ * With a job already in flight the next one runs on the device's second MSM lane (own stream and workspace): its
+ * digits / sort / reduction overlap the first job's accumulate kernel (two jobs in flight: +20 % MSMs/s at 2^20, +5 % at
+ * 2^24).  Synchronous calls from one thread never use (or allocate) the second lane. */
 typedef struct ark_hip_msm_job ark_hip_msm_job;
 int ark_hip_msm_sw_device_async(int curve, const void* d_bases, const void* d_scalars, size_t n,
                                 int scalars_are_montgomery, ark_hip_msm_job** out_job);
