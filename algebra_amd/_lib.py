@@ -64,6 +64,8 @@ SYMBOLS = {
     "ark_hip_batch_mul_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ark_hip_fft_in_place_degree_aware": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_size_t]),
     "ark_hip_fft_in_place_degree_aware_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_size_t]),
+    "ark_hip_fft_batch_in_place_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.POINTER(C.c_void_p), C.c_size_t,
+                                                    C.c_int]),
     "ark_hip_shutdown": (None, []),
     "ark_hip_synchronize": (C.c_int, []),
     "ark_hip_version": (C.c_char_p, []),

@@ -341,7 +341,7 @@ struct FftPwKey {
 struct FftWorkspace {
   std::map<FftKey, FftTables> tables;  // per (field, log n, root)
   std::map<FftPwKey, DevBuf> powers;   // per (field, log n, offset[, constant]): [lo (1024) | hi (n >> 10)]
-  DevBuf tmp;                          // ping buffer for the multi-pass transform
+  std::map<hipStream_t, DevBuf> tmps;  // ping buffer of the multi-pass transform, one per stream (transforms in flight)
   DevBuf pw;                           // coset power tables + constants
   DevBuf stage;                        // host-pointer entry: device copy of the data
   hipEvent_t ev[10] = {};              // pass timing (created on first use, reused)
@@ -351,7 +351,9 @@ struct FftWorkspace {
     tables.clear();
     for (auto& kv : powers) kv.second.release();
     powers.clear();
-    tmp.release(); pw.release(); stage.release();
+    for (auto& kv : tmps) kv.second.release();
+    tmps.clear();
+    pw.release(); stage.release();
     for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   }
 };
@@ -433,7 +435,7 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
   auto it = ws.powers.find(key);
   if (it == ws.powers.end()) {
     if (ws.powers.size() >= 64) {  // bounded: a caller cycling through offsets must not grow the cache for ever
-      ARK_HIP_TRY(hipStreamSynchronize(stream));
+      ARK_HIP_TRY(hipDeviceSynchronize());  // transforms in flight on any stream may still read the tables
       for (auto& kv : ws.powers) kv.second.release();
       ws.powers.clear();
     }
@@ -537,8 +539,9 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
   u32* data = (u32*)d_data;
   u32* tmp = nullptr;
   if (P > 1 || zlog) {
-    if (ws.tmp.ensure(n * F::BYTES)) return -3;
-    tmp = (u32*)ws.tmp.p;
+    DevBuf& tb = ws.tmps[stream];
+    if (tb.ensure(n * F::BYTES)) return -3;
+    tmp = (u32*)tb.p;
   }
   int s0 = zlog;
   for (int i = 0; i < P; i++) {

@@ -163,5 +163,25 @@ class Radix2EvaluationDomain:
         """ifft_in_place (radix2/mod.rs:150-153)."""
         return self._run(evals, True, False)
 
+    def fft_batch_in_place(self, polys, inverse=False):
+        """Several transforms over this domain at once (the polynomials a prover transforms together): CUDA tensors of
+        exactly size() elements each, transformed in place, up to three in flight on the GPU
+        (ark_hip_fft_batch_in_place_device; the reference's callers loop over fft_in_place).  Returns `polys`."""
+        import torch
+        L = lib()
+        n = self.size()
+        ptrs = (C.c_void_p * len(polys))()
+        for i, x in enumerate(polys):
+            assert _is_torch(x) and x.is_cuda and x.is_contiguous() and x.numel() * x.element_size() == n * 32
+            ptrs[i] = x.data_ptr()
+        torch.cuda.current_stream().synchronize()
+        check(L.ark_hip_fft_batch_in_place_device(self.field, C.byref(self._s), ptrs, len(polys), int(bool(inverse))),
+              "ark_hip_fft_batch_in_place_device")
+        check(L.ark_hip_synchronize(), "ark_hip_synchronize")
+        return polys
+
+    def ifft_batch_in_place(self, evals):
+        return self.fft_batch_in_place(evals, inverse=True)
+
     def __repr__(self):
         return "Radix-2 multiplicative subgroup of size %d" % self.size()

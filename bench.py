@@ -336,11 +336,26 @@ def main():
         L.ark_hip_fft_last_timing(ft)
         check(L.ark_hip_fft_set_timing(0), "fft timing")
         dev_ms = ft[0]
+        # the same transform as a batch of 8 polynomials (three in flight: ark_hip_fft_batch_in_place_device)
+        ys = [x.clone() for _ in range(8)]
+        ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in ys])
+        check(L.ark_hip_fft_batch_in_place_device(dom.field, sref, ptrs, 8, 0), "fft batch")
+        check(L.ark_hip_synchronize(), "sync")
+        e0 = time.perf_counter()
+        reps_b = max(1, args.fft_steps // 8)
+        for _ in range(reps_b):
+            check(L.ark_hip_fft_batch_in_place_device(dom.field, sref, ptrs, 8, 0), "fft batch")
+        check(L.ark_hip_synchronize(), "sync")
+        batch_ms = (time.perf_counter() - e0) * 1e3 / (8 * reps_b)
+        batch_same = bool(torch.equal(ys[0], ys[7]))
+        del ys
         fft = {
             "metric": "BLS12-381 Fr radix-2 FFT elements/sec (2^%d, in place, device resident)" % kf,
             "value": nf / (fft_ms * 1e-3), "unit": "elements/s", "ms_per_step": fft_ms,
             "device_ms": dev_ms, "passes": [ft[2 + i] for i in range(int(ft[1]))],
             "ifft_fft_roundtrip_exact": roundtrip_ok,
+            "batch_of_8": {"what": "8 polynomials over the same domain per call, three transforms in flight",
+                           "ms_per_transform": batch_ms, "value": nf / (batch_ms * 1e-3), "results_agree": batch_same},
             "roofline": {"bound": "hbm", "kernel": "fft_pass_kernel (x%d passes)" % int(ft[1]),
                          "achieved": 64.0 * nf / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": 64.0 * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

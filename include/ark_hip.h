@@ -214,6 +214,13 @@ int ark_hip_ifft_in_place_device(int field, const ark_hip_radix2_domain* dom, vo
  * log2(size / next_pow2(num_coeffs)) butterfly stages are skipped and only the coefficients are uploaded. */
 int ark_hip_fft_in_place_degree_aware(int field, const ark_hip_radix2_domain* dom, uint64_t* data, size_t num_coeffs);
 int ark_hip_fft_in_place_degree_aware_device(int field, const ark_hip_radix2_domain* dom, void* d_data, size_t num_coeffs);
+/* `count` independent transforms over one domain (forward, or inverse != 0), each in place on its own device buffer of
+ * dom->size elements -- the several polynomials a prover transforms at once.  Up to three run concurrently on the GPU,
+ * which fills the vector-ALU slots a single transform leaves idle around its pass boundaries: per transform 2^22
+ * 0.53 -> 0.48 ms, 2^20 0.157 -> 0.108 ms, 2^16 44 -> 18 us.  Asynchronous on the context stream like the single call.
+ * No counterpart in the reference (its callers loop over fft_in_place, poly/src/domain/mod.rs:92-112). */
+int ark_hip_fft_batch_in_place_device(int field, const ark_hip_radix2_domain* dom, void* const* d_data, size_t count,
+                                      int inverse);
 /* r[i] = a[i] * b[i] over n Fr elements in device memory: `Evaluations *= &Evaluations`
  * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
  * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */

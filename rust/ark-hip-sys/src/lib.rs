@@ -106,6 +106,8 @@ extern "C" {
                                              num_coeffs: usize) -> c_int;
     pub fn ark_hip_fft_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void) -> c_int;
     pub fn ark_hip_ifft_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void) -> c_int;
+    pub fn ark_hip_fft_batch_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *const *mut c_void,
+                                             count: usize, inverse: c_int) -> c_int;
     pub fn ark_hip_fr_mul_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
 }
 

@@ -162,6 +162,29 @@ def test_fft_degree_aware_short_inputs(fname):
             assert np.array_equal(dc.fft(x).reshape(-1), O.fft(fid, full, log_n, gen, False, 8)), (fname, log_n, ln, "coset")
 
 
+@pytest.mark.parametrize("fname", ["BLS12_381_FR", "BN254_FR", "BLS12_377_FR"])
+def test_fft_batch_matches_single_transforms(fname):
+    # ark_hip_fft_batch_in_place_device: several transforms over one domain, up to three in flight on separate streams --
+    # each result limb for limb what the oracle gives for that polynomial (forward / inverse, subgroup / coset), batch
+    # sizes around the lane count, sizes from the single-workgroup kernel to three passes
+    import torch
+    fid = O.FID[fname]
+    gen = O.field_const(fid, 3)
+    for log_n, count in [(3, 5), (10, 4), (11, 1), (13, 2), (16, 7), (20, 3)]:
+        n = 1 << log_n
+        d = A.Radix2EvaluationDomain.new(fname, n)
+        for dom, off in ((d, None), (d.get_coset(gen), gen)):
+            xs = [O.gen_scalars(fid, 7000 + 31 * log_n + i, n, montgomery=True) for i in range(count)]
+            for inverse in (False, True):
+                dev = [torch.from_numpy(x.view(np.int64)).cuda() for x in xs]
+                dom.fft_batch_in_place(dev, inverse=inverse)
+                for i in range(count):
+                    exp = O.fft(fid, xs[i], log_n, off, inverse, 8)
+                    assert np.array_equal(dev[i].cpu().numpy().view(np.uint64).reshape(-1), exp), (fname, log_n, count, i, inverse)
+    d = A.Radix2EvaluationDomain.new(fname, 1 << 8)
+    assert d.fft_batch_in_place([]) == []
+
+
 def test_concurrent_host_threads_msm_and_fft():
     # SURVEY 8(b) threading row: trait functions may be called from many rayon threads at once.  Four host threads
     # hammer the host-pointer MSM (shared staging buffers), the device MSM and the FFT; every result must be right.

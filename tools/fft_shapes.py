@@ -37,7 +37,7 @@ def timed(fn, reps):
 
 
 seven = np.array(S.limbs4(7 * (1 << 256) % r), dtype=np.uint64)  # Fr::GENERATOR = 7, Montgomery form
-print("# degree  fft  fft_on_4x_domain  ifft  coset_fft  coset_ifft   (ms per transform, BLS12-381 Fr, device resident)")
+print("# degree  fft  fft_on_4x_domain  ifft  coset_fft  coset_ifft  fft_batch_of_8   (ms per transform, BLS12-381 Fr, device resident)")
 for k in range(lo, hi + 1):
     n = 1 << k
     reps = 200 if k <= 16 else (50 if k <= 20 else 20)
@@ -54,4 +54,7 @@ for k in range(lo, hi + 1):
     t_ifft = timed(lambda: check(L.ark_hip_ifft_in_place_device(dom.field, sref, y.data_ptr()), "ifft"), reps)
     t_cfft = timed(lambda: check(L.ark_hip_fft_in_place_device(cos.field, cref, y.data_ptr()), "cfft"), reps)
     t_cifft = timed(lambda: check(L.ark_hip_ifft_in_place_device(cos.field, cref, y.data_ptr()), "cifft"), reps)
-    print("2^%-2d  %8.4f  %8.4f  %8.4f  %8.4f  %8.4f" % (k, t_fft, t_big, t_ifft, t_cfft, t_cifft), flush=True)
+    ys = [x.clone() for _ in range(8)]
+    ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in ys])
+    t_b8 = timed(lambda: check(L.ark_hip_fft_batch_in_place_device(dom.field, sref, ptrs, 8, 0), "batch"), max(3, reps // 8)) / 8
+    print("2^%-2d  %8.4f  %8.4f  %8.4f  %8.4f  %8.4f  %8.4f" % (k, t_fft, t_big, t_ifft, t_cfft, t_cifft, t_b8), flush=True)
