@@ -173,3 +173,25 @@ def test_msm_plan_is_host_only_and_sane():
         c, w = C.c_int(), C.c_int()
         assert L.ark_hip_msm_plan(curve, 1 << logn, prepared, C.byref(c), C.byref(w)) == 0
         assert (c.value, w.value) == want, (curve, logn, prepared, c.value, w.value)
+
+
+def test_synth_discrete_log_identity_is_exact_for_large_indices():
+    # tools/synth.py::dlog_of_msm backs every at-size parity check (k*G identity): its chunked uint64 sums must stay exact
+    # for the largest index ranges used (a 2^28-pair job overflowed the first version's chunks of 32)
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import numpy as np
+    import synth as S
+    r = S.R["BLS12_381_FR"]
+    sc = S.gen_scalars(1500, 1, r)
+    for first in (0, (1 << 26) - 700, (1 << 28) - 1500):
+        want = 0
+        for i in range(sc.shape[0]):
+            s = sum(int(sc[i, j]) << (64 * j) for j in range(4))
+            want += s * (S.A0 + (first + i) * S.B0)
+        assert S.dlog_of_msm(sc, S.A0, S.B0, r, first_index=first) == want % r
+    # the large-n summation path (n > 2^26 switches to chunks of 4): entries just below 2^61 must not wrap
+    x = np.full(1003, (1 << 61) - 1, dtype=np.uint64)
+    assert S._exact_sum(x, 4) == 1003 * ((1 << 61) - 1)
+    assert S._exact_sum(np.full(77, (1 << 58) - 1, dtype=np.uint64)) == 77 * ((1 << 58) - 1)
