@@ -303,3 +303,69 @@ def test_batch_mul_matches_oracle(cname):
     assert np.array_equal(A.batch_mul(cid, base, mont[:5]), exp[:5])
     ident = O.scalar_mul(cid, O.generator(cid), np.zeros(4, dtype=np.uint64))      # base = identity -> all identity
     assert not A.batch_mul(cid, ident, mont[:7]).any()
+
+
+def test_two_msm_lanes_under_concurrent_threads_and_batched_fft():
+    # Two MSM lanes per device (a job enqueued while another is in flight runs on the second stream / workspace) and
+    # up to three FFTs in flight: three host threads mix device-pointer MSMs (synchronous = enqueue + wait, so calls
+    # from different threads overlap), pairs of asynchronous prepared jobs waited in reverse order, and batched FFTs.
+    # Every result must equal the oracle's.
+    import threading
+    import torch
+    cid = O.CID["BLS12_381_G1"]
+    fid = O.FID["BLS12_381_FR"]
+    n = 6000
+    bases = O.gen_bases(cid, A4, B4, n)
+    d_b = torch.from_numpy(bases.view(np.int64)).cuda()
+    pb = A.PreparedBases(cid, bases)
+    scs = [O.gen_scalars(sf(cid), 500 + i, n - 37 * i) for i in range(4)]
+    d_s = [torch.from_numpy(s.view(np.int64)).cuda() for s in scs]
+    want = [oracle_aff(cid, bases[: s.shape[0]], s) for s in scs]
+    log_n = 11
+    dom = A.Radix2EvaluationDomain.new("BLS12_381_FR", 1 << log_n)
+    xs = [O.gen_scalars(fid, 40 + i, 1 << log_n, montgomery=True) for i in range(4)]
+    fexp = [O.fft(fid, x, log_n, None, False, 2) for x in xs]
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(10):
+                k = (t + it) % 4
+                kind = (t + 2 * it) % 3
+                if kind == 0:
+                    try:
+                        got = A.msm_bigint(cid, d_b[: scs[k].shape[0]], d_s[k])
+                    except A.ArkHipError as ex:     # four jobs already in flight on the device
+                        if ex.code != -6:
+                            raise
+                        continue
+                    if not np.array_equal(aff(cid, got), want[k]):
+                        errors.append(("msm", t, it))
+                elif kind == 1:
+                    k2 = (k + 1) % 4
+                    try:
+                        j1 = pb.msm_bigint_async(d_s[k])
+                        j2 = pb.msm_bigint_async(d_s[k2])
+                    except A.ArkHipError as ex:     # four jobs in flight on the device: a legal answer under load
+                        if ex.code != -6:
+                            raise
+                        continue
+                    r2, r1 = j2.wait(), j1.wait()
+                    if not (np.array_equal(aff(cid, r1), want[k]) and np.array_equal(aff(cid, r2), want[k2])):
+                        errors.append(("prepared", t, it))
+                else:
+                    dev = [torch.from_numpy(x.view(np.int64)).cuda() for x in xs]
+                    dom.fft_batch_in_place(dev)
+                    for i in range(4):
+                        if not np.array_equal(dev[i].cpu().numpy().view(np.uint64).reshape(-1), fexp[i]):
+                            errors.append(("fft", t, it, i))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("exc", t, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    pb.free()
+    assert not errors, errors[:5]
