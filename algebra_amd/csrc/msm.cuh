@@ -179,6 +179,34 @@ static __global__ void __launch_bounds__(1024) scan_sums_inplace(u32* sums, u32 
     __syncthreads();
   }
 }
+// small arrays (m <= SCAN_SMALL_MAX): the whole exclusive scan in ONE workgroup -- the three-kernel form costs two
+// dependent launches more than it computes at n <= 2^18.  offsets[m] = total.
+static constexpr u32 SCAN_SMALL_MAX = 16384;
+static __global__ void __launch_bounds__(1024) scan_small_kernel(const u32* __restrict__ in, u32 m, u32* __restrict__ offsets) {
+  __shared__ u32 sh[1024];
+  const u32 per = (m + 1023u) / 1024u;
+  const u32 lo = threadIdx.x * per;
+  u32 s = 0;
+  for (u32 k = 0; k < per; k++)
+    if (lo + k < m) s += in[lo + k];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (u32 o = 1; o < 1024; o <<= 1) {
+    u32 y = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += y;
+    __syncthreads();
+  }
+  u32 run = sh[threadIdx.x] - s;
+  for (u32 k = 0; k < per; k++)
+    if (lo + k < m) {
+      offsets[lo + k] = run;
+      run += in[lo + k];
+    }
+  if (threadIdx.x == 1023) offsets[m] = sh[1023];
+}
+// exclusive scan of m counters into offsets[0..m] (offsets[m] = total), `sums` = scratch of ceil(m / SCAN_TILE) words
+static inline void scan_exclusive(const u32* in, size_t m, u32* sums, u32* offsets, hipStream_t stream);
 // each block rescans its tile; writes offsets (exclusive); offsets[m] = total
 static __global__ void __launch_bounds__(256) scan_apply(const u32* __restrict__ in, size_t m, const u32* __restrict__ sums,
                                                   u32* __restrict__ offsets) {
@@ -208,6 +236,17 @@ static __global__ void __launch_bounds__(256) scan_apply(const u32* __restrict__
     run += x[k];
     if (j == m - 1) offsets[m] = run;
   }
+}
+
+static inline void scan_exclusive(const u32* in, size_t m, u32* sums, u32* offsets, hipStream_t stream) {
+  if (m <= SCAN_SMALL_MAX) {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, in, (u32)m, offsets);
+    return;
+  }
+  const u32 nblk = (u32)((m + SCAN_TILE - 1) / SCAN_TILE);
+  hipLaunchKernelGGL(scan_block_sums, dim3(nblk), dim3(256), 0, stream, in, m, sums);
+  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, nblk);
+  hipLaunchKernelGGL(scan_apply, dim3(nblk), dim3(256), 0, stream, in, m, sums, offsets);
 }
 
 // ---- K3b: bucket processing order, heaviest first -------------------------------------------------
@@ -447,25 +486,25 @@ struct HeavyEntry { u32 bucket, first_item, items; };
 // throughput-bound duration is (non-zero entries) / 5.5e9 s: threshold = entries / 154 000, at least 64 and at least
 // 4 x the mean run.  The entry count is only known after the sort (zero digits are dropped: small scalars leave most
 // windows empty), so the threshold is computed on the device.  ctr[2] <- threshold.
-static __global__ void msm_thresh_kernel(const u32* __restrict__ offsets, u32 nslots, u32 forced, u32* __restrict__ ctr) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__device__ __forceinline__ u32 msm_heavy_threshold(const u32* __restrict__ offsets, u32 nslots, u32 forced) {
   const u32 total = offsets[nslots];
   u32 t = total / 154000u;
   if (t < 64u) t = 64u;
   const u32 mr = 4u * (total / nslots);
   if (t < mr) t = mr;
-  if (forced) t = forced;
-  ctr[2] = t;
+  return forced ? forced : t;
 }
 
 static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* __restrict__ offsets, u32 nbuckets,
-                                                                    u32* __restrict__ ctr /*[3]*/,
+                                                                    u32 forced, u32* __restrict__ ctr /*[3]*/,
                                                                     HeavyEntry* __restrict__ list,
                                                                     uint2* __restrict__ items) {
   u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 thresh = msm_heavy_threshold(offsets, nbuckets, forced);  // the same value in every lane
+  if (g == 0) ctr[2] = thresh;                                        // for the kernels that follow
   if (g >= nbuckets) return;
   u32 cnt = offsets[g + 1] - offsets[g];
-  if (cnt <= ctr[2]) return;
+  if (cnt <= thresh) return;
   u32 k = (cnt + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
   u32 first = atomicAdd(&ctr[0], k);
   u32 slot = atomicAdd(&ctr[1], 1u);
@@ -857,7 +896,7 @@ struct MsmJob {
 static constexpr int MSM_JOBS = 4;
 
 struct MsmWorkspace {
-  DevBuf hctr, hlist, hitems, hpart, hfinal, keys, part, thist, toff, sorted, offsets, sums, buckets, lvlS[2], lvlA[2], err,
+  DevBuf hctr, hlist, hitems, hpart, hfinal, keys, part, thist, toff, sorted, offsets, sums, buckets, lvlS[2], lvlA[2],
       order, ohist, ooff;
   MsmJob jobs[MSM_JOBS];
   std::mutex mu;
@@ -867,7 +906,7 @@ struct MsmWorkspace {
     keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
     offsets.release(); sums.release();
     order.release(); ohist.release(); ooff.release();
-    buckets.release(); err.release();
+    buckets.release();
     for (int i = 0; i < 2; i++) { lvlS[i].release(); lvlA[i].release(); }
     for (auto& j : jobs) {
       if (j.pinned) (void)hipHostFree(j.pinned);
@@ -941,7 +980,6 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (ws.sums.ensure((size_t)(ntscan > noscan ? ntscan : noscan) * 4)) return -3;
   if (ws.order.ensure(nbk * 4) || ws.ohist.ensure(nohist * 4) || ws.ooff.ensure((nohist + 1) * 4)) return -3;
   if (ws.buckets.ensure(nbk * Pt::BYTES)) return -3;
-  if (ws.err.ensure(16)) return -3;
 
   // bucket reduction geometry: level 0 (chunked running sums over L0 buckets per lane), then the bit-sliced sums
   u32 L0 = 32;
@@ -1015,18 +1053,15 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
       ws.hpart.ensure(max_items * Pt::BYTES))
     return -3;
   if (pl.shared && ws.hfinal.ensure(max_heavy * Pt::BYTES)) return -3;
-  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 8, stream));
-  ARK_HIP_TRY(hipMemsetAsync(ws.err.p, 0, 4, stream));
+  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 16, stream));  // [chunk items, heavy runs, threshold, scalar-range error flag]
   const u32 nblk = (u32)((n + 255) / 256);
   hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
-                     (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.err.p);
+                     (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.hctr.p + 3);
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[1], stream));
   // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
   hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
                      ntiles, thist);
-  hipLaunchKernelGGL(scan_block_sums, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums);
-  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, ntscan);
-  hipLaunchKernelGGL(scan_apply, dim3(ntscan), dim3(256), 0, stream, thist, nthist, sums, toff);
+  scan_exclusive(thist, nthist, sums, toff, stream);
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[2], stream));
   {
     // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device; the workspace is per device)
@@ -1054,9 +1089,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     const int wsum = pl.shared ? W : 1;
     const size_t wstr = mwin;
     hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nbk, shift, noblk, wsum, wstr, ohist);
-    hipLaunchKernelGGL(scan_block_sums, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums);
-    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, noscan);
-    hipLaunchKernelGGL(scan_apply, dim3(noscan), dim3(256), 0, stream, ohist, nohist, sums, ooff);
+    scan_exclusive(ohist, nohist, sums, ooff, stream);
     hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nbk, shift, noblk, wsum, wstr,
                        ooff, order);
   }
@@ -1064,9 +1097,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   {
     // runs too long for one lane: chunk partials by one wave each, combined per run (empty for uniform scalars)
     u32* hctr = (u32*)ws.hctr.p;
-    hipLaunchKernelGGL(msm_thresh_kernel, dim3(1), dim3(64), 0, stream, offsets, (u32)nb, forced_thresh, hctr);
     hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
-                       hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
+                       forced_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
     constexpr u32 LN = C::FA::LANES;                        // lanes per element of the accumulate field
     const u32 hthreads = Pt::BYTES * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
     hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * Pt::BYTES, stream,
@@ -1113,7 +1145,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   }
   ARK_HIP_TRY(hipGetLastError());
   ARK_HIP_TRY(hipMemcpyAsync(job.pinned, d_sums, npairs * Pt::BYTES, hipMemcpyDeviceToHost, stream));
-  ARK_HIP_TRY(hipMemcpyAsync((char*)job.pinned + npairs * Pt::BYTES, ws.err.p, 4, hipMemcpyDeviceToHost, stream));
+  ARK_HIP_TRY(hipMemcpyAsync((char*)job.pinned + npairs * Pt::BYTES, (const u32*)ws.hctr.p + 3, 4, hipMemcpyDeviceToHost, stream));
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[5], stream));
   ARK_HIP_TRY(hipEventRecord(job.done, stream));
   job.pl = pl;
