@@ -675,14 +675,22 @@ __global__ void __launch_bounds__(128, 2) msm_reduce_level_kernel(const char* __
   const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LANES;
   if (t >= total_out) return;
   const size_t base = (size_t)t * L;
-  Pt running = Pt::zero(), acc = Pt::zero();
+  // the weighted sum A lives in LDS between its updates (one 4-coordinate slot per lane, or per lane pair over Fp2): two
+  // accumulators + the loaded bucket + an addition's temporaries do not fit 256 registers (they spilled 16 B to scratch)
+  __shared__ uint4 park_lds[128 * 192 / 16];
+  static_assert((128 / Ops::LANES) * Pt::BYTES <= sizeof(uint4) * (128 * 192 / 16), "LDS slot size");
+  char* slot = (char*)park_lds + (size_t)(threadIdx.x / Ops::LANES) * Pt::BYTES;
+  Pt running = Pt::zero();
+  running.store(slot);
   for (u32 r = L; r-- > 0;) {
     Pt x = Pt::load(in + (base + r) * Pt::BYTES);
     Ops::add(running, x);
+    Pt acc = Pt::load(slot);
     Ops::add(acc, running);
+    acc.store(slot);
   }
   Ops::fin(running).store(outS + (size_t)t * Pt::BYTES);
-  Ops::fin(acc).store(outA + (size_t)t * Pt::BYTES);
+  Ops::fin(Pt::load(slot)).store(outA + (size_t)t * Pt::BYTES);
 }
 
 // ---- K5b: the rest of the reduction, bit-sliced -------------------------------------------------------
