@@ -94,7 +94,7 @@ __device__ __forceinline__ void fft_pack(const F& x, uint4& a, uint4& b) {
 }
 
 static constexpr int FFT_THREADS = 256;
-static constexpr int FFT_MAX_EPT = 8;  // elements per lane: tiles of up to 2048 elements
+static constexpr int FFT_MAX_EPT = 4;  // elements per lane: tiles of up to 1024 elements (32 KiB of LDS)
 
 // One pass = load tile -> kp butterfly stages in LDS -> store tile.  Loops over the lane's elements /
 // butterflies are fully unrolled with predication so that all global loads of a phase (tile rows,
@@ -172,8 +172,89 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
     }
   }
   __syncthreads();
-  // ---- kp butterfly stages in LDS ----
-  for (int ls = 0; ls < kp; ls++) {
+  // ---- kp butterfly stages in LDS, two at a time ----
+  // A lane owns a 4-point group {q0, q0+lg/2, q0+lg, q0+3lg/2} of two consecutive stages (gaps lg, lg/2): one LDS
+  // round trip and one barrier per TWO stages, three twiddles per four butterflies (both butterflies of the second
+  // stage share theirs).  An odd stage count ends with a single radix-2 stage.
+  int ls = 0;
+  for (; ls + 1 < kp; ls += 2) {
+    const u32 lg = 1u << (kp - 1 - ls), qt = lg >> 1;
+    const int s = a.s0 + ls;
+    u32 idx[FFT_MAX_EPT / 4][4];
+    uint4 wa0[FFT_MAX_EPT / 4][2], wa1[FFT_MAX_EPT / 4][2], wb[FFT_MAX_EPT / 4][2];
+    bool ha0[FFT_MAX_EPT / 4], hb[FFT_MAX_EPT / 4];
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
+      const u32 g = tid + it * FFT_THREADS;
+      ha0[it] = hb[it] = false;
+      if (g < E / 4) {
+        u32 gq, r;
+        if (!a.last) { r = g & T1; gq = g >> t; }
+        else { gq = g & ((1u << (kp - 2)) - 1u); r = g >> (kp - 2); }
+        const u32 j0 = gq & (qt - 1u);
+        const u32 q0 = ((gq & ~(qt - 1u)) << 2) | j0;
+        size_t ta0, ta1, tb;
+        if (!a.last) {
+          const size_t col = ((size_t)mid << t) | r;
+#pragma unroll
+          for (int m = 0; m < 4; m++) idx[it][m] = ((q0 + m * qt) << t) | r;
+          ta0 = ((((size_t)j0) << lo_shift) | col) << s;
+          ta1 = ((((size_t)(j0 + qt)) << lo_shift) | col) << s;
+          tb = ((((size_t)j0) << lo_shift) | col) << (s + 1);
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; m++) idx[it][m] = (r << kp) | (q0 + m * qt);
+          ta0 = (size_t)j0 << s;
+          ta1 = (size_t)(j0 + qt) << s;
+          tb = (size_t)j0 << (s + 1);
+        }
+        const uint4* g1 = (const uint4*)(a.roots + ta1 * F::N);  // never the trivial twiddle: j0 + lg/2 > 0
+        wa1[it][0] = g1[0];
+        wa1[it][1] = g1[1];
+        if (ta0 != 0) {
+          const uint4* g0 = (const uint4*)(a.roots + ta0 * F::N);
+          wa0[it][0] = g0[0];
+          wa0[it][1] = g0[1];
+          ha0[it] = true;
+        }
+        if (tb != 0) {
+          const uint4* g2 = (const uint4*)(a.roots + tb * F::N);
+          wb[it][0] = g2[0];
+          wb[it][1] = g2[1];
+          hb[it] = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
+      const u32 g = tid + it * FFT_THREADS;
+      if (g < E / 4) {
+        F x0 = fft_unpack<F>(pl0[idx[it][0]], pl1[idx[it][0]]);
+        F x1 = fft_unpack<F>(pl0[idx[it][1]], pl1[idx[it][1]]);
+        F x2 = fft_unpack<F>(pl0[idx[it][2]], pl1[idx[it][2]]);
+        F x3 = fft_unpack<F>(pl0[idx[it][3]], pl1[idx[it][3]]);
+        // first stage, gap lg: (x0, x2) and (x1, x3)                    fft.rs:190-198 butterfly_fn_io
+        F s0 = F::add(x0, x2), d0 = F::sub(x0, x2);
+        if (ha0[it]) d0 = F::mul(d0, fft_unpack<F>(wa0[it][0], wa0[it][1]));
+        F s1 = F::add(x1, x3), d1 = F::mul(F::sub(x1, x3), fft_unpack<F>(wa1[it][0], wa1[it][1]));
+        // second stage, gap lg/2: (s0, s1) and (d0, d1), one twiddle for both
+        F y0 = F::add(s0, s1), y1 = F::sub(s0, s1);
+        F y2 = F::add(d0, d1), y3 = F::sub(d0, d1);
+        if (hb[it]) {
+          const F w = fft_unpack<F>(wb[it][0], wb[it][1]);
+          y1 = F::mul(y1, w);
+          y3 = F::mul(y3, w);
+        }
+        uint4 o0, o1;
+        fft_pack<F>(y0, o0, o1); pl0[idx[it][0]] = o0; pl1[idx[it][0]] = o1;
+        fft_pack<F>(y1, o0, o1); pl0[idx[it][1]] = o0; pl1[idx[it][1]] = o1;
+        fft_pack<F>(y2, o0, o1); pl0[idx[it][2]] = o0; pl1[idx[it][2]] = o1;
+        fft_pack<F>(y3, o0, o1); pl0[idx[it][3]] = o0; pl1[idx[it][3]] = o1;
+      }
+    }
+    __syncthreads();
+  }
+  for (; ls < kp; ls++) {
     const u32 lg = 1u << (kp - 1 - ls);
     const int s = a.s0 + ls;
     u32 i0s[FFT_MAX_EPT / 2], i1s[FFT_MAX_EPT / 2];
@@ -533,8 +614,6 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     int base = kx / P, rem = kx % P;
     for (int i = 0; i < P; i++) kps[i] = base + (i < rem ? 1 : 0);
     t = FFT_LANE_BITS;
-    const char* envt = getenv("ARK_HIP_FFT_T");  // tuning knob: log2 of adjacent columns per tile (2 or 3)
-    if (envt && atoi(envt) >= 2 && atoi(envt) <= 3) t = atoi(envt);
   }
   u32* data = (u32*)d_data;
   u32* tmp = nullptr;
@@ -549,7 +628,7 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     // columns per tile: keep every tile at 1024 elements (32 KiB of LDS, 4 elements per lane) -- passes with
     // fewer stages take more adjacent columns, i.e. longer contiguous segments
     int ti = t;
-    if (P > 1 && !getenv("ARK_HIP_FFT_T")) {
+    if (P > 1) {
       ti = 10 - kps[i];
       if (ti < FFT_LANE_BITS) ti = FFT_LANE_BITS;
       const int room = (i == P - 1) ? (k - kps[i]) : (k - s0 - kps[i]);  // bits available for columns
