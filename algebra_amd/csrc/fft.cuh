@@ -613,6 +613,17 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     P = (kx + maxkp - 1) / maxkp;
     int base = kx / P, rem = kx % P;
     for (int i = 0; i < P; i++) kps[i] = base + (i < rem ? 1 : 0);
+    // stages run two per LDS round trip: a pass with an odd stage count pays a whole round trip for its last stage, so
+    // pairs of odd passes trade one stage (8,7,7 -> 8,8,6: 11 round trips instead of 12)
+    if (!getenv("ARK_HIP_FFT_BALANCED")) {
+      for (int i = 0; i < P; i++)
+        for (int j = P - 1; j > i; j--)
+          if ((kps[i] & 1) && (kps[j] & 1) && kps[i] < maxkp && kps[j] > 2) {
+            kps[i]++;
+            kps[j]--;
+            break;
+          }
+    }
     t = FFT_LANE_BITS;
   }
   u32* data = (u32*)d_data;
