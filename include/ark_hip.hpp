@@ -340,6 +340,13 @@ class Radix2EvaluationDomain {
     ifft_in_place(v);
     return v;
   }
+  // Several polynomials over this domain at once, each size() elements in THIS GPU's memory, transformed in place with up
+  // to three transforms in flight (no counterpart in the reference: its callers loop over fft_in_place).  Asynchronous:
+  // ark_hip_synchronize() before the results are read.
+  void fft_batch_in_place_device(const std::vector<void*>& d_polys, bool inverse = false) const {
+    check(ark_hip_fft_batch_in_place_device(FIELD_ID, &s_, d_polys.data(), d_polys.size(), inverse ? 1 : 0),
+          "ark_hip_fft_batch_in_place_device");
+  }
   const ark_hip_radix2_domain& raw() const { return s_; }
 
  private:
