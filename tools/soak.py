@@ -65,6 +65,13 @@ for it in range(iters):
     if not np.array_equal(got, exp):
         bad += 1
         print("FFT MISMATCH", fname, log_n, it)
+    if it % 3 == 0:  # the same transform as a batch of three device buffers (three streams)
+        import torch
+        devs = [torch.from_numpy(x.view(np.int64)).cuda() for _ in range(3)]
+        d.fft_batch_in_place(devs, inverse=inv)
+        if not all(np.array_equal(t.cpu().numpy().view(np.uint64).reshape(-1), exp) for t in devs):
+            bad += 1
+            print("FFT BATCH MISMATCH", fname, log_n, it)
     if not inv and log_n >= 3:  # ragged short input: degree-aware path
         ln = int(rng.integers(1, (1 << log_n) // 4 + 1))
         full = np.zeros((1 << log_n, 4), dtype=np.uint64)
