@@ -758,8 +758,9 @@ struct MsmPlan {
   int red_windows() const { return shared ? 1 : W; }
 };
 
-// relative cost of one base-field product (Fp384 = 1): Fp256 ~0.5, Fp2 over Fp384 ~3.3
-static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 3.3 : 1.0); }
+// relative cost of one mixed addition (Fp384 G1 = 1): Fp256 ~0.5; Fp2 over Fp384 2.7 (measured: 0.49 ns against
+// 0.18 ns per addition at full occupancy)
+static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 2.7 : 1.0); }
 static inline int msm_scalar_bits(int curve_id) {
   switch (curve_id) {
     case 0: return BN254_FR::BITS;
@@ -808,23 +809,29 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       if (shared) nbk = (double)(1u << (c - 1));
       const double entries = (double)n * W;
       const double madd = 1.0 / 5.5e9 * mul_cost, fadd = 1.4 / 5.5e9 * mul_cost;
+      const bool fp2 = mul_cost > 2.0;  // a lane PAIR per bucket
       // accumulate: throughput-bound when the buckets make several rounds over the chip's resident lanes (2 waves x 4
       // SIMDs x 256 CUs x 64 lanes; a G2 bucket takes a lane pair); with a single round the kernel lasts as long as
       // its most loaded lane (Poisson tail): ~24 us per addition on a fully occupied SIMD, ~14 us with one wave per SIMD
       // (profiles/r2_small_n_sweep.txt)
       double acc = entries * madd;
       if (shared) {
-        const double lanes = 131072.0 / (mul_cost > 2.0 ? 2.0 : 1.0);
+        const double lanes = 131072.0 / (fp2 ? 2.0 : 1.0);
         const double load = entries / nbk, lmax = load + 3.0 * sqrt(load) + 2.0;
-        const double per_add = (nbk <= lanes / 2 ? 14e-6 : 24e-6) * mul_cost;  // one wave per SIMD runs a chain faster
+        // one dependent addition: a wave alone on its SIMD runs a chain faster; over Fp2 ~30 us whatever the occupancy
+        // (BLS12-377 G2 2^16, c = 15 / 16 / 17: 25 / 28 / 31 us -- profiles/r2_msm_sweeps.txt)
+        const double per_add = fp2 ? 30e-6 : (nbk <= lanes / 2 ? 14e-6 : 24e-6) * mul_cost;
         const double walk = lmax * per_add + W * 5e-6;                          // + run switches of a shared bucket
         if (nbk <= lanes || walk > acc) acc = walk;
       } else {
         const double chain = (entries / nbk) * 14e-6 * mul_cost;  // one lane walks one (window, bucket) run
         if (chain > acc) acc = chain;
       }
-      double red0 = nbk * 2.0 * fadd;
-      const double red0_lat = 2.0 * 8.0 * 21e-6 * mul_cost;     // >= 8 buckets per lane at level 0
+      // level 0 of the reduction: 2 full additions per bucket; over Fp2 with ONE bucket set (a lane PAIR per bucket: half
+      // the lanes, the same chain length) the kernels run at ~40 % of the addition throughput (measured: BLS12-377 G2 2^16, 2^18 buckets 1.7 ms,
+      // 2^16 buckets 0.76 ms; 2^22, 2^19 buckets 2.2 ms -- profiles/r2_msm_sweeps.txt)
+      double red0 = nbk * 2.0 * fadd * (fp2 && shared ? 2.5 : 1.0);
+      const double red0_lat = (fp2 && shared) ? 0.6e-3 : 2.0 * 8.0 * 21e-6 * mul_cost;  // latency floor of the reduction (G2: measured 0.62-0.76 ms for 2^12..2^16 buckets)
       if (red0_lat > red0) red0 = red0_lat;
       const double bits_stage = 0.5e-3 * mul_cost;              // bit-sliced stage + host tail
       // partition sort: per entry, plus a per-(window, bucket) term.  On the shared path at n >= 2^23 the latter is
@@ -834,11 +841,13 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       const double per_bucket = (shared && n >= ((size_t)1 << 23) && c <= 22) ? 1.5e-11 : 1.0e-10;
       const double sort = entries * 2.0e-11 + (double)W * (double)(1u << (c - 1)) * per_bucket;
       double cost = acc + red0 + bits_stage + sort;
-      if (narrow == 0 && !shared) {
+      if (narrow == W) continue;  // every window one bit narrower: the layout of c - 1 with twice the buckets
+      if (narrow == 0) {
         // uniform widths: a top window with only a few significant bits funnels n/2^tb points into each of 2^tb
-        // buckets: correct (heavy-bucket path) but measured ~1.4x slower.
+        // buckets: correct (heavy-bucket path) but measured ~1.4x slower on the plain path and ~2x on a prepared set
+        // (BLS12-377 G2 2^16: c = 18 3.7 ms against 1.9 ms at c = 17; 2^24 G1: c = 21, 23)
         const int tb = (bits - 1) - (W - 1) * c;
-        if (tb >= 1 && tb <= 5) cost *= 1.4;
+        if (tb >= (shared ? 0 : 1) && tb <= 5) cost *= shared ? 2.0 : 1.4;
       }
       if ((size_t)n * (size_t)W >= (1ull << 32)) continue;  // 32-bit sort positions
       if (cost < best) { best = cost; best_c = c; }

@@ -168,7 +168,8 @@ def test_msm_plan_is_host_only_and_sane():
     # window sizes that were measured to be the fastest on MI355X (profiles/r2_msm_sweeps.txt): a change of the planner's
     # cost model must not silently move them
     measured = {(1, 24, 0): (20, 13), (1, 24, 1): (22, 12), (1, 25, 1): (22, 12), (1, 26, 1): (24, 11), (1, 23, 1): (22, 12),
-                (1, 20, 1): (19, 14), (1, 16, 1): (17, 15), (0, 24, 1): (22, 12), (0, 23, 1): (22, 12), (3, 22, 1): (20, 13)}
+                (1, 20, 1): (19, 14), (1, 16, 1): (17, 15), (0, 24, 1): (22, 12), (0, 23, 1): (22, 12), (3, 22, 1): (20, 13),
+                (3, 16, 1): (17, 15), (4, 16, 1): (17, 15), (3, 12, 1): (17, 15), (3, 22, 0): (19, 14)}
     for (curve, logn, prepared), want in measured.items():
         c, w = C.c_int(), C.c_int()
         assert L.ark_hip_msm_plan(curve, 1 << logn, prepared, C.byref(c), C.byref(w)) == 0
