@@ -1004,12 +1004,14 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     size_t want = (mwin * (size_t)Wr) >> 17;  // keep ~1e5 (S, A) pairs for the bit-sliced stage
     u32 p2 = 1;
     while (p2 < want) p2 <<= 1;
-    const u32 l0_min = (mwin * (size_t)Wr) <= ((size_t)1 << 17) ? 4 : 8;  // few buckets: short chains beat fewer pairs
+    // few buckets: short chains beat fewer pairs (measured: 2^15 buckets L0 = 2, 2^16..2^17 L0 = 4, profiles/r2_msm_sweeps.txt)
+    const size_t nbr = mwin * (size_t)Wr;
+    const u32 l0_min = nbr <= ((size_t)1 << 15) ? 2 : (nbr <= ((size_t)1 << 17) ? 4 : 8);
     if (p2 < l0_min) p2 = l0_min;
     if (p2 < L0) L0 = p2;
     if (const char* e0 = getenv("ARK_HIP_MSM_L0")) {  // tuning knob
       int v = atoi(e0);
-      if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L0 = (u32)v;
+      if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L0 = (u32)v;
     }
     while (L0 > mwin) L0 >>= 1;
   }
