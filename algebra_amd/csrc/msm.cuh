@@ -1009,6 +1009,9 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     const u32 l0_min = nbr <= ((size_t)1 << 15) ? 2 : (nbr <= ((size_t)1 << 17) ? 4 : 8);
     if (p2 < l0_min) p2 = l0_min;
     if (p2 < L0) L0 = p2;
+    // one shared bucket set (prepared base set), measured per bucket count (profiles/r2_msm_sweeps.txt, sessions L0 / AN):
+    // 2^18 buckets L0 = 8, 2^19 .. 2^21 L0 = 16 (2^19: reduction 1.32 -> 0.99 ms against L0 = 8)
+    if (Wr == 1 && nbr > ((size_t)1 << 18)) L0 = nbr <= ((size_t)1 << 21) ? 16 : 32;
     if (const char* e0 = getenv("ARK_HIP_MSM_L0")) {  // tuning knob
       int v = atoi(e0);
       if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L0 = (u32)v;
@@ -1025,6 +1028,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   // 8-step LDS tree -- both pure latency, so chunks are kept short once there are enough of them to fill the chip
   // (few workgroups, e.g. one window of a prepared set at small n: latency only, 2^16 1.39 -> 1.11 ms; many: throughput)
   u32 chunk = (size_t)Wr * Q * ((m + 4095) / 4096) < 512 ? 1024 : 4096;
+  if (Wr == 1) chunk = m <= 16384 ? 1024 : (m <= 65536 ? 2048 : 4096);  // measured: m = 2^15 pairs 2048 (0.77 -> 0.70 ms)
   if (const char* ec = getenv("ARK_HIP_MSM_CHUNK")) {
     int v = atoi(ec);
     if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096 || v == 8192 || v == 16384) chunk = (u32)v;
