@@ -34,8 +34,8 @@ def poly_mul(field, a, b):
     da, db = up(a), up(b)
     torch.cuda.synchronize()
     sref = C.byref(dom._s)
-    check(L.ark_hip_fft_in_place_device(fid, sref, da.data_ptr()), "fft a")
-    check(L.ark_hip_fft_in_place_device(fid, sref, db.data_ptr()), "fft b")
+    ptrs = (C.c_void_p * 2)(da.data_ptr(), db.data_ptr())
+    check(L.ark_hip_fft_batch_in_place_device(fid, sref, ptrs, 2, 0), "fft a, b")  # the two transforms in flight together
     check(L.ark_hip_fr_mul_device(fid, da.data_ptr(), db.data_ptr(), da.data_ptr(), n), "pointwise mul")
     check(L.ark_hip_ifft_in_place_device(fid, sref, da.data_ptr()), "ifft")
     check(L.ark_hip_synchronize(), "sync")
