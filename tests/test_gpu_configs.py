@@ -69,6 +69,52 @@ def test_msm_bls12_381_g1_2_26_and_shard_plan_dlog(logn):
     dlog_case("BLS12_381_G1", logn, 5000 + logn)
 
 
+def test_two_jobs_in_flight_at_2_22_dlog():
+    # the two MSM lanes at a throughput-bound size: two asynchronous jobs over one prepared base set (different scalar
+    # vectors), both in flight, each == its own k*G; then a plain synchronous job while a prepared one is still in flight
+    import torch
+    cname, logn = "BLS12_381_G1", 22
+    cid = O.CID[cname]
+    r = rmod(cid)
+    n = 1 << logn
+    bases = S.grow_bases(cid, n, S.A0, S.B0, r)
+    pb = A.PreparedBases(cid, bases)
+    scs = [S.gen_scalars(n, 9100 + i, r) for i in range(2)]
+    dev = [torch.from_numpy(x.view(np.int64)).cuda() for x in scs]
+    kgs = [O.to_affine(cid, O.scalar_mul(cid, O.generator(cid), S.limbs4(S.dlog_of_msm(x, S.A0, S.B0, r)))) for x in scs]
+    j0 = pb.msm_bigint_async(dev[0])
+    j1 = pb.msm_bigint_async(dev[1])
+    r1, r0 = j1.wait(), j0.wait()
+    assert np.array_equal(A.into_affine(cid, r0), kgs[0]) and np.array_equal(A.into_affine(cid, r1), kgs[1])
+    j0 = pb.msm_bigint_async(dev[0])
+    plain = A.msm_bigint(cid, bases, dev[1])          # enqueued behind / beside the prepared job: second lane
+    assert np.array_equal(A.into_affine(cid, plain), kgs[1])
+    assert np.array_equal(A.into_affine(cid, j0.wait()), kgs[0])
+    pb.free()
+    del bases, dev
+    torch.cuda.empty_cache()
+
+
+def test_fft_batch_2_22_vs_oracle_and_single():
+    # BASELINE config 3 through the batched entry: three polynomials at 2^22 (three streams), one checked limb for limb
+    # against the oracle, all three against the single-transform entry
+    import torch
+    fname, log_n = "BLS12_381_FR", 22
+    fid = O.FID[fname]
+    n = 1 << log_n
+    d = A.Radix2EvaluationDomain.new(fname, n)
+    xs = [O.gen_scalars(fid, 3300 + i, n, montgomery=True) for i in range(3)]
+    dev = [torch.from_numpy(x.view(np.int64)).cuda() for x in xs]
+    single = [d.fft(t) for t in dev]                   # copies
+    d.fft_batch_in_place(dev)
+    for i in range(3):
+        assert torch.equal(dev[i].view(torch.int64).reshape(-1), single[i].view(torch.int64).reshape(-1)), i
+    threads = min(os.cpu_count() or 8, 64)
+    assert np.array_equal(dev[1].cpu().numpy().view(np.uint64).reshape(-1), O.fft(fid, xs[1], log_n, None, False, threads))
+    del dev, single
+    torch.cuda.empty_cache()
+
+
 def test_msm_g2_2_18_vs_oracle_wnaf():
     import torch
     cname, logn = "BLS12_377_G2", 18
