@@ -234,16 +234,18 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
         F x2 = fft_unpack<F>(pl0[idx[it][2]], pl1[idx[it][2]]);
         F x3 = fft_unpack<F>(pl0[idx[it][3]], pl1[idx[it][3]]);
         // first stage, gap lg: (x0, x2) and (x1, x3)                    fft.rs:190-198 butterfly_fn_io
-        F s0 = F::add(x0, x2), d0 = F::sub(x0, x2);
-        if (ha0[it]) d0 = F::mul(d0, fft_unpack<F>(wa0[it][0], wa0[it][1]));
-        F s1 = F::add(x1, x3), d1 = F::mul(F::sub(x1, x3), fft_unpack<F>(wa1[it][0], wa1[it][1]));
+        // (tile values are relaxed residues in [0, 2p): the products skip their final conditional subtraction, the
+        //  last pass's stores make the results canonical)
+        F s0 = F::add_r2(x0, x2), d0 = F::sub_r(x0, x2);
+        if (ha0[it]) d0 = F::mul_r1(d0, fft_unpack<F>(wa0[it][0], wa0[it][1]));
+        F s1 = F::add_r2(x1, x3), d1 = F::mul_r1(F::sub_r(x1, x3), fft_unpack<F>(wa1[it][0], wa1[it][1]));
         // second stage, gap lg/2: (s0, s1) and (d0, d1), one twiddle for both
-        F y0 = F::add(s0, s1), y1 = F::sub(s0, s1);
-        F y2 = F::add(d0, d1), y3 = F::sub(d0, d1);
+        F y0 = F::add_r2(s0, s1), y1 = F::sub_r(s0, s1);
+        F y2 = F::add_r2(d0, d1), y3 = F::sub_r(d0, d1);
         if (hb[it]) {
           const F w = fft_unpack<F>(wb[it][0], wb[it][1]);
-          y1 = F::mul(y1, w);
-          y3 = F::mul(y3, w);
+          y1 = F::mul_r1(y1, w);
+          y3 = F::mul_r1(y3, w);
         }
         uint4 o0, o1;
         fft_pack<F>(y0, o0, o1); pl0[idx[it][0]] = o0; pl1[idx[it][0]] = o1;
@@ -297,9 +299,9 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
         const u32 i0 = i0s[it], i1 = i1s[it];
         F lo = fft_unpack<F>(pl0[i0], pl1[i0]);
         F hi = fft_unpack<F>(pl0[i1], pl1[i1]);
-        F sum = F::add(lo, hi);  // fft.rs:190-198 butterfly_fn_io
-        F dif = F::sub(lo, hi);
-        if (hasw[it]) dif = F::mul(dif, fft_unpack<F>(w0[it], w1[it]));
+        F sum = F::add_r2(lo, hi);  // fft.rs:190-198 butterfly_fn_io, on relaxed residues
+        F dif = F::sub_r(lo, hi);
+        if (hasw[it]) dif = F::mul_r1(dif, fft_unpack<F>(w0[it], w1[it]));
         uint4 o0, o1;
         fft_pack<F>(sum, o0, o1);
         pl0[i0] = o0;
@@ -344,7 +346,11 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
                         F::load(a.post_lo + (opos & ((1u << PW_LO_BITS) - 1)) * F::N));
           else
             pw = F::load(a.post_const);
-          x = F::mul(x, pw);
+          x = F::mul(x, pw);  // relaxed x times canonical pw: mul's one conditional subtraction makes it canonical
+          fft_pack<F>(x, v0, v1);
+        } else {
+          F x = fft_unpack<F>(v0, v1);
+          x = F::reduce_once(x.l);  // [0, 2p) -> [0, p)
           fft_pack<F>(x, v0, v1);
         }
         uint4* g = (uint4*)(dst + opos * F::N);

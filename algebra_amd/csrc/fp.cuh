@@ -438,6 +438,44 @@ struct Fp {
     }
     return r;
   }
+  // The same relaxed domain [0, 2p) for fields whose 4p may exceed R (BLS12-381 Fr: p = 0.45 R) -- the FFT butterflies.
+  // add_r2: the sum of two relaxed values may carry out of the N limbs; it is then certainly >= 2p.
+  ARK_HD static Fp add_r2(const Fp& a, const Fp& b) {
+    u32 t[N], d[N];
+    u32 c = 0, borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      u32 co;
+      t[i] = __builtin_addc(a.l[i], b.l[i], c, &co);
+      c = co;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const u32 p2 = (i == 0) ? ((u32)P::P[0] << 1) : (((u32)P::P[i] << 1) | ((u32)P::P[i - 1] >> 31));
+      u32 bo;
+      d[i] = __builtin_subc(t[i], p2, borrow, &bo);
+      borrow = bo;
+    }
+    const bool keep = borrow != 0 && c == 0;  // t < 2p and no carry: t stands
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = keep ? t[i] : d[i];
+    return r;
+  }
+  // relaxed a (< 2p) times CANONICAL b (< p): (2p^2 + R p) / R < 2p for every p < R/2 -- no condition on 4p <= R
+  ARK_HD static Fp mul_r1(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    Acc96 c{0, 0};
+    u32 m[N];
+    Fp r;
+    mont_cols_lo<P, 0>(c, a.l, b.l, m);
+    mont_cols_hi<P, N>(c, a.l, b.l, m, r.l);
+    r.l[N - 1] = (u32)c.lo;
+    return r;
+#else
+    return mul(a.canonical(), b);
+#endif
+  }
   // 2p - a for a relaxed a (<= 2p): a representative of -a in [0, 2p]; only ever used as a multiplication operand
   ARK_HD static Fp neg_r(const Fp& a) {
     Fp r;
