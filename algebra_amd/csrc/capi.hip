@@ -1,6 +1,10 @@
 // C ABI of libark_hip.so (see include/ark_hip.h for the contract and the reference items replaced).
 #include "../../include/ark_hip.h"
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -13,6 +17,162 @@
 using namespace arkhip;
 
 namespace {
+
+struct PreparedBases;
+
+// ---- pageable host memory -> device at PCIe rate ---------------------------------------------------------
+// hipMemcpyAsync from pageable memory is staged by the runtime through one internal bounce buffer on the calling thread
+// (~25-30 GB/s measured on the MI355X boxes against ~57 GB/s from page-locked memory).  The host-pointer entry points
+// (what SWCurveConfig::msm hands over: Rust slices in ordinary heap memory) therefore stage large uploads themselves:
+// a few worker threads copy 32 MiB pieces into a ring of pinned buffers while the DMA engine drains the previous
+// pieces.  Small copies go straight to hipMemcpyAsync.
+class CopyPool {
+ public:
+  explicit CopyPool(int nthreads) {
+    for (int i = 0; i < nthreads; i++) th_.emplace_back([this]() { run(); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int threads() const { return (int)th_.size(); }
+  // memcpy(dst, src, bytes) split over the workers; returns when done
+  void copy(void* dst, const void* src, size_t bytes) {
+    const int parts = (int)th_.size();
+    if (parts <= 1 || bytes < ((size_t)1 << 20)) {
+      memcpy(dst, src, bytes);
+      return;
+    }
+    std::atomic<int> left(parts);
+    std::mutex dmu;
+    std::condition_variable dcv;
+    const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (int i = 0; i < parts; i++) {
+        const size_t off = (size_t)i * per;
+        const size_t len = off >= bytes ? 0 : (bytes - off < per ? bytes - off : per);
+        q_.push_back([=, &left, &dmu, &dcv]() {
+          if (len) memcpy((char*)dst + off, (const char*)src + off, len);
+          if (left.fetch_sub(1) == 1) {
+            std::lock_guard<std::mutex> l2(dmu);
+            dcv.notify_one();
+          }
+        });
+      }
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> l2(dmu);
+    dcv.wait(l2, [&]() { return left.load() == 0; });
+  }
+
+ private:
+  void run() {
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this]() { return stop_ || !q_.empty(); });
+        if (stop_ && q_.empty()) return;
+        job = std::move(q_.front());
+        q_.pop_front();
+      }
+      job();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::deque<std::function<void()>> q_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+};
+
+struct HostStager {
+  static constexpr int SLOTS = 4;
+  static constexpr size_t SLOT_BYTES = (size_t)32 << 20;
+  void* pinned[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t drained[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  int next = 0;
+  CopyPool* pool = nullptr;
+  int mode = -1;  // -1: not decided; 0: plain hipMemcpyAsync; 1: staged
+  void release() {
+    for (int i = 0; i < SLOTS; i++) {
+      if (pinned[i]) (void)hipHostFree(pinned[i]);
+      pinned[i] = nullptr;
+      if (drained[i]) (void)hipEventDestroy(drained[i]);
+      drained[i] = nullptr;
+    }
+    delete pool;
+    pool = nullptr;
+  }
+  static bool is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+      (void)hipGetLastError();  // ordinary heap memory: "invalid value" is the answer, not an error to leave behind
+      return false;
+    }
+    return a.type == hipMemoryTypeHost;
+  }
+  // enqueue dst[0..bytes) <- src (pageable or pinned host memory) on `st`.  On return `src` has been read completely,
+  // unless it is page-locked and `src_stable` (the caller keeps it valid until the stream has passed this point): then
+  // the DMA engine reads it in place.
+  int upload(void* dst, const void* src, size_t bytes, hipStream_t st, bool src_stable = false) {
+    if (bytes && src_stable && is_pinned(src)) {
+      ARK_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+      return 0;
+    }
+    if (mode < 0) {
+      const char* e = getenv("ARK_HIP_COPY_THREADS");  // 0: leave pageable copies to the runtime
+      int nt = e ? atoi(e) : 4;
+      const int hw = (int)std::thread::hardware_concurrency();
+      if (hw > 0 && nt > hw) nt = hw;
+      mode = nt > 0 ? 1 : 0;
+      if (mode) pool = new CopyPool(nt);
+    }
+    if (bytes == 0) return 0;
+    if (!mode || bytes < ((size_t)8 << 20)) {
+      ARK_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+      ARK_HIP_TRY(hipStreamSynchronize(st));  // pageable source: the contract is "read on return"
+      return 0;
+    }
+    for (size_t off = 0; off < bytes; off += SLOT_BYTES) {
+      const size_t len = bytes - off < SLOT_BYTES ? bytes - off : SLOT_BYTES;
+      const int k = next;
+      next = (next + 1) % SLOTS;
+      if (!pinned[k]) {
+        ARK_HIP_TRY(hipHostMalloc(&pinned[k], SLOT_BYTES));
+        ARK_HIP_TRY(hipEventCreateWithFlags(&drained[k], hipEventDisableTiming));
+      } else {
+        ARK_HIP_TRY(hipEventSynchronize(drained[k]));  // the DMA that last read this slot
+      }
+      pool->copy(pinned[k], (const char*)src + off, len);
+      ARK_HIP_TRY(hipMemcpyAsync((char*)dst + off, pinned[k], len, hipMemcpyHostToDevice, st));
+      ARK_HIP_TRY(hipEventRecord(drained[k], st));
+    }
+    return 0;
+  }
+};
+
+// ---- resident copies of base sets handed over by host pointer -------------------------------------------
+// SWCurveConfig::msm / VariableBaseMSM::msm_bigint take `&[Affine]` on every call; provers (and the reference's own
+// bench, bench-templates/src/macros/ec.rs:223-240) pass the SAME slice -- an SRS -- again and again.  The host-pointer
+// entry keeps device copies keyed by (curve, host address, length) and validated by a fingerprint of sampled content, so
+// a repeat call pays the scalar upload only.
+struct BaseCacheEntry {
+  int curve = -1;
+  const void* host = nullptr;
+  size_t n = 0;
+  uint64_t fingerprint = 0;
+  DevBuf dev;
+  uint64_t last_use = 0;
+  unsigned hits = 0;
+  PreparedBases* prepared = nullptr;  // built after `auto_prepare` hits (off by default)
+};
+struct BaseCacheStats { uint64_t hits = 0, misses = 0, refreshed = 0, evicted = 0; };
 
 // One context per (logical) device: stream, workspaces, staging.  Every entry point runs on the calling thread's
 // current device (ark_hip_set_device / ark_hip_init; default: the first device initialised) and holds that
@@ -35,6 +195,13 @@ struct Context {
   DevBuf ring_s[2], ring_b[2];         // double-buffered scalar / base uploads of the streaming entry points
   hipEvent_t ring_free[2] = {nullptr, nullptr}, ring_up[2] = {nullptr, nullptr};
   int ring_next = 0;
+  hipEvent_t lane_ev = nullptr;        // orders the second MSM lane after the context stream (producers of its inputs)
+  HostStager stager;
+  std::vector<BaseCacheEntry> base_cache;
+  BaseCacheStats cache_stats;
+  uint64_t cache_clock = 0;
+  long long cache_budget = -1;         // bytes; -1: not configured yet (env / default on first use); 0: disabled
+  int auto_prepare = -1;               // hits after which a cached base set is prepared; 0: never; -1: env / default
   bool msm_timing = false, fft_timing = false;
   MsmTimings msm_tm;
   FftTimings fft_tm;
@@ -424,12 +591,32 @@ int msm_enqueue_ctx(Context* c, int curve, const void* pts, size_t wstride, cons
                     size_t n, int mont, int lane = 0) {
   hipStream_t st;
   if (int rc = msm_lane_stream(c, lane, &st)) return rc;
+  if (lane) {
+    // the device-pointer entry points are documented as asynchronous on the context stream: an FFT / pointwise product
+    // queued there may be producing this job's scalars, so the second lane starts behind everything queued so far
+    if (!c->lane_ev) ARK_HIP_TRY(hipEventCreateWithFlags(&c->lane_ev, hipEventDisableTiming));
+    ARK_HIP_TRY(hipEventRecord(c->lane_ev, c->stream));
+    ARK_HIP_TRY(hipStreamWaitEvent(st, c->lane_ev, 0));
+  }
   int slot = msm_enqueue_dispatch(curve, c->msm[lane], pts, wstride, prep, d_scalars, n, mont, st, c->msm_timing);
   return slot < 0 ? slot : lane * MSM_JOBS + slot;
 }
+// May be called WITHOUT the context lock held (ark_hip_msm_wait): the timings go through a local and are published
+// under the (recursive) lock.
 int msm_finish_ctx(Context* c, int curve, int slot, uint64_t* out) {
   if (slot < 0 || slot >= 2 * MSM_JOBS) return ARK_HIP_ERR_ARG;
-  return msm_finish_dispatch(curve, c->msm[slot / MSM_JOBS], slot % MSM_JOBS, out, c->msm_timing ? &c->msm_tm : nullptr);
+  MsmTimings tm;
+  const int rc = msm_finish_dispatch(curve, c->msm[slot / MSM_JOBS], slot % MSM_JOBS, out, &tm);
+  if (rc == 0 && tm.c != 0) {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    c->msm_tm = tm;
+  }
+  return rc;
+}
+// error paths: wait for a job and drop its result, so that its slot is free again and nothing is left in flight
+void msm_discard_ctx(Context* c, int curve, int slot) {
+  uint64_t scratch[36];
+  (void)msm_finish_ctx(c, curve, slot, scratch);
 }
 
 // next slot of the upload ring: the copy stream waits until the MSM that last read this slot has finished
@@ -453,6 +640,202 @@ int ring_publish(Context* c, int k, hipStream_t compute) {
 int ring_release(Context* c, int k, hipStream_t compute) {
   ARK_HIP_TRY(hipEventRecord(c->ring_free[k], compute));
   return 0;
+}
+
+// ---- base-set cache of the host-pointer entry points ----------------------------------------------------
+void free_prepared(PreparedBases* pb) {  // the caller has made sure no job in flight reads the table
+  pb->table.release();
+  delete pb;
+}
+
+// Fingerprint of a base set: every byte of up to 4096 evenly spaced points plus the last one.  A replaced or
+// regenerated set differs everywhere and is always noticed; an in-place edit of a few points between two calls is only
+// noticed if it touches a sampled point -- the documented limit of a transparent cache (callers that
+// patch an SRS in place call ark_hip_msm_cache_clear, or disable the cache with ARK_HIP_BASE_CACHE_MB=0).
+uint64_t base_fingerprint(const uint64_t* bases, size_t n, size_t words_per_point) {
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n;
+  auto mix = [&](const uint64_t* p) {
+    for (size_t k = 0; k < words_per_point; k++) {
+      h ^= p[k];
+      h *= 0xff51afd7ed558ccdull;
+      h ^= h >> 29;
+    }
+  };
+  const size_t S = n < 4096 ? n : 4096;
+  for (size_t k = 0; k < S; k++) mix(bases + (k * n / S) * words_per_point);
+  if (n) mix(bases + (n - 1) * words_per_point);
+  return h;
+}
+void cache_configure(Context* c) {
+  if (c->cache_budget < 0) {
+    long long budget = -1;
+    if (const char* e = getenv("ARK_HIP_BASE_CACHE_MB")) budget = atoll(e) * (1ll << 20);
+    if (budget < 0) {
+      size_t fr = 0, tot = 0;
+      budget = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 4) : (8ll << 30);  // a quarter of the HBM
+    }
+    c->cache_budget = budget;
+  }
+  if (c->auto_prepare < 0) {
+    const char* e = getenv("ARK_HIP_AUTO_PREPARE");
+    c->auto_prepare = e ? atoi(e) : 0;
+    if (c->auto_prepare < 0) c->auto_prepare = 0;
+  }
+}
+void cache_drop(Context* c, size_t idx) {
+  BaseCacheEntry& e = c->base_cache[idx];
+  if (e.prepared) free_prepared(e.prepared);
+  e.dev.release();
+  c->base_cache.erase(c->base_cache.begin() + (long)idx);
+}
+int cache_clear(Context* c) {
+  if (c->base_cache.empty()) return 0;
+  if (int rc = sync_compute(c)) return rc;  // a job in flight may still read a cached copy
+  while (!c->base_cache.empty()) cache_drop(c, c->base_cache.size() - 1);
+  return 0;
+}
+// Device copy of `bases` (uploading it on a miss or when the content changed).  *out = nullptr when the set cannot be
+// cached (cache disabled, or larger than the budget): the caller then falls back to its staging buffer.
+int cache_get(Context* c, int curve, const uint64_t* bases, size_t n, BaseCacheEntry** out) {
+  *out = nullptr;
+  cache_configure(c);
+  const size_t wpp = (size_t)CURVES[curve].fe_words * 2, bytes = n * wpp * 8;
+  if (c->cache_budget <= 0 || (long long)bytes > c->cache_budget || n == 0) return 0;
+  const uint64_t fp = base_fingerprint(bases, n, wpp);
+  c->cache_clock++;
+  for (auto& e : c->base_cache) {
+    if (e.curve != curve || e.host != (const void*)bases || e.n != n) continue;
+    e.last_use = c->cache_clock;
+    if (e.fingerprint != fp) {  // same address and length, different content: refresh in place
+      if (int rc = sync_compute(c)) return rc;
+      if (e.prepared) free_prepared(e.prepared);
+      e.prepared = nullptr;
+      if (int rc = c->stager.upload(e.dev.p, bases, bytes, c->copy_stream)) return rc;
+      ARK_HIP_TRY(hipStreamSynchronize(c->copy_stream));
+      e.fingerprint = fp;
+      e.hits = 0;
+      c->cache_stats.refreshed++;
+    } else {
+      e.hits++;
+      c->cache_stats.hits++;
+    }
+    *out = &e;
+    return 0;
+  }
+  // miss: make room (least recently used first), then upload
+  long long used = 0;
+  for (auto& e : c->base_cache) used += (long long)e.dev.cap;
+  bool synced = false;
+  while (!c->base_cache.empty() && used + (long long)bytes > c->cache_budget) {
+    size_t lru = 0;
+    for (size_t i = 1; i < c->base_cache.size(); i++)
+      if (c->base_cache[i].last_use < c->base_cache[lru].last_use) lru = i;
+    if (!synced) {
+      if (int rc = sync_compute(c)) return rc;
+      synced = true;
+    }
+    used -= (long long)c->base_cache[lru].dev.cap;
+    cache_drop(c, lru);
+    c->cache_stats.evicted++;
+  }
+  BaseCacheEntry ne;
+  ne.curve = curve;
+  ne.host = bases;
+  ne.n = n;
+  ne.fingerprint = fp;
+  ne.last_use = c->cache_clock;
+  if (ne.dev.ensure(bytes)) return 0;  // no room on the device right now: not an error, the caller streams instead
+  if (int rc = c->stager.upload(ne.dev.p, bases, bytes, c->copy_stream)) {
+    ne.dev.release();
+    return rc;
+  }
+  if (hipStreamSynchronize(c->copy_stream) != hipSuccess) {
+    ne.dev.release();
+    return -1000;
+  }
+  c->cache_stats.misses++;
+  c->base_cache.push_back(ne);
+  *out = &c->base_cache.back();
+  return 0;
+}
+
+// One MSM whose scalars (and, with `host_bases`, bases) come from host memory, against `d_bases` (resident) or streamed
+// bases: the pairs are cut into pieces, piece k+1 uploads on the copy stream -- and digit-recodes / sorts on the other
+// MSM lane -- while piece k's accumulate kernel runs; partial results are added on the host (the reference's own chunk
+// sum, variable_base/mod.rs:542-557).  pieces == 1: plain upload-then-compute.
+int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_bases, const uint64_t* scalars, size_t n,
+               int mont, size_t step, uint64_t* out_xyz) {
+  const size_t ab = (size_t)CURVES[curve].fe_words * 16;
+  const size_t pw = (size_t)CURVES[curve].fe_words * 3;
+  if (step == 0 || step > n) step = n;
+  std::vector<uint64_t> partials;
+  int pending[2] = {-1, -1};
+  int npend = 0;
+  auto drain_one = [&]() -> int {
+    uint64_t part[36];
+    const int rc = msm_finish_ctx(c, curve, pending[0], part);
+    pending[0] = pending[1];
+    npend--;
+    if (rc) return rc;
+    partials.insert(partials.end(), part, part + pw);
+    return 0;
+  };
+  auto fail = [&](int rc) -> int {  // nothing of this call stays in flight, no job slot stays taken
+    while (npend) {
+      msm_discard_ctx(c, curve, pending[0]);
+      pending[0] = pending[1];
+      npend--;
+    }
+    (void)hipStreamSynchronize(c->copy_stream);
+    return rc;
+  };
+  if (n == 0) {
+    int slot = msm_enqueue_ctx(c, curve, nullptr, 0, nullptr, nullptr, 0, mont);
+    if (slot < 0) return slot;
+    return msm_finish_ctx(c, curve, slot, out_xyz);
+  }
+  for (size_t off = 0; off < n; off += step) {
+    const size_t cnt = n - off < step ? n - off : step;
+    if (npend == 2) {
+      if (int rc = drain_one()) return fail(rc);
+    }
+    const int lane = msm_pick_lane(c);  // before anything is put in flight: BUSY must leave nothing behind
+    if (lane < 0) return fail(lane);
+    hipStream_t compute;
+    if (int rc = msm_lane_stream(c, lane, &compute)) return fail(rc);
+    int k = 0;
+    if (int rc = ring_acquire(c, &k)) return fail(rc);
+    if (c->ring_s[k].cap < cnt * 32 || (host_bases && c->ring_b[k].cap < cnt * ab)) {
+      if (int rc = sync_compute(c)) return fail(rc);  // growing frees memory an enqueued MSM may still read
+      if (c->ring_s[k].ensure(step * 32) || (host_bases && c->ring_b[k].ensure(step * ab))) return fail(ARK_HIP_ERR_NOMEM);
+    }
+    if (host_bases)
+      if (int rc = c->stager.upload(c->ring_b[k].p, host_bases + off * (ab / 8), cnt * ab, c->copy_stream)) return fail(rc);
+    if (int rc = c->stager.upload(c->ring_s[k].p, scalars + off * 4, cnt * 32, c->copy_stream)) return fail(rc);
+    if (int rc = ring_publish(c, k, compute)) return fail(rc);
+    const void* pts = host_bases ? (const void*)c->ring_b[k].p : (const void*)((const char*)d_bases + off * ab);
+    int slot = msm_enqueue_ctx(c, curve, pts, 0, nullptr, c->ring_s[k].p, cnt, mont, lane);
+    (void)ring_release(c, k, compute);
+    if (slot < 0) return fail(slot);
+    pending[npend++] = slot;
+  }
+  while (npend) {
+    if (int rc = drain_one()) return fail(rc);
+  }
+  if (partials.size() == pw) {
+    memcpy(out_xyz, partials.data(), pw * 8);
+    return 0;
+  }
+  return ark_hip_sw_sum(curve, partials.data(), partials.size() / pw, out_xyz);
+}
+// pieces of one streamed MSM: enough work per piece to keep its fixed costs (sort floors, bucket reduction) small
+size_t msm_stream_step(size_t n) {
+  size_t pieces = n >= ((size_t)1 << 23) ? 4 : (n >= ((size_t)1 << 21) ? 2 : 1);
+  if (const char* e = getenv("ARK_HIP_STREAM_PIECES")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) pieces = (size_t)v;
+  }
+  return (n + pieces - 1) / pieces;
 }
 
 }  // namespace
@@ -485,6 +868,9 @@ void ark_hip_shutdown(void) {
       (void)hipStreamSynchronize(c->copy_stream);
       for (int j = 0; j < 2; j++)
         if (c->fft_side[j]) (void)hipStreamSynchronize(c->fft_side[j]);
+      while (!c->base_cache.empty()) cache_drop(c, c->base_cache.size() - 1);
+      c->stager.release();
+      if (c->lane_ev) (void)hipEventDestroy(c->lane_ev);
       c->msm[0].release();
       c->msm[1].release();
       c->fft.release();
@@ -518,7 +904,7 @@ int ark_hip_synchronize(void) {
   return 0;
 }
 
-const char* ark_hip_version(void) { return "ark_hip 0.2 (gfx950)"; }
+const char* ark_hip_version(void) { return "ark_hip 0.3 (gfx950)"; }
 
 int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_field, int* ext_degree) {
   if (curve < 0 || curve > 4) return ARK_HIP_ERR_ARG;
@@ -629,20 +1015,56 @@ int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars,
   return ark_hip_msm_wait(job, out_xyz);
 }
 
+// The entry SWCurveConfig::msm / the msm_bigint hook land in (rust/ark-hip/src/msm.rs, patches/0001): host slices in,
+// Projective out.  The base set is looked up in (or entered into) the context's resident-base cache, so that a prover
+// calling with the same SRS slice again pays only for its scalars; those are streamed in pieces (msm_stream).
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xyz) {
   if (curve < 0 || curve > 4 || !out_xyz || (n && (!bases || !scalars))) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
   Context* c = sc.c;
-  size_t bb = n * (size_t)CURVES[curve].fe_words * 2 * 8, sb = n * 32;
-  if (n) {
-    if (c->stage_a.ensure(bb) || c->stage_b.ensure(sb)) return ARK_HIP_ERR_NOMEM;
-    ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, bases, bb, hipMemcpyHostToDevice, c->stream));
-    ARK_HIP_TRY(hipMemcpyAsync(c->stage_b.p, scalars, sb, hipMemcpyHostToDevice, c->stream));
+  if (n == 0) return msm_stream(c, curve, nullptr, nullptr, nullptr, 0, mont, 0, out_xyz);
+  BaseCacheEntry* ce = nullptr;
+  if (int rc = cache_get(c, curve, bases, n, &ce)) return rc;
+  if (!ce)  // not cacheable (disabled / over budget / no room): bases and scalars both stream through the ring
+    return msm_stream(c, curve, nullptr, bases, scalars, n, mont, msm_stream_step(n), out_xyz);
+  if (c->auto_prepare > 0 && !ce->prepared && ce->hits >= (unsigned)c->auto_prepare) {
+    ark_hip_msm_bases* pb = nullptr;  // a failed build (no room for the table) just leaves the plain path in place
+    if (ark_hip_msm_bases_prepare_device(curve, ce->dev.p, n, &pb) == 0) ce->prepared = (PreparedBases*)pb;
+    else ce->hits = 0;
   }
-  // the staging buffers stay locked with the context until the result is back
-  int slot = msm_enqueue_ctx(c, curve, c->stage_a.p, 0, nullptr, c->stage_b.p, n, mont);
-  if (slot < 0) return slot;
-  return msm_finish_ctx(c, curve, slot, out_xyz);
+  if (ce->prepared) return ark_hip_msm_prepared((const ark_hip_msm_bases*)ce->prepared, scalars, n, mont, out_xyz);
+  return msm_stream(c, curve, ce->dev.p, nullptr, scalars, n, mont, msm_stream_step(n), out_xyz);
+}
+
+// ---- resident-base cache control ----
+int ark_hip_msm_cache_config(long long budget_bytes, int auto_prepare_after) {
+  ARK_SCOPE(sc);
+  cache_configure(sc.c);
+  if (budget_bytes >= 0) {
+    sc.c->cache_budget = budget_bytes;
+    if (budget_bytes == 0) {
+      if (int rc = cache_clear(sc.c)) return rc;
+    }
+  }
+  if (auto_prepare_after >= 0) sc.c->auto_prepare = auto_prepare_after;
+  return 0;
+}
+int ark_hip_msm_cache_clear(void) {
+  ARK_SCOPE(sc);
+  return cache_clear(sc.c);
+}
+int ark_hip_msm_cache_stats(uint64_t out[6]) {
+  if (!out) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  uint64_t bytes = 0;
+  for (auto& e : sc.c->base_cache) bytes += e.dev.cap;
+  out[0] = sc.c->base_cache.size();
+  out[1] = bytes;
+  out[2] = sc.c->cache_stats.hits;
+  out[3] = sc.c->cache_stats.misses;
+  out[4] = sc.c->cache_stats.refreshed;
+  out[5] = sc.c->cache_stats.evicted;
+  return 0;
 }
 
 // the window plan the library would use (host arithmetic only: no GPU needed)
@@ -706,7 +1128,7 @@ int ark_hip_msm_bases_prepare(int curve, const uint64_t* bases, size_t n, ark_hi
   const size_t bb = n * (size_t)CURVES[curve].fe_words * 16;
   if (n) {
     if (c->stage_a.ensure(bb)) return ARK_HIP_ERR_NOMEM;
-    ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, bases, bb, hipMemcpyHostToDevice, c->stream));
+    if (int rc = c->stager.upload(c->stage_a.p, bases, bb, c->stream)) return rc;
   }
   return ark_hip_msm_bases_prepare_device(curve, c->stage_a.p, n, out);
 }
@@ -716,8 +1138,7 @@ int ark_hip_msm_bases_free(ark_hip_msm_bases* bases) {
   Scope sc;
   if (int rc = sc.enter(pb->logical)) return rc;
   if (int rc = sync_compute(sc.c)) return rc;  // a job in flight on either lane may still read the table
-  pb->table.release();
-  delete pb;
+  free_prepared(pb);
   return 0;
 }
 int ark_hip_msm_bases_info(const ark_hip_msm_bases* bases, size_t* n, int* window_bits, int* windows, size_t* table_bytes) {
@@ -762,6 +1183,10 @@ int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* s
   Scope sc;
   if (int rc = sc.enter(pb->logical)) return rc;
   Context* c = sc.c;
+  const int lane = msm_pick_lane(c);  // first: a BUSY return must not leave a copy from caller memory in flight
+  if (lane < 0) return lane;
+  hipStream_t compute;
+  if (int rc = msm_lane_stream(c, lane, &compute)) return rc;
   int k = 0;
   if (int rc = ring_acquire(c, &k)) return rc;
   if (n) {
@@ -769,16 +1194,20 @@ int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* s
       if (int rc = sync_compute(c)) return rc;  // growing frees memory an enqueued MSM may still read
       if (c->ring_s[k].ensure(n * 32)) return ARK_HIP_ERR_NOMEM;
     }
-    ARK_HIP_TRY(hipMemcpyAsync(c->ring_s[k].p, scalars, n * 32, hipMemcpyHostToDevice, c->copy_stream));
+    // page-locked scalars (ark_hip_host_alloc) are read in place by the DMA engine -- the caller keeps them valid until
+    // the wait returns; ordinary memory goes through the pinned staging ring and has been read when this returns
+    if (int rc = c->stager.upload(c->ring_s[k].p, scalars, n * 32, c->copy_stream, true)) {
+      (void)hipStreamSynchronize(c->copy_stream);
+      return rc;
+    }
   }
-  const int lane = msm_pick_lane(c);
-  if (lane < 0) return lane;
-  hipStream_t compute;
-  if (int rc = msm_lane_stream(c, lane, &compute)) return rc;
-  if (int rc = ring_publish(c, k, compute)) return rc;
-  int slot = msm_enqueue_ctx(c, pb->curve, pb->table.p, pb->n, &pb->plan, c->ring_s[k].p, n, mont, lane);
+  int rc = ring_publish(c, k, compute);
+  int slot = rc ? rc : msm_enqueue_ctx(c, pb->curve, pb->table.p, pb->n, &pb->plan, c->ring_s[k].p, n, mont, lane);
   (void)ring_release(c, k, compute);
-  if (slot < 0) return slot;
+  if (slot < 0) {
+    (void)hipStreamSynchronize(c->copy_stream);  // nothing reads caller memory once an error has been returned
+    return slot;
+  }
   *out_job = (ark_hip_msm_job*)new MsmJobHandle{pb->logical, pb->curve, slot};
   return 0;
 }
@@ -800,51 +1229,9 @@ int ark_hip_msm_sw_chunks(int curve, const uint64_t* bases, size_t n_bases, cons
     return ARK_HIP_ERR_ARG;
   if (step == 0) step = (size_t)1 << 20;
   ARK_SCOPE(sc);
-  Context* c = sc.c;
   const size_t ab = (size_t)CURVES[curve].fe_words * 16;
   const uint64_t* b0 = bases + (n_bases - n_scalars) * (ab / 8);
-  const size_t pw = (size_t)CURVES[curve].fe_words * 3;
-  std::vector<uint64_t> partials;  // Jacobian partial per step
-  int pending_slot[2] = {-1, -1};
-  int npend = 0;
-  auto drain_one = [&]() -> int {
-    uint64_t part[36];
-    int rc = msm_finish_ctx(c, curve, pending_slot[0], part);
-    pending_slot[0] = pending_slot[1];
-    npend--;
-    if (rc) return rc;
-    partials.insert(partials.end(), part, part + pw);
-    return 0;
-  };
-  for (size_t off = 0; off < n_scalars; off += step) {
-    const size_t cnt = n_scalars - off < step ? n_scalars - off : step;
-    if (npend == 2) {
-      if (int rc = drain_one()) return rc;
-    }
-    int k = 0;
-    if (int rc = ring_acquire(c, &k)) return rc;
-    if (c->ring_b[k].cap < cnt * ab || c->ring_s[k].cap < cnt * 32) {
-      if (int rc = sync_compute(c)) return rc;
-      if (c->ring_b[k].ensure((step < n_scalars ? step : n_scalars) * ab) ||
-          c->ring_s[k].ensure((step < n_scalars ? step : n_scalars) * 32))
-        return ARK_HIP_ERR_NOMEM;
-    }
-    ARK_HIP_TRY(hipMemcpyAsync(c->ring_b[k].p, b0 + off * (ab / 8), cnt * ab, hipMemcpyHostToDevice, c->copy_stream));
-    ARK_HIP_TRY(hipMemcpyAsync(c->ring_s[k].p, scalars + off * 4, cnt * 32, hipMemcpyHostToDevice, c->copy_stream));
-    const int lane = msm_pick_lane(c);  // step k+1 also sorts under step k's accumulate kernel
-    if (lane < 0) return lane;
-    hipStream_t compute;
-    if (int rc = msm_lane_stream(c, lane, &compute)) return rc;
-    if (int rc = ring_publish(c, k, compute)) return rc;
-    int slot = msm_enqueue_ctx(c, curve, c->ring_b[k].p, 0, nullptr, c->ring_s[k].p, cnt, 1, lane);
-    (void)ring_release(c, k, compute);
-    if (slot < 0) return slot;
-    pending_slot[npend++] = slot;
-  }
-  while (npend) {
-    if (int rc = drain_one()) return rc;
-  }
-  return ark_hip_sw_sum(curve, partials.data(), partials.size() / pw, out_xyz);
+  return msm_stream(sc.c, curve, nullptr, b0, scalars, n_scalars, 1, step, out_xyz);
 }
 
 // One MSM over the GPUs of this node from ONE host process: base-range shards (the reference's own split,
@@ -1001,7 +1388,7 @@ static int fft_host_entry(int field, const ark_hip_radix2_domain* dom, uint64_t*
   const size_t bytes = (size_t)dom->size * 32;
   if (num_coeffs > dom->size) return ARK_HIP_ERR_ARG;
   if (c->stage_a.ensure(bytes)) return ARK_HIP_ERR_NOMEM;
-  ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, data, num_coeffs * 32, hipMemcpyHostToDevice, c->stream));  // only what is there
+  if (int rc = c->stager.upload(c->stage_a.p, data, num_coeffs * 32, c->stream)) return rc;  // only what is there
   int rc = fft_device_entry(field, dom, c->stage_a.p, inverse, num_coeffs);
   if (rc) return rc;
   ARK_HIP_TRY(hipMemcpyAsync(data, c->stage_a.p, bytes, hipMemcpyDeviceToHost, c->stream));

@@ -511,6 +511,17 @@ int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
   return 0;
 }
 
+// The power-table cache is bounded (a caller cycling through offsets must not grow it for ever).  Eviction happens
+// only here, BEFORE a transform looks anything up: a transform takes at most two entries (pre + post), so the pointers
+// it has fetched are never freed under it.
+static inline int fft_powers_make_room(FftWorkspace& ws) {
+  if (ws.powers.size() + 2 <= 64) return 0;
+  ARK_HIP_TRY(hipDeviceSynchronize());  // transforms in flight on any stream may still read the tables
+  for (auto& kv : ws.powers) kv.second.release();
+  ws.powers.clear();
+  return 0;
+}
+
 // lo/hi power tables of `base4` for a size-2^k transform (hi optionally multiplied by `mul4`), or -- k < 0 -- the single
 // constant `base4`, resident and cached.  base4 / mul4 are host pointers.
 template <class FP>
@@ -521,11 +532,6 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
   if (mul4) key.mul = {mul4[0], mul4[1], mul4[2], mul4[3]};
   auto it = ws.powers.find(key);
   if (it == ws.powers.end()) {
-    if (ws.powers.size() >= 64) {  // bounded: a caller cycling through offsets must not grow the cache for ever
-      ARK_HIP_TRY(hipDeviceSynchronize());  // transforms in flight on any stream may still read the tables
-      for (auto& kv : ws.powers) kv.second.release();
-      ws.powers.clear();
-    }
     const size_t nlo = k < 0 ? 0 : ((size_t)1 << PW_LO_BITS);
     const size_t nhi = k < 0 ? 0 : (k > PW_LO_BITS ? ((size_t)1 << (k - PW_LO_BITS)) : 1);
     DevBuf buf;
@@ -579,6 +585,7 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     if (rc) return rc;
   }
   // coset scaling tables (cached per offset): x[i] *= h^i on the way in; out[i] *= postc * h^-i on the way out
+  if (int rc = fft_powers_make_room(ws)) return rc;
   const u32 *pre_lo = nullptr, *pre_hi = nullptr, *post_lo = nullptr, *post_hi = nullptr, *post_const = nullptr;
   if (pre4) {
     int rc = fft_get_powers<FP>(ws, k, pre4, nullptr, stream, &pre_lo, &pre_hi);

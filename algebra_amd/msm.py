@@ -79,6 +79,22 @@ def msm_bigint(curve, bases, bigints):
     return _run(curve, bases, bigints, n, False)
 
 
+def base_cache_config(budget_bytes=-1, auto_prepare_after=-1):
+    """Resident-base cache of the host-array entry (ark_hip_msm_cache_config): numpy base sets passed to msm /
+    msm_bigint are kept on the GPU per (array address, length, sampled fingerprint).  0 bytes disables it."""
+    check(lib().ark_hip_msm_cache_config(int(budget_bytes), int(auto_prepare_after)), "ark_hip_msm_cache_config")
+
+
+def base_cache_clear():
+    check(lib().ark_hip_msm_cache_clear(), "ark_hip_msm_cache_clear")
+
+
+def base_cache_stats():
+    out = (C.c_uint64 * 6)()
+    check(lib().ark_hip_msm_cache_stats(out), "ark_hip_msm_cache_stats")
+    return dict(zip(("entries", "bytes", "hits", "misses", "refreshed", "evicted"), [int(v) for v in out]))
+
+
 def sum_projective(curve, points):
     """Sum of Projective points on the host (Projective: Sum, group.rs:659-663): the multi-GPU combine."""
     cid = cv.curve_id(curve)

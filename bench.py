@@ -5,20 +5,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): G1 scalar-muls/sec of a BLS12-381 G1 MSM, inputs resident in HBM.
-  N = 1  the configuration the metric is quoted on: ONE 2^24-point MSM per step on one GPU.
-  N > 1  BASELINE config 4: ONE 2^26-point MSM per step, base-range shards of 2^26/N pairs per GPU (strong scaling);
-         rank r owns pairs [r*n, (r+1)*n), computes its partial on its GPU, the 144-byte partials are all-gathered
-         over RCCL and summed (elliptic-curve addition, so not an RCCL reduction op).  A weak-scaling measurement
-         (2^24 per GPU) rides along as an extra key.
-The base set is a fixed SRS: it is uploaded and PREPARED once before the timed region (ark_hip_msm_bases_prepare:
-per-window multiples, include/ark_hip.h) -- the timed step is everything that depends on the scalars: digit recoding,
-bucket sort, bucket accumulation, bucket reduction, combine, result on the host.  The same MSM through the plain entry
-(raw bases, nothing precomputed) is timed next to it (`plain`), as are the Fr radix-2 FFT at 2^22 (`fft`), the
-roofline figures of the dominant kernel measured with HIP events inside this run, and the CPU baseline (the oracle's
-restatement of ark-ec's msm_bigint_wnaf on this box's host cores).
+  value   ONE MSM per step through the PLAIN entry -- ark_hip_msm_sw_device on raw bases, nothing precomputed: what
+          VariableBaseMSM::msm / msm_bigint compute (variable_base/mod.rs:59-85).  N = 1: 2^24 pairs (the configuration
+          the metric is quoted on).  N > 1: weak scaling, 2^24 pairs per GPU -- one 2^(24 + log2 N) MSM whose base-range
+          shard [r*2^24, (r+1)*2^24) lives on rank r; the 144-byte partials are all-gathered over RCCL and summed
+          (elliptic-curve addition, so not an RCCL reduction op).  No other collective exists on the path.
+  extras  (never `value`)  `prepared`: the same job against a PREPARED base set (ark_hip_msm_bases_prepare: per-window
+          multiples built once, outside the step, for a fixed SRS); `pipelined`: two asynchronous jobs in flight;
+          `trait_surface`: the same job through ark_hip_msm_sw from HOST pointers -- what SWCurveConfig::msm and the
+          msm_bigint hook call -- first call (bases + scalars over PCIe) and repeat calls (resident-base cache: scalars
+          only), PCIe-inclusive; `config4_strong_2_26`: BASELINE config 4 -- ONE 2^26 MSM split over the N ranks (N = 1:
+          the whole job on one GPU, the strong-scaling reference); the other BASELINE configs; the Fr FFT at 2^22; the
+          CPU baseline (the oracle's restatement of ark-ec's msm_bigint_wnaf on this box's host cores).
+The roofline figures of the dominant kernel are measured with HIP events on the library's stream inside this run.
 
 Synthetic inputs (tools/synth.py): bases P_i = (a + i*b)*G grown on the GPU from the generator; uniform
-scalars in [0, r).  After timing, the result is checked bit-exactly against k*G with k = sum_i s_i (a + i b) mod r
+scalars in [0, r).  After timing, every result is checked bit-exactly against k*G with k = sum_i s_i (a + i b) mod r
 (exact big-integer identity).
 """
 import argparse
@@ -44,10 +46,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # (profiles/r1_ubench_instruction_rates.txt, line 1); a Montgomery Fp384 product needs 2 * 12^2 = 288 of them
 MAD_U64_U32_PER_S = 27.73e12
 MADS_PER_MIXED_ADD = 8 * 288 + 432  # 8 products + one sum of two products under a single reduction (ec.cuh)
-# the same Montgomery product (fp.cuh's Comba with its carry chains) run back to back in a loop: the rate the multiplier
-# pipeline sustains for THIS instruction mix (profiles/r2_ubench_product_rate.txt, algebra_amd/csrc/ubench/mulbench.hip)
-COMBA384_GMUL_S_2_WAVES = 54.73   # 2 waves per SIMD -- the accumulate kernel's occupancy (214-220 VGPRs)
-COMBA384_GMUL_S_PEAK = 61.78      # 8 waves per SIMD
+LOG_PER_GPU = 24                    # pairs per GPU of the headline job (BASELINE config 2)
+LOG_CONFIG4 = 26                    # BASELINE config 4: one 2^26 MSM over all ranks
 limbs4 = S.limbs4
 
 
@@ -55,15 +55,11 @@ def gen_scalars(n, seed):
     return S.gen_scalars(n, seed, R_MOD)
 
 
-def dlog_of_msm(scalars, a, b):
-    return S.dlog_of_msm(scalars, a, b, R_MOD)
-
-
 def pmc_traffic(kernel, log_n):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json,
     produced by tools/pmc_traffic.py on this same command; FETCH_SIZE / WRITE_SIZE collected in separate passes,
     corrected as MI355X_MICROARCH.md prescribes).  None when no matching measurement is committed."""
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -81,14 +77,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=None,
-                    help="log2 of the TOTAL number of (base, scalar) pairs of one MSM (default: 24 on one GPU, "
-                         "26 on several -- BASELINE configs 2 and 4)")
-    ap.add_argument("--no-prepare", action="store_true", help="headline through the plain entry (raw bases)")
+                    help="log2 of the pairs PER GPU of the headline MSM (default 24: BASELINE config 2; the job is one "
+                         "MSM of 2^(log-n) * N pairs)")
     ap.add_argument("--fft-log-n", type=int, default=22)
     ap.add_argument("--fft-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=24)
-    ap.add_argument("--no-extras", action="store_true", help="skip the plain / weak-scaling / 2^26 side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip every side measurement")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +106,7 @@ def main():
     torch.cuda.set_device(dev_index)
     L = lib()
     check(L.ark_hip_init(dev_index), "ark_hip_init")
+    cid = cv.curve_id(CURVE)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -118,13 +114,11 @@ def main():
         else:
             dist.init_process_group(backend)
         # bring the communicator up outside the timed region (RCCL initialises lazily on the first collective)
-        D.combine_partials(cv.curve_id(CURVE), np.zeros(cv.projective_words(cv.curve_id(CURVE)), dtype=np.uint64))
+        D.combine_partials(cid, np.zeros(cv.projective_words(cid), dtype=np.uint64))
 
-    cid = cv.curve_id(CURVE)
-    log_total = args.log_n if args.log_n is not None else (24 if world == 1 else 26)
-    n_total = 1 << log_total
-    if n_total % world:
-        raise SystemExit("world size must divide 2^%d" % log_total)
+    log_local = args.log_n if args.log_n is not None else LOG_PER_GPU
+    n = 1 << log_local                      # pairs on this GPU
+    n_total = n * world                     # pairs of the one MSM
     ab = cv.affine_bytes(cid)
 
     def barrier():
@@ -177,108 +171,127 @@ def main():
         check(L.ark_hip_msm_set_timing(0), "set_timing")
         return res, elapsed, phases / max(steps, 1)
 
-    # ---- the headline job: ONE MSM of n_total pairs, base-range shards --------------------------------------
-    n = n_total // world
+    # ---- the headline job: ONE MSM of n_total pairs through the plain entry, base-range shards ----------------
     first = rank * n
     bases, scalars_h, scalars = make_inputs(n, first, 0xA11CE + rank)
-    prep_s = None
-    pb = None
-    if not args.no_prepare:
-        t0 = time.perf_counter()
-        pb = A.PreparedBases(cid, bases)
-        prep_s = time.perf_counter() - t0
-        headline_msm = pb.msm_bigint
-    else:
-        headline_msm = lambda sc: A.msm_bigint(cid, bases, sc)  # noqa: E731
-    result, elapsed, phases = run_timed(headline_msm, scalars, args.warmup, args.steps)
+    result, elapsed, phases = run_timed(lambda sc: A.msm_bigint(cid, bases, sc), scalars, args.warmup, args.steps)
     want = expected_affine(scalars_h, first)
     exact = bool(np.array_equal(A.into_affine(cid, result), want)) if rank == 0 else None
+    extras = not args.no_extras
 
-    # ---- the same MSM through the plain entry (raw bases, nothing precomputed) ------------------------------
-    plain = None
-    if not args.no_extras and not args.no_prepare:
-        r2, e2, ph2 = run_timed(lambda sc: A.msm_bigint(cid, bases, sc), scalars, 1, min(args.steps, 5))
-        if rank == 0:
-            st = min(args.steps, 5)
-            plain = {"what": "same job through ark_hip_msm_sw_device (raw bases, no table)", "value": n_total * st / e2,
-                     "ms_per_step": e2 * 1e3 / st, "window_bits": int(ph2[6]), "windows": int(ph2[7]),
-                     "accumulate_ms": ph2[3], "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, r2), want))}
-
-    # ---- the same MSMs with two jobs in flight (asynchronous entry): job k+1's digits / sort / reduction run under
-    # job k's accumulate kernel on the library's second MSM lane -- steady-state throughput of a prover that commits to
-    # one polynomial after another.  Never the headline: `value` above is one job at a time. ----------------------------
+    # ---- extension: the same job against a PREPARED base set (fixed SRS; the table is built outside the step) ----
+    prepared = None
     pipelined = None
-    if world == 1 and pb is not None and not args.no_extras:
-        st = max(args.steps, 4)
-        pb.msm_bigint_async(scalars).wait()
-        barrier()
-        t0 = time.perf_counter()
-        pend, last = [], None
-        for _ in range(st):
-            pend.append(pb.msm_bigint_async(scalars))
-            if len(pend) == 2:
-                last = pend.pop(0).wait()
-        while pend:
-            last = pend.pop(0).wait()
-        barrier()
-        ep = time.perf_counter() - t0
-        pipelined = {"what": "same MSM, two asynchronous jobs in flight (ark_hip_msm_prepared_device_async)",
-                     "value": n_total * st / ep, "ms_per_step": ep * 1e3 / st, "steps": st,
-                     "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, last), want))}
-
-    # ---- N > 1: weak scaling on the side (2^24 pairs per GPU) ----------------------------------------------
-    weak = None
-    if world > 1 and not args.no_extras and n != (1 << 24):
-        if pb is not None:
-            pb.free()
-            pb = None
-        del bases, scalars
-        torch.cuda.empty_cache()
-        nw = 1 << 24
-        wb, wsh, ws_ = make_inputs(nw, rank * nw, 0xBEEF + rank)
-        wpb = A.PreparedBases(cid, wb)
-        rw, ew, _ = run_timed(wpb.msm_bigint, ws_, 1, min(args.steps, 5))
-        wwant = expected_affine(wsh, rank * nw)
-        if rank == 0:
-            st = min(args.steps, 5)
-            weak = {"what": "2^24 pairs per GPU (one 2^%d MSM)" % (24 + int(np.log2(world))), "value": nw * world * st / ew,
-                    "ms_per_step": ew * 1e3 / st, "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, rw), wwant))}
-        wpb.free()
-        del wb, ws_
-        torch.cuda.empty_cache()
-        bases = scalars = None
-
-    # ---- N = 1: the 2^26 job on ONE GPU, so that the N > 1 lines have their strong-scaling reference ---------
-    big = None
-    if world == 1 and not args.no_extras and log_total == 24:
-        if pb is not None:
-            pb.free()
-            pb = None
-        torch.cuda.empty_cache()
-        nb_ = 1 << 26
-        bb, bsh, bs = make_inputs(nb_, 0, 0xB16)
-        res_b, el_b, ph_b = run_timed(lambda sc: A.msm_bigint(cid, bb, sc), bs, 1, 2)
-        kb = S.mul_gen(cid, S.dlog_of_msm(bsh, A0, B0, R_MOD), R_MOD)
-        big = {"what": "one 2^26 MSM on one GPU, plain entry", "value": nb_ * 2 / el_b, "ms_per_step": el_b * 1e3 / 2,
-               "window_bits": int(ph_b[6]), "windows": int(ph_b[7]),
-               "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_b), kb))}
+    if extras:
         try:
             t0 = time.perf_counter()
-            bpb = A.PreparedBases(cid, bb)
-            bprep = time.perf_counter() - t0
-            res_p, el_p, ph_p = run_timed(bpb.msm_bigint, bs, 1, 2)
-            big["prepared"] = {"value": nb_ * 2 / el_p, "ms_per_step": el_p * 1e3 / 2, "window_bits": int(ph_p[6]),
-                               "windows": int(ph_p[7]), "table_gib": bpb.info()["table_bytes"] / 2**30, "prepare_s": bprep,
-                               "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_p), kb))}
-            bpb.free()
-        except Exception as e:  # noqa: BLE001 -- the side measurement must never cost the headline line
-            big["prepared"] = {"error": repr(e)[:200]}
-        del bb, bs
+            pb = A.PreparedBases(cid, bases)
+            prep_s = time.perf_counter() - t0
+            st = min(args.steps, 5)
+            r2, e2, ph2 = run_timed(pb.msm_bigint, scalars, 1, st)
+            if rank == 0:
+                prepared = {"what": "same job, base set prepared ONCE outside the step (ark_hip_msm_bases_prepare: per-window "
+                                    "multiples of a fixed SRS in HBM); an extension, not the VariableBaseMSM::msm operation",
+                            "value": n_total * st / e2, "ms_per_step": e2 * 1e3 / st, "prepare_s": prep_s,
+                            "table_gib": pb.info()["table_bytes"] / 2**30, "window_bits": int(ph2[6]),
+                            "windows": int(ph2[7]), "accumulate_ms": ph2[3],
+                            "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, r2), want))}
+            # two asynchronous jobs in flight: job k+1's digits / sort / reduction run under job k's accumulate kernel
+            # on the library's second MSM lane -- steady state of a prover committing to one polynomial after another
+            if world == 1:
+                st = max(args.steps, 4)
+                pb.msm_bigint_async(scalars).wait()
+                barrier()
+                t0 = time.perf_counter()
+                pend, last = [], None
+                for _ in range(st):
+                    pend.append(pb.msm_bigint_async(scalars))
+                    if len(pend) == 2:
+                        last = pend.pop(0).wait()
+                while pend:
+                    last = pend.pop(0).wait()
+                barrier()
+                ep = time.perf_counter() - t0
+                pipelined = {"what": "prepared base set, two asynchronous jobs in flight (ark_hip_msm_prepared_device_async)",
+                             "value": n_total * st / ep, "ms_per_step": ep * 1e3 / st, "steps": st,
+                             "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, last), want))}
+            pb.free()
+            del pb
+        except Exception as e:  # noqa: BLE001 -- a side measurement must never cost the headline line
+            prepared = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
+
+    # ---- the trait surface: the same job through ark_hip_msm_sw from HOST pointers (N = 1) ---------------------
+    trait = None
+    if extras and world == 1:
+        try:
+            hb = bases.cpu().numpy().view(np.uint64).reshape(n, -1)   # ordinary (pageable) host memory, like a Rust Vec
+            A.base_cache_clear()
+            s0 = A.base_cache_stats()
+            t0 = time.perf_counter()
+            r_first = A.msm_bigint(cid, hb, scalars_h)
+            first_ms = (time.perf_counter() - t0) * 1e3
+            reps = 4
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r_rep = A.msm_bigint(cid, hb, scalars_h)
+            rep_ms = (time.perf_counter() - t0) * 1e3 / reps
+            s1 = A.base_cache_stats()
+            trait = {"what": "ark_hip_msm_sw(host bases, host scalars): the call behind SWCurveConfig::msm / the msm_bigint "
+                             "hook; PCIe-inclusive, pageable host memory; repeat calls hit the resident-base cache and "
+                             "upload only the 2^%d x 32 B of scalars, streamed in pieces" % log_local,
+                     "first_call_ms": first_ms, "repeat_call_ms": rep_ms, "repeat_value": n / (rep_ms * 1e-3),
+                     "host_bytes_first_call": int(hb.nbytes + scalars_h.nbytes), "host_bytes_repeat_call": int(scalars_h.nbytes),
+                     "cache": {k: s1[k] - s0[k] for k in ("hits", "misses", "refreshed", "evicted")},
+                     "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, r_first), want)
+                                             and np.array_equal(A.into_affine(cid, r_rep), want))}
+            A.base_cache_clear()
+            del hb
+        except Exception as e:  # noqa: BLE001
+            trait = {"error": repr(e)[:200]}
+
+    # ---- BASELINE config 4: ONE 2^26 MSM split over the ranks (strong scaling; N = 1: the whole job on one GPU) ----
+    config4 = None
+    if extras and (world > 1 or log_local == LOG_PER_GPU):
+        try:
+            nb_ = (1 << LOG_CONFIG4) // world
+            if nb_ == n:
+                bb, bsh, bs = bases, scalars_h, scalars
+            else:
+                del bases, scalars
+                bases = scalars = None
+                torch.cuda.empty_cache()
+                bb, bsh, bs = make_inputs(nb_, rank * nb_, 0xB16 + rank)
+            st = 2 if world == 1 else min(args.steps, 5)
+            res_b, el_b, ph_b = run_timed(lambda sc: A.msm_bigint(cid, bb, sc), bs, 1, st)
+            kb = expected_affine(bsh, rank * nb_)
+            if rank == 0:
+                config4 = {"what": "one 2^%d MSM, plain entry, %d pairs per GPU over %d GPU(s)" % (LOG_CONFIG4, nb_, world),
+                           "value": (1 << LOG_CONFIG4) * st / el_b, "ms_per_step": el_b * 1e3 / st, "scaling": "strong",
+                           "window_bits": int(ph_b[6]), "windows": int(ph_b[7]), "accumulate_ms": ph_b[3],
+                           "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_b), kb))}
+            if world == 1:
+                try:
+                    t0 = time.perf_counter()
+                    bpb = A.PreparedBases(cid, bb)
+                    bprep = time.perf_counter() - t0
+                    res_p, el_p, ph_p = run_timed(bpb.msm_bigint, bs, 1, 2)
+                    config4["prepared"] = {"value": nb_ * 2 / el_p, "ms_per_step": el_p * 1e3 / 2, "window_bits": int(ph_p[6]),
+                                           "windows": int(ph_p[7]), "table_gib": bpb.info()["table_bytes"] / 2**30,
+                                           "prepare_s": bprep,
+                                           "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_p), kb))}
+                    bpb.free()
+                except Exception as e:  # noqa: BLE001
+                    config4["prepared"] = {"error": repr(e)[:200]}
+            if nb_ != n:
+                del bb, bs
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            config4 = {"error": repr(e)[:200]}
 
     # ---- the other BASELINE configurations, one line each (rank 0, single GPU) --------------------------------
     others = None
-    if world == 1 and not args.no_extras:
+    if world == 1 and extras:
         others = {}
         for cname, lg, st in (("BN254_G1", 16, 20), ("BLS12_381_G1", 20, 10), ("BLS12_377_G2", 22, 3)):
             try:
@@ -365,7 +378,7 @@ def main():
 
     # ---- sharded FFT leg (N > 1): 2^fft_log_n coefficients per GPU, all-to-all exchanges over RCCL ----------
     fft_sharded = None
-    if world > 1 and args.fft_steps > 0 and not args.no_extras:
+    if world > 1 and args.fft_steps > 0 and extras:
         try:
             nloc = 1 << args.fft_log_n
             ntot = nloc * world
@@ -385,7 +398,7 @@ def main():
                                      % args.fft_log_n,
                            "value": ntot * args.fft_steps / float(tt[0].item()), "unit": "elements/s",
                            "ms_per_step": float(tt[0].item()) * 1e3 / args.fft_steps, "log_n_total": int(np.log2(ntot)),
-                           "ifft_fft_roundtrip_exact": float(tt[1].item()) == 0.0, "exchanges": "3 all-to-all"}
+                           "ifft_fft_roundtrip_exact": float(tt[1].item()) == 0.0}
         except Exception as e:  # never lose the MSM line to the secondary leg
             fft_sharded = {"error": repr(e)[:300]}
 
@@ -394,7 +407,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O  # test infrastructure: used here only as the timed CPU baseline
-        ns = 1 << min(args.cpu_sample_log_n, int(np.log2(n)))
+        ns = 1 << min(args.cpu_sample_log_n, log_local)
         if bases is None or bases.numel() < ns * ab:
             bases, scalars_h, scalars = make_inputs(ns, 0, 0xA11CE)
         hb = bases[: ns * ab].cpu().numpy().view(np.uint64).reshape(ns, -1)
@@ -417,11 +430,12 @@ def main():
         # mixed additions actually executed by the accumulate kernel: one per (scalar, window) with a non-zero digit,
         # minus the first point of every non-empty bucket (a copy, not an addition)
         entries = n * W * (1.0 - 2.0 ** -cbits)
-        nbuckets = (1 << (cbits - 1)) if not args.no_prepare else W * (1 << (cbits - 1))
+        nbuckets = W * (1 << (cbits - 1))
         madds = entries - nbuckets * (1.0 - np.exp(-entries / nbuckets))
         mads_per_s = madds * MADS_PER_MIXED_ADD / (acc_ms * 1e-3)
+        traffic, traffic_src = pmc_traffic("msm_accumulate_kernel", log_local)
         out = {
-            "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (log_total, "" if world == 1 else " over %d GPUs" % world),
+            "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (int(np.log2(n_total)), "" if world == 1 else " over %d GPUs" % world),
             "value": n_total * args.steps / elapsed,
             "unit": "scalar-muls/s",
             "n_gpus": world,
@@ -429,47 +443,34 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong",
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "BLS12-381 G1 MSM, one job of 2^%d random bases/scalars, device resident, %s"
-                                   % (log_total, "raw bases" if args.no_prepare else
-                                      "base set prepared once (fixed SRS: per-window multiples in HBM)"),
+            "config": {"workload": "BLS12-381 G1 MSM, one job of 2^%d random bases/scalars, device resident, plain entry "
+                                   "(raw bases, nothing precomputed: VariableBaseMSM::msm_bigint)" % int(np.log2(n_total)),
                        "arithmetic": "Montgomery Fp384 on 32-bit limbs (v_mad_u64_u32), exact integers",
                        "curve": CURVE, "window_bits": cbits, "windows": W,
-                       "pairs_per_gpu": n, "sharding": "base-range, %d rank(s)" % world,
-                       "prepare_s": prep_s},
+                       "pairs_per_gpu": n, "sharding": "base-range, %d rank(s), partials all-gathered" % world},
             "bit_exact_vs_kG": exact,
             "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
                           "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_%skernel" % ("" if args.no_prepare else "shared_"),
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic("msm_accumulate_%skernel" % ("" if args.no_prepare else "shared_"),
-                                                int(np.log2(n)))[0],
-                         "traffic_source": pmc_traffic("msm_accumulate_%skernel" % ("" if args.no_prepare else "shared_"),
-                                                       int(np.log2(n)))[1],
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "alu": {"what": "v_mad_u64_u32 lane-ops/s issued by the mixed additions the accumulate kernel "
                                          "executes (%d per addition: 8 Montgomery products + one two-product sum) vs the "
                                          "instruction's measured issue rate on this chip" % MADS_PER_MIXED_ADD,
                                  "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
                                  "frac": mads_per_s / MAD_U64_U32_PER_S,
-                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32)",
-                                 "montgomery_products": {
-                                     "what": "the same work in Fp384 Montgomery products (288 multiply-adds each) vs the "
-                                             "rate of that product alone in a tight loop: what is left above the kernel "
-                                             "is the product's own carry handling, not the kernel around it",
-                                     "achieved_gmul_s": mads_per_s / 288.0 / 1e9,
-                                     "loop_rate_at_kernel_occupancy_gmul_s": COMBA384_GMUL_S_2_WAVES,
-                                     "loop_rate_peak_gmul_s": COMBA384_GMUL_S_PEAK,
-                                     "frac_of_peak": mads_per_s / 288.0 / 1e9 / COMBA384_GMUL_S_PEAK}},
+                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32)"},
                          "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
             "cpu_baseline": cpu,
-            "plain": plain,
+            "trait_surface": trait,
+            "prepared": prepared,
             "pipelined": pipelined,
-            "weak_scaling": weak,
-            "msm_2_26_one_gpu": big,
+            "config4_strong_2_26": config4,
             "other_configs": others,
             "fft": fft,
             "fft_sharded": fft_sharded,

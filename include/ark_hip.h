@@ -24,6 +24,9 @@
  * Environment: ARK_HIP_WAIT=block makes an MSM wait for the GPU with a blocking hipEventSynchronize; by default the
  * calling thread polls the completion event (the MSM is on its caller's critical path; a sleeping thread was measured
  * to add up to 1 ms per call on some hosts).  ARK_HIP_MSM_C / ARK_HIP_MSM_C_PREPARED force the window size (tuning).
+ * ARK_HIP_COPY_THREADS (default 4; 0 = leave it to the HIP runtime): worker threads that stage uploads from ordinary
+ * (pageable) host memory through page-locked buffers.  ARK_HIP_STREAM_PIECES: pieces a host-scalar MSM is cut into
+ * (default 4 from 2^23 pairs, 2 from 2^21).  ARK_HIP_BASE_CACHE_MB / ARK_HIP_AUTO_PREPARE: see ark_hip_msm_cache_config.
  */
 #ifndef ARK_HIP_H
 #define ARK_HIP_H
@@ -87,6 +90,21 @@ int ark_hip_curve_generator(int curve, uint64_t* out_xy);
  * silently drops bits above ceil(bits/c)*c there, i.e. its result depends on the window size it happened to pick. */
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int scalars_are_montgomery,
                    uint64_t* out_xyz);
+/* Resident-base cache of ark_hip_msm_sw (and of ark_hip_msm_sw_multi, per device).  The reference's callers hand the SAME
+ * `&[Affine]` -- an SRS -- to msm / msm_bigint on every call (bench-templates/src/macros/ec.rs:223-240 does exactly that),
+ * so the host-pointer entry keeps a device copy per (curve, host address, length), validated on every call by a
+ * fingerprint of sampled content (4096 evenly spaced points + the last): a repeat call uploads only its scalars, which
+ * stream in pieces behind the previous piece's kernels.  A set that was replaced or regenerated at the same address is
+ * noticed and re-uploaded; an in-place edit confined to unsampled points is NOT -- call ark_hip_msm_cache_clear after
+ * patching a base set in place, or disable the cache.  Least-recently-used sets are dropped beyond the budget.
+ *   ark_hip_msm_cache_config(budget_bytes, auto_prepare_after): budget < 0 keeps the current value (default: a quarter
+ *     of the device memory, or ARK_HIP_BASE_CACHE_MB), 0 disables and empties the cache; auto_prepare_after = K > 0
+ *     builds the per-window table of a cached set (ark_hip_msm_bases_prepare) once it has been hit K times
+ *     (default 0 = never, or ARK_HIP_AUTO_PREPARE), < 0 keeps the current value.
+ *   ark_hip_msm_cache_stats: [entries, device bytes, hits, misses, refreshed (content changed), evicted]. */
+int ark_hip_msm_cache_config(long long budget_bytes, int auto_prepare_after);
+int ark_hip_msm_cache_clear(void);
+int ark_hip_msm_cache_stats(uint64_t out[6]);
 /* Same with bases/scalars already in this GPU's memory (device pointers); out_xyz is a host pointer. */
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalars_are_montgomery,
                           uint64_t* out_xyz);

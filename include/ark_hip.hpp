@@ -80,6 +80,19 @@ using Bls12_377G1 = CurveTag<ARK_HIP_BLS12_377_G1, 6, ARK_HIP_BLS12_377_FR>;
 using Bls12_377G2 = CurveTag<ARK_HIP_BLS12_377_G2, 12, ARK_HIP_BLS12_377_FR>;
 using Bls12_381G2 = CurveTag<ARK_HIP_BLS12_381_G2, 12, ARK_HIP_BLS12_381_FR>;
 
+// Resident-base cache behind VariableBaseMSM<..>::msm / msm_bigint (ark_hip_msm_cache_* in ark_hip.h): base vectors
+// passed again at the same address stay on the GPU; a repeat call uploads only its scalars.
+struct BaseCacheStats { uint64_t entries, bytes, hits, misses, refreshed, evicted; };
+inline void base_cache_config(long long budget_bytes = -1, int auto_prepare_after = -1) {
+  check(ark_hip_msm_cache_config(budget_bytes, auto_prepare_after), "ark_hip_msm_cache_config");
+}
+inline void base_cache_clear() { check(ark_hip_msm_cache_clear(), "ark_hip_msm_cache_clear"); }
+inline BaseCacheStats base_cache_stats() {
+  uint64_t o[6];
+  check(ark_hip_msm_cache_stats(o), "ark_hip_msm_cache_stats");
+  return BaseCacheStats{o[0], o[1], o[2], o[3], o[4], o[5]};
+}
+
 // Result<Projective, usize> of VariableBaseMSM::msm
 template <class T>
 struct MsmResult {

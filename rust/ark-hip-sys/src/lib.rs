@@ -3,7 +3,7 @@
 //! surface: ark-ec and ark-poly `#![forbid(unsafe_code)]` (ec/src/lib.rs:10, poly/src/lib.rs:4).
 #![allow(non_camel_case_types)]
 use ark_ff::{FftField, Field, PrimeField};
-use core::ffi::{c_char, c_int, c_void};
+use core::ffi::{c_char, c_int, c_longlong, c_void};
 
 // field ids / curve ids of include/ark_hip.h
 pub const BN254_FQ: c_int = 0;
@@ -65,6 +65,9 @@ extern "C" {
     pub fn ark_hip_host_free(ptr: *mut c_void) -> c_int;
     pub fn ark_hip_msm_sw(curve: c_int, bases: *const u64, scalars: *const u64, n: usize,
                           scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_cache_config(budget_bytes: c_longlong, auto_prepare_after: c_int) -> c_int;
+    pub fn ark_hip_msm_cache_clear() -> c_int;
+    pub fn ark_hip_msm_cache_stats(out: *mut u64) -> c_int;
     pub fn ark_hip_msm_sw_device(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,
                                  scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_msm_sw_device_async(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,

@@ -108,6 +108,26 @@ pub fn sw_msm_chunks<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalar
     (rc == 0).then(|| unsafe { out.assume_init() })
 }
 
+/// Resident-base cache behind `sw_msm` / `sw_msm_bigint` (include/ark_hip.h, `ark_hip_msm_cache_*`): the library keeps a
+/// device copy of every base slice it is handed, keyed by (curve, address, length) and validated by a fingerprint of
+/// sampled content, so that `G::msm_bigint(&srs, ..)` called again with the same SRS uploads only its scalars.
+/// Rust's borrow rules make the common case safe by construction (the slice cannot change during a call); between calls a
+/// `Vec` that is overwritten wholesale or reallocated is noticed, one that is patched in a few places may not be --
+/// call [`base_cache_clear`] after such an edit.  `budget_bytes = Some(0)` turns the cache off.
+pub fn base_cache_config(budget_bytes: Option<u64>, auto_prepare_after: Option<u32>) -> bool {
+    let b = budget_bytes.map(|v| v as core::ffi::c_longlong).unwrap_or(-1);
+    let a = auto_prepare_after.map(|v| v as c_int).unwrap_or(-1);
+    unsafe { sys::ark_hip_msm_cache_config(b, a) == 0 }
+}
+pub fn base_cache_clear() -> bool {
+    unsafe { sys::ark_hip_msm_cache_clear() == 0 }
+}
+/// `[entries, device bytes, hits, misses, refreshed, evicted]`
+pub fn base_cache_stats() -> Option<[u64; 6]> {
+    let mut out = [0u64; 6];
+    (unsafe { sys::ark_hip_msm_cache_stats(out.as_mut_ptr()) } == 0).then_some(out)
+}
+
 /// One MSM over `n_gpus` GPUs of this node, driven from this process (base-range shards, variable_base/mod.rs:521-557).
 pub fn msm_multi<P: SWCurveConfig>(curve: c_int, n_gpus: usize, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Option<Projective<P>> {
     if !layout_ok::<P, BigIntOf<P>>(curve) {
