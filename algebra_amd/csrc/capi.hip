@@ -195,7 +195,8 @@ struct Context {
   DevBuf ring_s[2], ring_b[2];         // double-buffered scalar / base uploads of the streaming entry points
   hipEvent_t ring_free[2] = {nullptr, nullptr}, ring_up[2] = {nullptr, nullptr};
   int ring_next = 0;
-  hipEvent_t lane_ev = nullptr;        // orders the second MSM lane after the context stream (producers of its inputs)
+  hipEvent_t lane_ev = nullptr;        // last asynchronous PRODUCER on the context stream (FFT, pointwise product): the
+  bool lane_ev_set = false;            // second MSM lane starts behind it -- but not behind lane 0's own MSM kernels
   HostStager stager;
   std::vector<BaseCacheEntry> base_cache;
   BaseCacheStats cache_stats;
@@ -586,18 +587,22 @@ int sync_compute(Context* c) {  // both MSM lanes idle
   if (c->stream_b) ARK_HIP_TRY(hipStreamSynchronize(c->stream_b));
   return 0;
 }
+// called by every entry point that leaves work running on the context stream whose OUTPUT a caller may hand to an MSM
+int mark_producer(Context* c) {
+  if (!c->lane_ev) ARK_HIP_TRY(hipEventCreateWithFlags(&c->lane_ev, hipEventDisableTiming));
+  ARK_HIP_TRY(hipEventRecord(c->lane_ev, c->stream));
+  c->lane_ev_set = true;
+  return 0;
+}
 // returns lane * MSM_JOBS + slot, or a negative error
 int msm_enqueue_ctx(Context* c, int curve, const void* pts, size_t wstride, const MsmPlan* prep, const void* d_scalars,
                     size_t n, int mont, int lane = 0) {
   hipStream_t st;
   if (int rc = msm_lane_stream(c, lane, &st)) return rc;
-  if (lane) {
-    // the device-pointer entry points are documented as asynchronous on the context stream: an FFT / pointwise product
-    // queued there may be producing this job's scalars, so the second lane starts behind everything queued so far
-    if (!c->lane_ev) ARK_HIP_TRY(hipEventCreateWithFlags(&c->lane_ev, hipEventDisableTiming));
-    ARK_HIP_TRY(hipEventRecord(c->lane_ev, c->stream));
-    ARK_HIP_TRY(hipStreamWaitEvent(st, c->lane_ev, 0));
-  }
+  // the device-pointer FFT / pointwise-product entry points are asynchronous on the context stream (= lane 0) and may be
+  // producing this job's scalars: the second lane starts behind the last of them (mark_producer), while lane 0's own MSM
+  // kernels -- which lane 1 exists to overlap -- are not waited for
+  if (lane && c->lane_ev_set) ARK_HIP_TRY(hipStreamWaitEvent(st, c->lane_ev, 0));
   int slot = msm_enqueue_dispatch(curve, c->msm[lane], pts, wstride, prep, d_scalars, n, mont, st, c->msm_timing);
   return slot < 0 ? slot : lane * MSM_JOBS + slot;
 }
@@ -1379,7 +1384,8 @@ static int fft_device_entry(int field, const ark_hip_radix2_domain* dom, void* d
     if (upto > num_coeffs)
       ARK_HIP_TRY(hipMemsetAsync((char*)d + num_coeffs * 32, 0, (upto - num_coeffs) * 32, sc.c->stream));
   }
-  return fft_any(sc.c, field, dom, d, inverse, zlog);
+  if (int rc = fft_any(sc.c, field, dom, d, inverse, zlog)) return rc;
+  return mark_producer(sc.c);
 }
 static int fft_host_entry(int field, const ark_hip_radix2_domain* dom, uint64_t* data, int inverse, size_t num_coeffs) {
   if (!dom || !data) return ARK_HIP_ERR_ARG;
@@ -1445,6 +1451,7 @@ int ark_hip_fft_batch_in_place_device(int field, const ark_hip_radix2_domain* do
     (void)hipEventRecord(c->fft_ev[j + 1], c->fft_side[j]);
     (void)hipStreamWaitEvent(c->stream, c->fft_ev[j + 1], 0);
   }
+  if (rc == 0) rc = mark_producer(c);
   return rc;
 }
 
@@ -1454,7 +1461,8 @@ int ark_hip_fft_batch_in_place_device(int field, const ark_hip_radix2_domain* do
 int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n) {
   if (n && (!d_a || !d_b || !d_r)) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
-  return fr_mul_dispatch(field, d_a, d_b, d_r, n, sc.c->stream);
+  if (int rc = fr_mul_dispatch(field, d_a, d_b, d_r, n, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
 }
 
 // out = base^exp in Fr (host arithmetic): domain elements / twiddles for hosts without field code of their own
@@ -1474,7 +1482,8 @@ int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out)
 int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, const uint64_t* root) {
   if (!d_data || !root) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
-  return fft_axis_dispatch(field, sc.c->fft, d_data, G, cols, root, sc.c->stream);
+  if (int rc = fft_axis_dispatch(field, sc.c->fft, d_data, G, cols, root, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
 }
 
 int ark_hip_fft_set_timing(int enable) {
