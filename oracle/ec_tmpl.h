@@ -419,23 +419,100 @@ static void ECN(msm_wnaf_parallel)(const ark_curve_ctx *C, u64 *out_jac, const u
     free(digits);
 }
 
-/* mod.rs:512-558 msm_bigint_wnaf: threads/2 base-range chunks, each on its own 2-thread pool */
+/* mod.rs:512-558 msm_bigint_wnaf: threads/2 base-range chunks, each summed with msm_bigint_wnaf_parallel (:437-503)
+ * on its own 2-thread pool, chunk sums added up.  The ARITHMETIC here is exactly that -- the same chunk boundaries, the
+ * same per-chunk window size c = ln_without_floats(chunk) + 2, the same digits, bucket sums and window combine -- but
+ * the SCHEDULE is flat: rayon's nested pools keep every core busy in the reference (work stealing), whereas nested
+ * OpenMP regions run serially by default, which left half the cores idle and serialised the digit pass (the round-2
+ * baseline, 1.2e6 scalar-muls/s on 256 cores).  Three flat phases over all `threads` threads:
+ *   1. digits of every scalar (window-major per chunk, int32: c <= 22 bits),
+ *   2. one task per (chunk, window): bucket accumulation + running-sum reduction, buckets in a per-thread arena,
+ *   3. one task per chunk: window combine; then the chunk sums are added in order. */
 static void ECN(msm_wnaf)(const ark_curve_ctx *C, u64 *out_jac, const u64 *bases, const u64 *scalars, size_t size, int threads) {
     ECN(jac_set_zero)(C, out_jac);
     if (size == 0) return;
+    if (threads < 1) threads = 1;
     size_t num_chunks = threads < 2 ? 1 : (size_t)threads / 2;
     size_t chunk = size / num_chunks;
     if (chunk == 0) chunk = size;
     size_t nchunks = (size + chunk - 1) / chunk;
-    u64 *partial = (u64 *)malloc(nchunks * 3 * FW * 8);
-    int inner = threads < 2 ? 1 : 2;
-#pragma omp parallel for num_threads((int)(nchunks < (size_t)threads ? nchunks : (size_t)threads)) schedule(dynamic, 1)
+    const int num_bits = C->S->bits;
+    /* per-chunk geometry (the last chunk may be shorter and so may use a smaller c) */
+    int *cs = (int *)malloc(nchunks * sizeof(int));
+    int *dcs = (int *)malloc(nchunks * sizeof(int));
+    size_t *doff = (size_t *)malloc((nchunks + 1) * sizeof(size_t)); /* start of chunk k's digits */
+    size_t *toff = (size_t *)malloc((nchunks + 1) * sizeof(size_t)); /* first (chunk, window) task of chunk k */
+    doff[0] = 0;
+    toff[0] = 0;
     for (size_t k = 0; k < nchunks; k++) {
-        size_t lo = k * chunk, hi = lo + chunk > size ? size : lo + chunk;
-        ECN(msm_wnaf_parallel)(C, partial + k * 3 * FW, bases + lo * 2 * FW, scalars + lo * SCALAR_LIMBS, hi - lo, inner);
+        size_t lo = k * chunk, hi = lo + chunk > size ? size : lo + chunk, len = hi - lo;
+        cs[k] = len < 32 ? 3 : (int)ln_without_floats(len) + 2;
+        dcs[k] = (num_bits + cs[k] - 1) / cs[k];
+        doff[k + 1] = doff[k] + len * (size_t)dcs[k];
+        toff[k + 1] = toff[k] + (size_t)dcs[k];
+    }
+    const size_t ntasks = toff[nchunks];
+    int32_t *digits = (int32_t *)malloc(doff[nchunks] * sizeof(int32_t));
+    u64 *window_sums = (u64 *)malloc(ntasks * 4 * FW * 8);
+    u64 *partial = (u64 *)malloc(nchunks * 3 * FW * 8);
+#pragma omp parallel num_threads(threads)
+    {
+        /* phase 1: digits[doff[k] + w * len + i] = digit w of scalar lo + i */
+#pragma omp for schedule(static)
+        for (size_t i = 0; i < size; i++) {
+            size_t k = i / chunk;
+            if (k >= nchunks) k = nchunks - 1;
+            size_t lo = k * chunk, hi = lo + chunk > size ? size : lo + chunk, len = hi - lo;
+            int64_t d[96];
+            make_digits(scalars + i * SCALAR_LIMBS, SCALAR_LIMBS, cs[k], num_bits, d);
+            for (int w = 0; w < dcs[k]; w++) digits[doff[k] + (size_t)w * len + (i - lo)] = (int32_t)d[w];
+        }
+        /* phase 2: (chunk, window) tasks */
+        u64 *arena = NULL;
+        size_t arena_nb = 0;
+#pragma omp for schedule(dynamic, 1)
+        for (size_t t = 0; t < ntasks; t++) {
+            size_t k = 0; /* chunks have (almost) all the same window count: start near t / dcs[0] */
+            k = t / (size_t)dcs[0];
+            if (k >= nchunks) k = nchunks - 1;
+            while (toff[k] > t) k--;
+            while (toff[k + 1] <= t) k++;
+            const int w = (int)(t - toff[k]);
+            size_t lo = k * chunk, hi = lo + chunk > size ? size : lo + chunk, len = hi - lo;
+            const size_t nb = (size_t)1 << cs[k];
+            if (arena_nb < nb) {
+                free(arena);
+                arena = (u64 *)malloc(nb * 4 * FW * 8);
+                arena_nb = nb;
+            }
+            for (size_t b = 0; b < nb; b++) ECN(bkt_set_zero)(C, arena + b * 4 * FW);
+            const int32_t *dg = digits + doff[k] + (size_t)w * len;
+            const u64 *bs = bases + lo * 2 * FW;
+            for (size_t i = 0; i < len; i++) {
+                int32_t d = dg[i];
+                if (d > 0)
+                    ECN(bkt_add_affine)(C, arena + (size_t)(d - 1) * 4 * FW, bs + i * 2 * FW, 0);
+                else if (d < 0)
+                    ECN(bkt_add_affine)(C, arena + (size_t)(-(int64_t)d - 1) * 4 * FW, bs + i * 2 * FW, 1);
+            }
+            u64 *res = window_sums + t * 4 * FW;
+            ECN(bkt_set_zero)(C, res);
+            ECN(reduce_buckets)(C, res, arena, nb);
+        }
+        free(arena);
+        /* phase 3: window combine per chunk */
+#pragma omp for schedule(dynamic, 1)
+        for (size_t k = 0; k < nchunks; k++)
+            ECN(combine_windows)(C, partial + k * 3 * FW, window_sums + toff[k] * 4 * FW, dcs[k], cs[k]);
     }
     for (size_t k = 0; k < nchunks; k++) ECN(jac_add)(C, out_jac, partial + k * 3 * FW);
     free(partial);
+    free(window_sums);
+    free(digits);
+    free(toff);
+    free(doff);
+    free(dcs);
+    free(cs);
 }
 
 /* mod.rs:657-751 msm_serial over u64-sized scalars (unsigned windows, scalar == 1 fast path) */
