@@ -198,6 +198,8 @@ struct Context {
   hipEvent_t lane_ev = nullptr;        // last asynchronous PRODUCER on the context stream (FFT, pointwise product): the
   bool lane_ev_set = false;            // second MSM lane starts behind it -- but not behind lane 0's own MSM kernels
   HostStager stager;
+  DevBuf piece_buckets;                // streamed MSM: the ONE bucket array its pieces share (MsmPiece)
+  hipEvent_t piece_ev[2] = {nullptr, nullptr};
   std::vector<BaseCacheEntry> base_cache;
   BaseCacheStats cache_stats;
   uint64_t cache_clock = 0;
@@ -309,8 +311,9 @@ const CurveInfo CURVES[5] = {
 #endif
 
 int msm_enqueue_dispatch(int curve, MsmWorkspace& ws, const void* pts, size_t wstride, const MsmPlan* prep, const void* s,
-                         size_t n, int mont, hipStream_t st, bool timing) {
-#define X(NAME) msm_enqueue_##NAME(ws, pts, wstride, prep, s, n, mont, st, timing)
+                         size_t n, int mont, hipStream_t st, bool timing, int sbytes = 0, int sbits = 0,
+                         const MsmPiece* piece = nullptr) {
+#define X(NAME) msm_enqueue_##NAME(ws, pts, wstride, prep, s, n, mont, st, timing, sbytes, sbits, piece)
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
@@ -596,14 +599,15 @@ int mark_producer(Context* c) {
 }
 // returns lane * MSM_JOBS + slot, or a negative error
 int msm_enqueue_ctx(Context* c, int curve, const void* pts, size_t wstride, const MsmPlan* prep, const void* d_scalars,
-                    size_t n, int mont, int lane = 0) {
+                    size_t n, int mont, int lane = 0, int sbytes = 0, int sbits = 0, const MsmPiece* piece = nullptr) {
   hipStream_t st;
   if (int rc = msm_lane_stream(c, lane, &st)) return rc;
   // the device-pointer FFT / pointwise-product entry points are asynchronous on the context stream (= lane 0) and may be
   // producing this job's scalars: the second lane starts behind the last of them (mark_producer), while lane 0's own MSM
   // kernels -- which lane 1 exists to overlap -- are not waited for
   if (lane && c->lane_ev_set) ARK_HIP_TRY(hipStreamWaitEvent(st, c->lane_ev, 0));
-  int slot = msm_enqueue_dispatch(curve, c->msm[lane], pts, wstride, prep, d_scalars, n, mont, st, c->msm_timing);
+  int slot = msm_enqueue_dispatch(curve, c->msm[lane], pts, wstride, prep, d_scalars, n, mont, st, c->msm_timing, sbytes, sbits,
+                                  piece);
   return slot < 0 ? slot : lane * MSM_JOBS + slot;
 }
 // May be called WITHOUT the context lock held (ark_hip_msm_wait): the timings go through a local and are published
@@ -699,10 +703,13 @@ int cache_clear(Context* c) {
   while (!c->base_cache.empty()) cache_drop(c, c->base_cache.size() - 1);
   return 0;
 }
-// Device copy of `bases` (uploading it on a miss or when the content changed).  *out = nullptr when the set cannot be
-// cached (cache disabled, or larger than the budget): the caller then falls back to its staging buffer.
-int cache_get(Context* c, int curve, const uint64_t* bases, size_t n, BaseCacheEntry** out) {
+// Device copy of `bases`.  *out = nullptr when the set cannot be cached (cache disabled, larger than the budget, no room):
+// the caller then streams bases and scalars through the ring.  *need_fill: the entry's buffer is reserved but does NOT
+// hold the bases yet (a miss, or the content changed) -- the caller uploads them, piecewise under the MSM's own kernels
+// (msm_stream), and drops the entry with cache_forget if that fails.
+int cache_get(Context* c, int curve, const uint64_t* bases, size_t n, BaseCacheEntry** out, bool* need_fill) {
   *out = nullptr;
+  *need_fill = false;
   cache_configure(c);
   const size_t wpp = (size_t)CURVES[curve].fe_words * 2, bytes = n * wpp * 8;
   if (c->cache_budget <= 0 || (long long)bytes > c->cache_budget || n == 0) return 0;
@@ -715,11 +722,10 @@ int cache_get(Context* c, int curve, const uint64_t* bases, size_t n, BaseCacheE
       if (int rc = sync_compute(c)) return rc;
       if (e.prepared) free_prepared(e.prepared);
       e.prepared = nullptr;
-      if (int rc = c->stager.upload(e.dev.p, bases, bytes, c->copy_stream)) return rc;
-      ARK_HIP_TRY(hipStreamSynchronize(c->copy_stream));
       e.fingerprint = fp;
       e.hits = 0;
       c->cache_stats.refreshed++;
+      *need_fill = true;
     } else {
       e.hits++;
       c->cache_stats.hits++;
@@ -750,39 +756,61 @@ int cache_get(Context* c, int curve, const uint64_t* bases, size_t n, BaseCacheE
   ne.fingerprint = fp;
   ne.last_use = c->cache_clock;
   if (ne.dev.ensure(bytes)) return 0;  // no room on the device right now: not an error, the caller streams instead
-  if (int rc = c->stager.upload(ne.dev.p, bases, bytes, c->copy_stream)) {
-    ne.dev.release();
-    return rc;
-  }
-  if (hipStreamSynchronize(c->copy_stream) != hipSuccess) {
-    ne.dev.release();
-    return -1000;
-  }
   c->cache_stats.misses++;
   c->base_cache.push_back(ne);
   *out = &c->base_cache.back();
+  *need_fill = true;
   return 0;
 }
+// an entry whose upload did not complete must not be found again
+void cache_forget(Context* c, int curve, const void* host, size_t n) {
+  for (size_t i = 0; i < c->base_cache.size(); i++)
+    if (c->base_cache[i].curve == curve && c->base_cache[i].host == host && c->base_cache[i].n == n) {
+      (void)sync_compute(c);
+      (void)hipStreamSynchronize(c->copy_stream);
+      cache_drop(c, i);
+      return;
+    }
+}
 
-// One MSM whose scalars (and, with `host_bases`, bases) come from host memory, against `d_bases` (resident) or streamed
-// bases: the pairs are cut into pieces, piece k+1 uploads on the copy stream -- and digit-recodes / sorts on the other
-// MSM lane -- while piece k's accumulate kernel runs; partial results are added on the host (the reference's own chunk
-// sum, variable_base/mod.rs:542-557).  pieces == 1: plain upload-then-compute.
+// One MSM whose scalars (and, with `host_bases`, bases) come from host memory, against `d_bases` (resident; with
+// `host_bases` as well: a resident copy being FILLED by this very call, piece by piece) or bases streamed through the ring: the pairs are cut into pieces; piece k+1 uploads on the copy stream -- and digit-recodes / sorts on the other MSM
+// lane -- while piece k's accumulate kernel runs.
+//   shared (2..8 pieces): the pieces are pieces of ONE MSM -- one plan, one bucket array, one reduction (MsmPiece);
+//   otherwise (msm_chunks with its fixed 2^20 steps): independent MSMs whose results are added on the host (the
+//   reference's own chunk sum, variable_base/mod.rs:542-557).
 int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_bases, const uint64_t* scalars, size_t n,
-               int mont, size_t step, uint64_t* out_xyz) {
+               int mont, size_t step, uint64_t* out_xyz, bool allow_shared = true) {
   const size_t ab = (size_t)CURVES[curve].fe_words * 16;
   const size_t pw = (size_t)CURVES[curve].fe_words * 3;
   if (step == 0 || step > n) step = n;
+  const size_t npieces = n ? (n + step - 1) / step : 0;
+  const bool shared = allow_shared && npieces >= 2 && npieces <= 8;
+  MsmPlan plan{};
+  if (shared) {
+    plan = msm_make_plan(n, msm_scalar_bits(curve), msm_mul_cost(curve), false);
+    if ((size_t)step * (size_t)plan.W >= (1ull << 32)) return ARK_HIP_ERR_SIZE;
+    const size_t need = plan.nbuckets() * (size_t)CURVES[curve].fe_words * 32;  // XYZZ: four field elements
+    if (c->piece_buckets.cap < need) {
+      if (int rc = sync_compute(c)) return rc;
+      if (c->piece_buckets.ensure(need)) return ARK_HIP_ERR_NOMEM;
+    }
+    for (int j = 0; j < 2; j++)
+      if (!c->piece_ev[j]) ARK_HIP_TRY(hipEventCreateWithFlags(&c->piece_ev[j], hipEventDisableTiming));
+  }
   std::vector<uint64_t> partials;
   int pending[2] = {-1, -1};
+  bool pending_last[2] = {false, false};
   int npend = 0;
   auto drain_one = [&]() -> int {
     uint64_t part[36];
+    const bool has_result = !shared || pending_last[0];
     const int rc = msm_finish_ctx(c, curve, pending[0], part);
     pending[0] = pending[1];
+    pending_last[0] = pending_last[1];
     npend--;
     if (rc) return rc;
-    partials.insert(partials.end(), part, part + pw);
+    if (has_result) partials.insert(partials.end(), part, part + pw);
     return 0;
   };
   auto fail = [&](int rc) -> int {  // nothing of this call stays in flight, no job slot stays taken
@@ -799,7 +827,8 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
     if (slot < 0) return slot;
     return msm_finish_ctx(c, curve, slot, out_xyz);
   }
-  for (size_t off = 0; off < n; off += step) {
+  size_t piece_no = 0;
+  for (size_t off = 0; off < n; off += step, piece_no++) {
     const size_t cnt = n - off < step ? n - off : step;
     if (npend == 2) {
       if (int rc = drain_one()) return fail(rc);
@@ -810,18 +839,22 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
     if (int rc = msm_lane_stream(c, lane, &compute)) return fail(rc);
     int k = 0;
     if (int rc = ring_acquire(c, &k)) return fail(rc);
-    if (c->ring_s[k].cap < cnt * 32 || (host_bases && c->ring_b[k].cap < cnt * ab)) {
+    const bool ring_bases = host_bases && !d_bases;  // host_bases with d_bases: fill the resident copy piece by piece
+    if (c->ring_s[k].cap < cnt * 32 || (ring_bases && c->ring_b[k].cap < cnt * ab)) {
       if (int rc = sync_compute(c)) return fail(rc);  // growing frees memory an enqueued MSM may still read
-      if (c->ring_s[k].ensure(step * 32) || (host_bases && c->ring_b[k].ensure(step * ab))) return fail(ARK_HIP_ERR_NOMEM);
+      if (c->ring_s[k].ensure(step * 32) || (ring_bases && c->ring_b[k].ensure(step * ab))) return fail(ARK_HIP_ERR_NOMEM);
     }
+    const void* pts = ring_bases ? (const void*)c->ring_b[k].p : (const void*)((const char*)d_bases + off * ab);
     if (host_bases)
-      if (int rc = c->stager.upload(c->ring_b[k].p, host_bases + off * (ab / 8), cnt * ab, c->copy_stream)) return fail(rc);
+      if (int rc = c->stager.upload((void*)pts, host_bases + off * (ab / 8), cnt * ab, c->copy_stream)) return fail(rc);
     if (int rc = c->stager.upload(c->ring_s[k].p, scalars + off * 4, cnt * 32, c->copy_stream)) return fail(rc);
     if (int rc = ring_publish(c, k, compute)) return fail(rc);
-    const void* pts = host_bases ? (const void*)c->ring_b[k].p : (const void*)((const char*)d_bases + off * ab);
-    int slot = msm_enqueue_ctx(c, curve, pts, 0, nullptr, c->ring_s[k].p, cnt, mont, lane);
+    MsmPiece piece{&plan, c->piece_buckets.p, piece_no == 0, piece_no + 1 == npieces,
+                   piece_no == 0 ? nullptr : c->piece_ev[(piece_no - 1) & 1], c->piece_ev[piece_no & 1]};
+    int slot = msm_enqueue_ctx(c, curve, pts, 0, nullptr, c->ring_s[k].p, cnt, mont, lane, 0, 0, shared ? &piece : nullptr);
     (void)ring_release(c, k, compute);
     if (slot < 0) return fail(slot);
+    pending_last[npend] = piece_no + 1 == npieces;
     pending[npend++] = slot;
   }
   while (npend) {
@@ -875,6 +908,9 @@ void ark_hip_shutdown(void) {
         if (c->fft_side[j]) (void)hipStreamSynchronize(c->fft_side[j]);
       while (!c->base_cache.empty()) cache_drop(c, c->base_cache.size() - 1);
       c->stager.release();
+      c->piece_buckets.release();
+      for (int j = 0; j < 2; j++)
+        if (c->piece_ev[j]) (void)hipEventDestroy(c->piece_ev[j]);
       if (c->lane_ev) (void)hipEventDestroy(c->lane_ev);
       c->msm[0].release();
       c->msm[1].release();
@@ -1029,9 +1065,15 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
   Context* c = sc.c;
   if (n == 0) return msm_stream(c, curve, nullptr, nullptr, nullptr, 0, mont, 0, out_xyz);
   BaseCacheEntry* ce = nullptr;
-  if (int rc = cache_get(c, curve, bases, n, &ce)) return rc;
+  bool need_fill = false;
+  if (int rc = cache_get(c, curve, bases, n, &ce, &need_fill)) return rc;
   if (!ce)  // not cacheable (disabled / over budget / no room): bases and scalars both stream through the ring
     return msm_stream(c, curve, nullptr, bases, scalars, n, mont, msm_stream_step(n), out_xyz);
+  if (need_fill) {  // first call with this set: its bases cross PCIe with the scalars, piece k+1 under piece k's kernels
+    const int rc = msm_stream(c, curve, ce->dev.p, bases, scalars, n, mont, msm_stream_step(n), out_xyz);
+    if (rc) cache_forget(c, curve, bases, n);
+    return rc;
+  }
   if (c->auto_prepare > 0 && !ce->prepared && ce->hits >= (unsigned)c->auto_prepare) {
     ark_hip_msm_bases* pb = nullptr;  // a failed build (no room for the table) just leaves the plain path in place
     if (ark_hip_msm_bases_prepare_device(curve, ce->dev.p, n, &pb) == 0) ce->prepared = (PreparedBases*)pb;
@@ -1039,6 +1081,56 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
   }
   if (ce->prepared) return ark_hip_msm_prepared((const ark_hip_msm_bases*)ce->prepared, scalars, n, mont, out_xyz);
   return msm_stream(c, curve, ce->dev.p, nullptr, scalars, n, mont, msm_stream_step(n), out_xyz);
+}
+
+// ---- narrow scalars: VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64 (variable_base/mod.rs:87-117) ----
+// scalars: n unsigned integers of scalar_bytes (1, 2, 4, 8) bytes each, of which the low max_bits (0 = all) may be set
+// (msm_u1: one byte per bool, max_bits = 1).  Only ceil((max_bits + 1) / c) windows exist: nothing is expanded to 32
+// bytes and no empty window is sorted.
+int ark_hip_msm_sw_small_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalar_bytes, int max_bits,
+                                uint64_t* out_xyz) {
+  if (curve < 0 || curve > 4 || !out_xyz || (n && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
+  if (scalar_bytes != 1 && scalar_bytes != 2 && scalar_bytes != 4 && scalar_bytes != 8) return ARK_HIP_ERR_ARG;
+  if (max_bits == 0) max_bits = 8 * scalar_bytes;
+  if (max_bits < 1 || max_bits > 8 * scalar_bytes) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  const int lane = msm_pick_lane(sc.c);
+  if (lane < 0) return lane;
+  int slot = msm_enqueue_ctx(sc.c, curve, d_bases, 0, nullptr, d_scalars, n, 0, lane, scalar_bytes, max_bits);
+  if (slot < 0) return slot;
+  return msm_finish_ctx(sc.c, curve, slot, out_xyz);
+}
+int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, size_t n, int scalar_bytes, int max_bits,
+                         uint64_t* out_xyz) {
+  if (curve < 0 || curve > 4 || !out_xyz || (n && (!bases || !scalars))) return ARK_HIP_ERR_ARG;
+  if (scalar_bytes != 1 && scalar_bytes != 2 && scalar_bytes != 4 && scalar_bytes != 8) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  if (n == 0) return ark_hip_msm_sw_small_device(curve, nullptr, nullptr, 0, scalar_bytes, max_bits, out_xyz);
+  // the base set goes through the same resident-base cache as ark_hip_msm_sw; the scalars are small: one upload
+  BaseCacheEntry* ce = nullptr;
+  bool need_fill = false;
+  if (int rc = cache_get(c, curve, bases, n, &ce, &need_fill)) return rc;
+  const size_t bb = n * (size_t)CURVES[curve].fe_words * 16, sb = n * (size_t)scalar_bytes;
+  const void* d_bases = nullptr;
+  if (ce) {
+    if (need_fill) {
+      int rc = c->stager.upload(ce->dev.p, bases, bb, c->copy_stream);
+      if (rc == 0 && hipStreamSynchronize(c->copy_stream) != hipSuccess) rc = -1000;
+      if (rc) {
+        cache_forget(c, curve, bases, n);
+        return rc;
+      }
+    }
+    d_bases = ce->dev.p;
+  } else {
+    if (c->stage_a.ensure(bb)) return ARK_HIP_ERR_NOMEM;
+    if (int rc = c->stager.upload(c->stage_a.p, bases, bb, c->stream)) return rc;
+    d_bases = c->stage_a.p;
+  }
+  if (c->stage_b.ensure(sb)) return ARK_HIP_ERR_NOMEM;
+  if (int rc = c->stager.upload(c->stage_b.p, scalars, sb, c->stream)) return rc;
+  return ark_hip_msm_sw_small_device(curve, d_bases, c->stage_b.p, n, scalar_bytes, max_bits, out_xyz);
 }
 
 // ---- resident-base cache control ----
@@ -1236,7 +1328,7 @@ int ark_hip_msm_sw_chunks(int curve, const uint64_t* bases, size_t n_bases, cons
   ARK_SCOPE(sc);
   const size_t ab = (size_t)CURVES[curve].fe_words * 16;
   const uint64_t* b0 = bases + (n_bases - n_scalars) * (ab / 8);
-  return msm_stream(sc.c, curve, nullptr, b0, scalars, n_scalars, 1, step, out_xyz);
+  return msm_stream(sc.c, curve, nullptr, b0, scalars, n_scalars, 1, step, out_xyz, false);
 }
 
 // One MSM over the GPUs of this node from ONE host process: base-range shards (the reference's own split,

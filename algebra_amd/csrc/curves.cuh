@@ -8,14 +8,10 @@
 #ifndef ARK_ACC_MIN_WAVES_G1
 #define ARK_ACC_MIN_WAVES_G1 1
 #endif
-#ifndef ARK_ACC_PARK_G1
-#define ARK_ACC_PARK_G1 0   // 1: the G1 accumulate kernels keep ZZ / ZZZ of the bucket accumulator in LDS; 2: Y as well
-#endif
 namespace arkhip {
 
 struct BN254_G1 {
   static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
-  static constexpr int ACC_PARK = ARK_ACC_PARK_G1;
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 0;
   typedef Fp<BN254_FQ> F;
@@ -25,7 +21,6 @@ struct BN254_G1 {
 };
 struct BLS12_381_G1 {
   static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
-  static constexpr int ACC_PARK = ARK_ACC_PARK_G1;
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 1;
   typedef Fp<BLS12_381_FQ> F;
@@ -35,7 +30,6 @@ struct BLS12_381_G1 {
 };
 struct BLS12_377_G1 {
   static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
-  static constexpr int ACC_PARK = ARK_ACC_PARK_G1;
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 2;
   typedef Fp<BLS12_377_FQ> F;
@@ -45,7 +39,6 @@ struct BLS12_377_G1 {
 };
 struct BLS12_377_G2 {
   static constexpr int ACC_MIN_WAVES = 1;
-  static constexpr int ACC_PARK = 0;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 3;
   typedef Fp2<BLS12_377_FQ, 5> F;
@@ -55,7 +48,6 @@ struct BLS12_377_G2 {
 };
 struct BLS12_381_G2 {
   static constexpr int ACC_MIN_WAVES = 1;
-  static constexpr int ACC_PARK = 0;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 4;
   typedef Fp2<BLS12_381_FQ, 1> F;

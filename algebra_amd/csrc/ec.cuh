@@ -243,66 +243,6 @@ ARK_HD void xyzz_madd_relaxed(XYZZ<F>& acc, const F& x2, const F& y2) {
   acc.zz = F::mul_r(acc.zz, pp);
   acc.zzz = F::mul_r(acc.zzz, ppp);
 }
-// ZZ / ZZZ of a lane's accumulator parked in LDS between uses (N/4 16-byte words each, lane-private slots `stride`
-// words apart so that a wave's accesses are conflict-free): 2 N fewer live registers in the accumulate kernels.
-template <class F>
-struct ParkedZ {
-  uint4* base;   // this lane's first word
-  u32 stride;    // words between consecutive words of one element (= lanes sharing the array)
-  static constexpr int Q = F::N / 4;
-  ARK_DEV F get(int which) const {
-    F v;
-#pragma unroll
-    for (int g = 0; g < Q; g++) {
-      const uint4 q = base[(which * Q + g) * stride];
-      v.l[4 * g] = q.x; v.l[4 * g + 1] = q.y; v.l[4 * g + 2] = q.z; v.l[4 * g + 3] = q.w;
-    }
-    return v;
-  }
-  ARK_DEV void put(int which, const F& v) const {
-#pragma unroll
-    for (int g = 0; g < Q; g++)
-      base[(which * Q + g) * stride] = make_uint4(v.l[4 * g], v.l[4 * g + 1], v.l[4 * g + 2], v.l[4 * g + 3]);
-  }
-};
-// xyzz_madd_relaxed with the accumulator split as (ax, ay, inf) in registers and ZZ, ZZZ parked (slots 0, 1);
-// PARK_Y: Y parked as well (slot 2; `ay` is then unused)
-template <class F, bool PARK_Y>
-ARK_DEV void xyzz_madd_relaxed_parked(F& ax, F& ay, bool& inf, const ParkedZ<F>& z, const F& x2, const F& y2) {
-  if (inf) {
-    ax = x2; z.put(0, F::one()); z.put(1, F::one());
-    if constexpr (PARK_Y) z.put(2, y2); else ay = y2;
-    inf = false;
-    return;
-  }
-  F p = F::sub_r(F::mul_r(x2, z.get(0)), ax);
-  F r;
-  if constexpr (PARK_Y) r = F::sub_r(F::mul_r(y2, z.get(1)), z.get(2));
-  else r = F::sub_r(F::mul_r(y2, z.get(1)), ay);
-  const bool pz = p.is_zero_mod_p();
-  const bool rz = r.is_zero_mod_p();
-  if (pz) {
-    if (rz) {
-      XYZZ<F> d = xyzz_mdbl<F>(x2, y2.canonical());
-      ax = d.x; z.put(0, d.zz); z.put(1, d.zzz);
-      if constexpr (PARK_Y) z.put(2, d.y); else ay = d.y;
-      inf = d.is_zero();
-    } else {
-      inf = true;
-    }
-    return;
-  }
-  F pp = F::sqr_r(p);
-  F ppp = F::mul_r(p, pp);
-  F q = F::mul_r(ax, pp);
-  z.put(0, F::mul_r(z.get(0), pp));
-  z.put(1, F::mul_r(z.get(1), ppp));
-  F x3 = F::sub_r(F::sub_r(F::sqr_r(r), ppp), F::dbl_r(q));
-  if constexpr (PARK_Y) z.put(2, F::sop2_r(r, F::sub_r(q, x3), F::neg_r(z.get(2)), ppp));
-  else ay = F::sop2_r(r, F::sub_r(q, x3), F::neg_r(ay), ppp);
-  ax = x3;
-}
-
 template <class F>
 ARK_HD XYZZ<F> xyzz_canonical(const XYZZ<F>& a) {
   if (a.is_zero()) return XYZZ<F>::zero();

@@ -8,13 +8,15 @@ namespace arkhip {
 struct MsmWorkspace;
 struct MsmTimings;
 struct MsmPlan;
+struct MsmPiece;
 struct FftWorkspace;
 struct FftTimings;
 
 // one function per curve / field, defined in msm_<curve>.hip / fft_<field>.hip
 #define ARK_DECL_CURVE(NAME)                                                                                    \
   int msm_enqueue_##NAME(MsmWorkspace& ws, const void* d_points, size_t wstride, const MsmPlan* prepared,         \
-                         const void* d_scalars, size_t n, int mont, hipStream_t stream, bool timing);            \
+                         const void* d_scalars, size_t n, int mont, hipStream_t stream, bool timing, int sbytes,  \
+                         int sbits, const MsmPiece* piece);                                                       \
   int msm_finish_##NAME(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm);                          \
   int msm_prepare_##NAME(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream);   \
   int batchmul_build_##NAME(const void* d_base_affine, void* d_scratch, void* d_table, hipStream_t stream);      \

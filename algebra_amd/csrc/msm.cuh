@@ -135,6 +135,41 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
   }
 }
 
+// ---- K1n: the same recoding for NARROW unsigned scalars ------------------------------------------------
+// VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64 (variable_base/mod.rs:87-117; CPU bodies :373-434):
+// the scalars arrive as BYTES-byte unsigned integers (bool = one byte, 0 / 1) and only the windows their `bits`
+// significant bits reach exist at all -- no 32-byte expansion, no empty windows to sort.  No s -> r-s fold (the value is
+// far below r/2); the widths add up to bits + 1, so the top window keeps the spare bit signed digits need.
+template <int BYTES>
+__global__ void __launch_bounds__(256) msm_digits_small_kernel(const unsigned char* __restrict__ scalars, u32 n, int c, int W,
+                                                               int narrow, u64 vmask, u32* __restrict__ keys) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 v;
+  if constexpr (BYTES == 1) v = scalars[i];
+  else if constexpr (BYTES == 2) v = ((const unsigned short*)scalars)[i];
+  else if constexpr (BYTES == 4) v = ((const u32*)scalars)[i];
+  else v = ((const u64*)scalars)[i];
+  v &= vmask;  // bits above the caller's bound do not exist (msm_u1: any non-zero byte of a bool is "true" -> see the host side)
+  u32 carry = 0;
+  for (int w = 0; w < W; w++) {
+    const int cw = msm_window_width(w, c, W, narrow);
+    const u32 mask = (1u << cw) - 1u;
+    const u32 half = 1u << (cw - 1);
+    const u32 raw = ((u32)v & mask) + carry;
+    v >>= cw;
+    carry = (w < W - 1 && raw >= half) ? 1u : 0u;
+    const int d = (int)raw - (int)(carry << cw);
+    u32 key = KEY_NONE;
+    if (d != 0) {
+      u32 mag = d < 0 ? (u32)(-d) : (u32)d;
+      if (mag > half) mag = half;  // unreachable: the top window has a spare bit
+      key = (d < 0 ? 0x80000000u : 0u) | (mag - 1);
+    }
+    keys[(size_t)w * n + i] = key;
+  }
+}
+
 // ---- K2: exclusive scan (three small kernels) --------------------------------------------------
 static constexpr int SCAN_TILE = 2048;  // elements per block (256 threads x 8)
 
@@ -301,24 +336,24 @@ static __global__ void __launch_bounds__(256) msm_order_scatter_kernel(const u32
 
 // ---- K4: bucket accumulation --------------------------------------------------------------------
 // One lane per bucket.  `order` (optional) maps lane -> bucket id so that lanes of one wave own
-// buckets of similar load.
+// buckets of similar load.  accum != 0: a later piece of a streamed MSM whose pieces share one bucket array
+// (MsmPiece): the bucket's previous sum is the starting value instead of infinity.
 template <class C>
 __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(const char* __restrict__ bases,
                                                              const u32* __restrict__ sorted,
                                                              const u32* __restrict__ offsets,
                                                              const u32* __restrict__ order, u32 nbuckets,
                                                              const u32* __restrict__ d_thresh, int HB, int LB,
-                                                             char* __restrict__ buckets) {
+                                                             int accum, char* __restrict__ buckets) {
   typedef typename C::FA F;  // Fp, or Fp2Half: then a lane PAIR owns the bucket (both lanes run the same control flow)
   u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / F::LANES;
   if (t >= nbuckets) return;
   u32 g = order ? order[t] : t;
   u32 j = offsets[g], end = offsets[g + 1];
   if (end - j > *d_thresh) return;  // left to the heavy-bucket kernels
-  XYZZ<F> acc = XYZZ<F>::zero();
-  __shared__ uint4 park_lds[C::ACC_PARK ? 256 * (C::ACC_PARK + 1) * (F::N / 4) : 1];  // ACC_PARK: see ParkedZ (ec.cuh)
-  const ParkedZ<F> parked{park_lds + threadIdx.x, 256};
-  bool inf = true;
+  if (accum && j == end) return;    // nothing to add to the stored sum
+  char* cell = buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES;  // g is a slot (msm_sort.cuh)
+  XYZZ<F> acc = accum ? XYZZ<F>::load(cell) : XYZZ<F>::zero();   // stored buckets are canonical: valid relaxed values
   if (j < end) {
     // software pipeline, two deep on the indices: the gather of point t+1 (whose index arrived an iteration ago) and
     // the index of point t+2 are both in flight during the ~10 multiplications of addition t
@@ -337,8 +372,7 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
         F y = p.y;  // negative digit: -P.  On relaxed residues 2p - y serves (a multiplication operand; no zero test)
         if constexpr (C::RELAXED_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
         else y = F::cond_neg(p.y, (e >> 31) != 0);
-        if constexpr (C::ACC_PARK != 0) xyzz_madd_relaxed_parked<F, C::ACC_PARK == 2>(acc.x, acc.y, inf, parked, p.x, y);
-        else if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
+        if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
       }
       if (!more) break;
@@ -348,16 +382,8 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
       j++;
     }
   }
-  if constexpr (C::ACC_PARK != 0) {
-    if (inf) acc = XYZZ<F>::zero();
-    else {
-      acc.zz = parked.get(0);
-      acc.zzz = parked.get(1);
-      if constexpr (C::ACC_PARK == 2) acc.y = parked.get(2);
-    }
-  }
   if constexpr (C::RELAXED_A) acc = xyzz_canonical<F>(acc);
-  acc.store(buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES);  // g is a slot (msm_sort.cuh)
+  acc.store(cell);
 }
 
 // ---- K4s: bucket accumulation over a PREPARED base set ---------------------------------------------
@@ -379,9 +405,6 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
   const u32 s = order ? order[t] : t;
   const u32 heavy_thresh = *d_thresh;
   Pt acc = Pt::zero();
-  __shared__ uint4 park_lds[C::ACC_PARK ? 256 * (C::ACC_PARK + 1) * (F::N / 4) : 1];  // ACC_PARK: ZZ / ZZZ of every lane's accumulator
-  const ParkedZ<F> parked{park_lds + threadIdx.x, 256};
-  bool inf = true;
   int w = 0;                    // next window to open
   u32 na = offsets[s], nb2 = offsets[s + 1];  // bounds of window w's run, fetched one window ahead
   u32 j = 0, end = 0;
@@ -433,8 +456,7 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
         F y = p.y;  // negative digit: -P.  On relaxed residues 2p - y serves (a multiplication operand; no zero test)
         if constexpr (C::RELAXED_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
         else y = F::cond_neg(p.y, (e >> 31) != 0);
-        if constexpr (C::ACC_PARK != 0) xyzz_madd_relaxed_parked<F, C::ACC_PARK == 2>(acc.x, acc.y, inf, parked, p.x, y);
-        else if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
+        if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, y);
         else xyzz_madd<F>(acc, p.x, y);
       }
       if (!have1) break;
@@ -443,14 +465,6 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_shared_k
       e1 = e2;
       wb1 = wb2;
       have1 = have2;
-    }
-  }
-  if constexpr (C::ACC_PARK != 0) {
-    if (inf) acc = Pt::zero();
-    else {
-      acc.zz = parked.get(0);
-      acc.zzz = parked.get(1);
-      if constexpr (C::ACC_PARK == 2) acc.y = parked.get(2);
     }
   }
   if constexpr (C::RELAXED_A) acc = xyzz_canonical<F>(acc);
@@ -599,7 +613,7 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __rest
                                                                const HeavyEntry* __restrict__ list,
                                                                const char* __restrict__ partials, int HB, int LB,
                                                                const u32* __restrict__ offsets, u32* __restrict__ sorted,
-                                                               char* __restrict__ buckets) {
+                                                               int accum, char* __restrict__ buckets) {
   typedef AccOps<C> Ops;
   typedef typename Ops::Pt Pt;
   constexpr u32 NS = 64 / Ops::LANES;
@@ -620,7 +634,12 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __rest
         Ops::fin(acc).store(buckets + (size_t)hslot * Pt::BYTES);  // `buckets` is the hfinal array here
         if (threadIdx.x == 0) sorted[offsets[h.bucket]] = hslot;
       } else {
-        Ops::fin(acc).store(buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES);
+        char* cell = buckets + (size_t)msm_slot_to_bucket(h.bucket, HB, LB) * Pt::BYTES;
+        if (accum) {  // a later piece of a streamed MSM: add to the sum the earlier pieces left (MsmPiece)
+          Pt prev = Pt::load(cell);
+          Ops::add(acc, prev);
+        }
+        Ops::fin(acc).store(cell);
       }
     }
     __syncthreads();
@@ -903,6 +922,7 @@ struct MsmJob {
   hipEvent_t done = nullptr;
   bool busy = false;
   bool empty = false;     // n == 0: identity, nothing enqueued
+  bool no_result = false; // a non-final piece of a streamed MSM (MsmPiece): only the scalar-range flag comes back
   MsmPlan pl{};
   int nbits = 0, log2L0 = 0;
   u32 Q = 0;
@@ -947,13 +967,29 @@ static inline int msm_job_pinned(MsmJob& j, size_t bytes) {
   return 0;
 }
 
+// One piece of a STREAMED MSM (capi.hip msm_stream: the host-pointer entry points).  The pairs of one MSM arrive in
+// pieces (uploads overlapping compute); every piece is digit-recoded and sorted on its own, but all pieces accumulate into
+// ONE bucket array laid out by the plan of the whole job, and only the last piece runs the bucket reduction: cutting an
+// MSM into independent sub-MSMs would pay the reduction and the sort's latency floors once per piece and force narrower
+// windows on each (2^24 as four 2^22 MSMs: +11 ms; as four pieces of one MSM: +1 ms).
+struct MsmPiece {
+  const MsmPlan* plan;     // plan of the WHOLE job
+  void* buckets;           // shared bucket array: plan->nbuckets() XYZZ points
+  bool first, last;        // first: buckets are overwritten, otherwise added to; last: the reduction runs
+  hipEvent_t after_prev;   // (nullable) recorded behind the previous piece's accumulate kernels, on another stream
+  hipEvent_t after_this;   // recorded behind this piece's accumulate kernels
+};
+
 // Enqueue one single-GPU MSM with device-resident inputs on `stream`; returns the job slot (>= 0) or a negative code.
 //   points / wstride / prepared:  plain call: points = the n bases, wstride = 0, prepared = nullptr;
 //                                 prepared base set: points = the [W][wstride] table of per-window multiples and
 //                                 `prepared` = the plan it was built for (msm_prepare_table).
 template <class C>
 int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const MsmPlan* prepared, const void* d_scalars,
-                size_t n, int scalars_mont, hipStream_t stream, bool timing) {
+                size_t n, int scalars_mont, hipStream_t stream, bool timing, int sbytes = 0, int sbits = 0,
+                const MsmPiece* piece = nullptr) {
+  // sbytes != 0: narrow unsigned scalars of sbytes bytes with at most sbits significant bits (K1n); never with `prepared`
+  // piece != nullptr: see MsmPiece (never with `prepared`; n > 0)
   typedef typename C::F F;
   typedef XYZZ<F> Pt;
   std::lock_guard<std::mutex> lock(ws.mu);
@@ -964,12 +1000,17 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   MsmJob& job = ws.jobs[slot];
   job.empty = (n == 0);
   job.timing = false;
+  job.no_result = false;
+  if (piece && (prepared || n == 0)) return -1;
   if (n == 0) {
     job.busy = true;
     return slot;
   }
   if (n >= (1ull << 31)) return -2;
-  const MsmPlan pl = prepared ? *prepared : msm_make_plan(n, C::S::BITS, msm_mul_cost(C::ID), false);
+  if (sbytes && (prepared || (sbytes != 1 && sbytes != 2 && sbytes != 4 && sbytes != 8) || sbits < 1 || sbits > 8 * sbytes))
+    return -1;
+  const MsmPlan pl = prepared ? *prepared
+                     : (piece ? *piece->plan : msm_make_plan(n, sbytes ? sbits + 1 : C::S::BITS, msm_mul_cost(C::ID), false));
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;                      // sort slots
   const size_t nbk = pl.nbuckets();             // accumulated buckets
@@ -996,7 +1037,9 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   const u32 noscan = (u32)((nohist + SCAN_TILE - 1) / SCAN_TILE);
   if (ws.sums.ensure((size_t)(ntscan > noscan ? ntscan : noscan) * 4)) return -3;
   if (ws.order.ensure(nbk * 4) || ws.ohist.ensure(nohist * 4) || ws.ooff.ensure((nohist + 1) * 4)) return -3;
-  if (ws.buckets.ensure(nbk * Pt::BYTES)) return -3;
+  if (!piece && ws.buckets.ensure(nbk * Pt::BYTES)) return -3;
+  char* const d_buckets = piece ? (char*)piece->buckets : (char*)ws.buckets.p;
+  const int accum = (piece && !piece->first) ? 1 : 0;
 
   // bucket reduction geometry: level 0 (chunked running sums over L0 buckets per lane), then the bit-sliced sums
   u32 L0 = 32;
@@ -1078,8 +1121,19 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (pl.shared && ws.hfinal.ensure(max_heavy * Pt::BYTES)) return -3;
   ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 16, stream));  // [chunk items, heavy runs, threshold, scalar-range error flag]
   const u32 nblk = (u32)((n + 255) / 256);
-  hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
-                     (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.hctr.p + 3);
+  if (sbytes) {
+    const u64 vmask = sbits >= 64 ? ~0ull : ((1ull << sbits) - 1ull);
+    const unsigned char* sp = (const unsigned char*)d_scalars;
+    switch (sbytes) {
+      case 1: hipLaunchKernelGGL((msm_digits_small_kernel<1>), dim3(nblk), dim3(256), 0, stream, sp, (u32)n, c, W, pl.narrow, vmask, keys); break;
+      case 2: hipLaunchKernelGGL((msm_digits_small_kernel<2>), dim3(nblk), dim3(256), 0, stream, sp, (u32)n, c, W, pl.narrow, vmask, keys); break;
+      case 4: hipLaunchKernelGGL((msm_digits_small_kernel<4>), dim3(nblk), dim3(256), 0, stream, sp, (u32)n, c, W, pl.narrow, vmask, keys); break;
+      default: hipLaunchKernelGGL((msm_digits_small_kernel<8>), dim3(nblk), dim3(256), 0, stream, sp, (u32)n, c, W, pl.narrow, vmask, keys); break;
+    }
+  } else {
+    hipLaunchKernelGGL((msm_digits_kernel<typename C::S>), dim3(nblk), dim3(256), 0, stream, (const u32*)d_scalars,
+                       (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.hctr.p + 3);
+  }
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[1], stream));
   // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
   hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
@@ -1117,6 +1171,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                        ooff, order);
   }
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[3], stream));
+  if (piece && piece->after_prev) ARK_HIP_TRY(hipStreamWaitEvent(stream, piece->after_prev, 0));  // the buckets' previous writer
   {
     // runs too long for one lane: chunk partials by one wave each, combined per run (empty for uniform scalars)
     u32* hctr = (u32*)ws.hctr.p;
@@ -1130,31 +1185,44 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     const u32 combine_grid = max_heavy < 16384 ? (u32)max_heavy : 16384u;  // grid-stride over the heavy runs
     if (pl.shared)
       hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
-                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
+                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted, 0,
                          (char*)ws.hfinal.p);
     else
       hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
-                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted,
-                         (char*)ws.buckets.p);
+                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted, accum,
+                         d_buckets);
   }
   if (pl.shared)
   {
     hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
                        (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, (const u32*)ws.hctr.p + 2, HB, LB,
-                       (char*)ws.buckets.p);
+                       d_buckets);
     hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3(1024), dim3(64), 0, stream,
                        (const u32*)ws.hctr.p, (const HeavyEntry*)ws.hlist.p, offsets, sorted, (const char*)ws.hfinal.p, W,
-                       Bbits, HB, LB, (char*)ws.buckets.p);
+                       Bbits, HB, LB, d_buckets);
   }
   else
     hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
-                       (const char*)d_points, sorted, offsets, order, (u32)nb, (const u32*)ws.hctr.p + 2, HB, LB,
-                       (char*)ws.buckets.p);
+                       (const char*)d_points, sorted, offsets, order, (u32)nb, (const u32*)ws.hctr.p + 2, HB, LB, accum,
+                       d_buckets);
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
+  if (piece) ARK_HIP_TRY(hipEventRecord(piece->after_this, stream));
+  if (piece && !piece->last) {  // the reduction belongs to the last piece: only the scalar-range flag goes back
+    ARK_HIP_TRY(hipGetLastError());
+    ARK_HIP_TRY(hipMemcpyAsync((char*)job.pinned + npairs * Pt::BYTES, (const u32*)ws.hctr.p + 3, 4, hipMemcpyDeviceToHost, stream));
+    if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[5], stream));
+    ARK_HIP_TRY(hipEventRecord(job.done, stream));
+    job.pl = pl;
+    job.npairs = npairs;
+    job.timing = timing;
+    job.no_result = true;
+    job.busy = true;
+    return slot;
+  }
 
   constexpr u32 LNr = C::FA::LANES;
   hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * Wr * LNr + 127) / 128)), dim3(128), 0, stream,
-                     (const char*)ws.buckets.p, L0, (u32)(m * Wr), (char*)ws.lvlS[0].p, (char*)ws.lvlA[0].p);
+                     (const char*)d_buckets, L0, (u32)(m * Wr), (char*)ws.lvlS[0].p, (char*)ws.lvlA[0].p);
   {
     const u32 rthreads = Pt::BYTES * (256 / LNr) > 49152 ? 128 : 256;  // LDS tree within 48 KiB
     hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, Wr), dim3(rthreads), (rthreads / LNr) * Pt::BYTES, stream,
@@ -1231,6 +1299,14 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
   const u32 Q = job.Q;
   const u32 h_err = *(const u32*)((const char*)job.pinned + job.npairs * Pt::BYTES);
   if (h_err) return -4;  // scalar out of range
+  if (job.no_result) {  // a non-final piece of a streamed MSM: out_xyz untouched
+    if (tm && job.timing) {
+      (void)hipEventElapsedTime(&tm->total, job.ev[0], job.ev[5]);
+      tm->c = c;
+      tm->W = W;
+    }
+    return 0;
+  }
 
   // host tail (serial chains):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(offset_w) T_w
   // (window combine of mod.rs:489-502, high to low).  A prepared base set has a single T: no doublings between

@@ -6,8 +6,8 @@
 #include "internal.hpp"
 namespace arkhip {
 int msm_enqueue_BLS12_377_G1(MsmWorkspace& ws, const void* d_points, size_t wstride, const MsmPlan* prepared, const void* d_scalars,
-                   size_t n, int mont, hipStream_t stream, bool timing) {
-  return msm_enqueue<BLS12_377_G1>(ws, d_points, wstride, prepared, d_scalars, n, mont, stream, timing);
+                   size_t n, int mont, hipStream_t stream, bool timing, int sbytes, int sbits, const MsmPiece* piece) {
+  return msm_enqueue<BLS12_377_G1>(ws, d_points, wstride, prepared, d_scalars, n, mont, stream, timing, sbytes, sbits, piece);
 }
 int msm_finish_BLS12_377_G1(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
   return msm_finish<BLS12_377_G1>(ws, slot, out_xyz, tm);

@@ -210,6 +210,14 @@ class MsmJob:
         self._keep = None
         return out
 
+    def __del__(self):  # a job dropped without wait() would hold its device slot for ever
+        if getattr(self, "_h", None) is not None:
+            try:
+                h, self._h = self._h, None
+                lib().ark_hip_msm_wait(h, None)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+
 
 def msm_bigint_async(curve, bases, bigints, montgomery=False):
     """Enqueue msm_bigint on device-resident inputs (CUDA tensors) and return an MsmJob."""
@@ -383,42 +391,59 @@ def batch_mul(curve, base, scalars, montgomery=True):
         t.free()
 
 
-def _small_to_bigint(values, signed_ok=False):
-    v = np.asarray(values)
+def _msm_small(curve, bases, scalars, dtype, max_bits=0):
+    """ark_hip_msm_sw_small(_device): the scalars cross the boundary as the reference's own narrow integers."""
+    cid = cv.curve_id(curve)
+    out = np.zeros(cv.projective_words(cid), dtype=np.uint64)
+    L = lib()
+    nbytes = np.dtype(dtype).itemsize
+    if _is_torch(scalars):
+        if not (_is_torch(bases) and bases.is_cuda and scalars.is_cuda):
+            raise TypeError("bases and scalars must both be CUDA tensors or both be host arrays")
+        assert bases.is_contiguous() and scalars.is_contiguous() and scalars.element_size() == nbytes
+        import torch
+        torch.cuda.current_stream().synchronize()
+        n = min(_rows(bases, cv.affine_words(cid)), scalars.numel())
+        check(L.ark_hip_msm_sw_small_device(cid, bases.data_ptr(), scalars.data_ptr(), n, nbytes, max_bits,
+                                            out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_sw_small_device")
+        return out
+    v = np.asarray(scalars)
     if v.dtype == np.bool_:
-        v = v.astype(np.uint64)
+        v = v.astype(np.uint8)          # Rust's bool is one byte, 0 or 1
     if not np.issubdtype(v.dtype, np.unsignedinteger):
         raise TypeError("msm_u*: unsigned integer (or bool) scalars expected")
-    out = np.zeros((v.size, 4), dtype=np.uint64)
-    out[:, 0] = v.astype(np.uint64).reshape(-1)
+    v = np.ascontiguousarray(v.reshape(-1), dtype=dtype)
+    b, bp = _host(bases)
+    n = min(_rows(b, cv.affine_words(cid)), v.size)
+    check(L.ark_hip_msm_sw_small(cid, bp, v.ctypes.data_as(C.c_void_p), n, nbytes, max_bits,
+                                 out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_sw_small")
     return out
 
 
 def msm_u1(curve, bases, scalars):
-    """VariableBaseMSM::msm_u1 (variable_base/mod.rs:89-93): boolean scalars.  On the device these are ordinary
-    1-bit scalars: every point with a set bit lands in bucket 0 of window 0 (heavy-bucket path), the other
-    windows are empty."""
-    return msm_bigint(curve, bases, _small_to_bigint(scalars))
+    """VariableBaseMSM::msm_u1 (variable_base/mod.rs:89-93; msm_binary :373-390): boolean scalars, one byte each as in
+    the reference's &[bool].  One window of one bucket: the sum of the selected bases (heavy-run kernels)."""
+    return _msm_small(curve, bases, scalars, np.uint8, 1)
 
 
 def msm_u8(curve, bases, scalars):
     """VariableBaseMSM::msm_u8 (mod.rs:95-99)."""
-    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint8)))
+    return _msm_small(curve, bases, scalars, np.uint8)
 
 
 def msm_u16(curve, bases, scalars):
     """VariableBaseMSM::msm_u16 (mod.rs:101-105)."""
-    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint16)))
+    return _msm_small(curve, bases, scalars, np.uint16)
 
 
 def msm_u32(curve, bases, scalars):
     """VariableBaseMSM::msm_u32 (mod.rs:107-111)."""
-    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint32)))
+    return _msm_small(curve, bases, scalars, np.uint32)
 
 
 def msm_u64(curve, bases, scalars):
     """VariableBaseMSM::msm_u64 (mod.rs:113-117)."""
-    return msm_bigint(curve, bases, _small_to_bigint(np.asarray(scalars, dtype=np.uint64)))
+    return _msm_small(curve, bases, scalars, np.uint64)
 
 
 def normalize_batch(curve, points):

@@ -105,6 +105,16 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
 int ark_hip_msm_cache_config(long long budget_bytes, int auto_prepare_after);
 int ark_hip_msm_cache_clear(void);
 int ark_hip_msm_cache_stats(uint64_t out[6]);
+/* VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64 (variable_base/mod.rs:87-117; CPU bodies msm_binary /
+ * msm_u8.. :373-434): scalars are n unsigned integers of scalar_bytes (1, 2, 4 or 8) bytes -- exactly the reference's
+ * &[bool] (one byte each, max_bits = 1), &[u8], &[u16], &[u32], &[u64] -- whose low max_bits bits may be set (0 = all
+ * 8 * scalar_bytes).  Only the ceil((max_bits + 1) / c) windows such scalars reach are built: nothing is widened to 32
+ * bytes (a u8 vector uploads 1/32 of what msm_bigint would) and no empty window is sorted.  The host-pointer form shares
+ * ark_hip_msm_sw's resident-base cache. */
+int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, size_t n, int scalar_bytes, int max_bits,
+                         uint64_t* out_xyz);
+int ark_hip_msm_sw_small_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalar_bytes,
+                                int max_bits, uint64_t* out_xyz);
 /* Same with bases/scalars already in this GPU's memory (device pointers); out_xyz is a host pointer. */
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalars_are_montgomery,
                           uint64_t* out_xyz);

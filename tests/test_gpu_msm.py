@@ -279,19 +279,51 @@ def test_resident_bases_through_the_c_abi_only():
     check(L.ark_hip_free(d_scalars), "free")
 
 
-def test_msm_specialized_small_scalar_entry_points():
-    # test_var_base_msm_specialized (test-templates/src/msm.rs:74-110): msm_u1/u8/u16/u32/u64 vs the naive sum
-    cid = O.CID["BLS12_381_G1"]
-    n = 5 << 10
+@pytest.mark.parametrize("cname", O.CURVES)
+def test_msm_specialized_small_scalar_entry_points(cname):
+    # test_var_base_msm_specialized (test-templates/src/msm.rs:74-110): msm_u1/u8/u16/u32/u64 vs the reference algorithm
+    # on the widened scalars.  The scalars cross the C ABI as the reference's own narrow integers (ark_hip_msm_sw_small).
+    import torch
+    cid = O.CID[cname]
+    n = 1 << 9 if cname.endswith("G2") else 5 << 10
     bases = O.gen_bases(cid, A4, B4, n)
     rng = np.random.default_rng(77)
+    u64 = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
     cases = [(A.msm_u1, rng.integers(0, 2, size=n).astype(bool)),
              (A.msm_u8, rng.integers(0, 1 << 8, size=n, dtype=np.uint64).astype(np.uint8)),
              (A.msm_u16, rng.integers(0, 1 << 16, size=n, dtype=np.uint64).astype(np.uint16)),
              (A.msm_u32, rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)),
-             (A.msm_u64, rng.integers(0, 1 << 63, size=n, dtype=np.uint64))]
+             (A.msm_u64, u64)]                                   # all 64 bits in play
     for fn, sc in cases:
+        if sc.dtype != np.bool_:                                 # extremes: 0, 1, the type's maximum
+            sc[0], sc[1], sc[2] = 0, 1, np.iinfo(sc.dtype).max
         big = np.zeros((n, 4), dtype=np.uint64)
         big[:, 0] = sc.astype(np.uint64)
-        exp = O.msm(cid, bases, big, O.SIGNED, 8)
-        assert np.array_equal(A.into_affine(cid, fn(cid, bases, sc)), O.to_affine(cid, exp)), fn.__name__
+        exp = O.to_affine(cid, O.msm(cid, bases, big, O.SIGNED, 8))
+        assert np.array_equal(A.into_affine(cid, fn(cid, bases, sc)), exp), fn.__name__
+        # device-resident inputs (ark_hip_msm_sw_small_device)
+        d_b = torch.from_numpy(bases.view(np.int64)).cuda()
+        host = sc.astype(np.uint8) if sc.dtype == np.bool_ else sc
+        signed = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[host.dtype.itemsize]
+        d_s = torch.from_numpy(host.view(signed)).cuda()
+        assert np.array_equal(A.into_affine(cid, fn(cid, d_b, d_s)), exp), fn.__name__ + " (device)"
+        # ragged / tiny sizes, msm_unchecked-style truncation to the shorter input
+        for m in (0, 1, 33):
+            e2 = O.to_affine(cid, O.msm(cid, bases[:m], big[:m], O.SIGNED, 2))
+            assert np.array_equal(A.into_affine(cid, fn(cid, bases, sc[:m])), e2), (fn.__name__, m)
+
+
+def test_msm_small_scalars_skewed_and_all_equal():
+    # the reference's bench shapes for the narrow entries (bench-templates/src/macros/ec.rs:244-372): every scalar the
+    # same value, and one bucket taking almost everything (heavy-run kernels)
+    cid = O.CID["BLS12_381_G1"]
+    n = 1 << 14
+    bases = O.gen_bases(cid, A4, B4, n)
+    for fn, dt, val in ((A.msm_u8, np.uint8, 255), (A.msm_u32, np.uint32, 0x80000001), (A.msm_u64, np.uint64, (1 << 64) - 1),
+                        (A.msm_u1, np.bool_, True)):
+        sc = np.full(n, val, dtype=dt)
+        sc[::97] = 0 if dt != np.bool_ else False
+        big = np.zeros((n, 4), dtype=np.uint64)
+        big[:, 0] = sc.astype(np.uint64)
+        exp = O.to_affine(cid, O.msm(cid, bases, big, O.SIGNED, 8))
+        assert np.array_equal(A.into_affine(cid, fn(cid, bases, sc)), exp), fn.__name__

@@ -343,10 +343,13 @@ def test_two_msm_lanes_under_concurrent_threads_and_batched_fft():
                         errors.append(("msm", t, it))
                 elif kind == 1:
                     k2 = (k + 1) % 4
+                    j1 = None
                     try:
                         j1 = pb.msm_bigint_async(d_s[k])
                         j2 = pb.msm_bigint_async(d_s[k2])
                     except A.ArkHipError as ex:     # four jobs in flight on the device: a legal answer under load
+                        if j1 is not None:
+                            j1.wait()               # a job that was enqueued is always waited for (it holds a slot)
                         if ex.code != -6:
                             raise
                         continue

@@ -138,8 +138,8 @@ def test_streamed_pieces_at_size(monkeypatch):
     want = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
     for _ in range(2):
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
-    st = A.base_cache_stats()
-    assert st["entries"] == 1 and st["hits"] >= 1
+    st = A.base_cache_stats()          # (mul_gen's one-point MSMs own the other entries)
+    assert st["bytes"] >= bases.nbytes and st["hits"] >= 1
 
 
 def test_auto_prepare_after_hits():
