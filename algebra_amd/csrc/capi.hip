@@ -21,11 +21,11 @@ namespace {
 struct PreparedBases;
 
 // ---- pageable host memory -> device at PCIe rate ---------------------------------------------------------
-// hipMemcpyAsync from pageable memory is staged by the runtime through one internal bounce buffer on the calling thread
-// (~25-30 GB/s measured on the MI355X boxes against ~57 GB/s from page-locked memory).  The host-pointer entry points
-// (what SWCurveConfig::msm hands over: Rust slices in ordinary heap memory) therefore stage large uploads themselves:
-// a few worker threads copy 32 MiB pieces into a ring of pinned buffers while the DMA engine drains the previous
-// pieces.  Small copies go straight to hipMemcpyAsync.
+// hipMemcpyAsync from pageable memory is staged by the runtime through an internal bounce buffer on the calling thread.
+// The host-pointer entry points (what SWCurveConfig::msm hands over: Rust slices in ordinary heap memory) can stage
+// large uploads themselves instead (ARK_HIP_COPY_THREADS=n): n worker threads copy 32 MiB pieces into a ring of pinned
+// buffers while the DMA engine drains the previous pieces.  Off by default -- on the MI355X hosts measured the runtime's
+// own path is as fast (46 GB/s).  Page-locked sources are always read in place.
 class CopyPool {
  public:
   explicit CopyPool(int nthreads) {
@@ -126,8 +126,11 @@ struct HostStager {
       return 0;
     }
     if (mode < 0) {
-      const char* e = getenv("ARK_HIP_COPY_THREADS");  // 0: leave pageable copies to the runtime
-      int nt = e ? atoi(e) : 4;
+      // default 0: pageable copies are left to the HIP runtime, which reaches ~46 GB/s on the MI355X hosts measured
+      // (2^24 first call 66 ms against 75 ms with four staging threads, profiles/r3_trait_surface.txt); the pool is for
+      // hosts whose runtime path is the slower one
+      const char* e = getenv("ARK_HIP_COPY_THREADS");
+      int nt = e ? atoi(e) : 0;
       const int hw = (int)std::thread::hardware_concurrency();
       if (hw > 0 && nt > hw) nt = hw;
       mode = nt > 0 ? 1 : 0;
@@ -866,9 +869,14 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
   }
   return ark_hip_sw_sum(curve, partials.data(), partials.size() / pw, out_xyz);
 }
-// pieces of one streamed MSM: enough work per piece to keep its fixed costs (sort floors, bucket reduction) small
+// pieces of one streamed MSM: the first piece's upload is the only one nothing hides, so many pieces -- as long as a
+// piece keeps ~2^18 pairs (its ~20 launches and the read-modify-write of every bucket are per piece).  Measured on
+// MI355X, BLS12-381 G1, repeat call with resident bases (profiles/r3_trait_surface.txt): 2^24: 1 / 2 / 4 / 8 pieces
+// 52.6 / 47.1 / 45.3 / 44.0 ms (resident inputs: 41.3); 2^22: 17.0 / 15.2 / 14.0 / 13.5 (13.3); 2^20: 5.9 / 5.4 / 5.3 (4.8).
 size_t msm_stream_step(size_t n) {
-  size_t pieces = n >= ((size_t)1 << 23) ? 4 : (n >= ((size_t)1 << 21) ? 2 : 1);
+  size_t pieces = n >> 18;
+  if (pieces < 1) pieces = 1;
+  if (pieces > 8) pieces = 8;
   if (const char* e = getenv("ARK_HIP_STREAM_PIECES")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64) pieces = (size_t)v;
@@ -1131,6 +1139,19 @@ int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, 
   if (c->stage_b.ensure(sb)) return ARK_HIP_ERR_NOMEM;
   if (int rc = c->stager.upload(c->stage_b.p, scalars, sb, c->stream)) return rc;
   return ark_hip_msm_sw_small_device(curve, d_bases, c->stage_b.p, n, scalar_bytes, max_bits, out_xyz);
+}
+
+// The narrow entries against a PREPARED base set: the per-window table was laid out for 255-bit scalars (its wide windows
+// would leave a u32 vector with one dense and one sparse window); row 0 of the table IS the base set, so narrow scalars
+// run as a plain MSM over it with a plan of their own.
+int ark_hip_msm_prepared_small_device(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int scalar_bytes,
+                                      int max_bits, uint64_t* out_xyz) {
+  if (!bases || !out_xyz) return ARK_HIP_ERR_ARG;
+  const PreparedBases* pb = (const PreparedBases*)bases;
+  if (n > pb->n) return ARK_HIP_ERR_ARG;
+  Scope sc;
+  if (int rc = sc.enter(pb->logical)) return rc;
+  return ark_hip_msm_sw_small_device(pb->curve, pb->table.p, d_scalars, n, scalar_bytes, max_bits, out_xyz);
 }
 
 // ---- resident-base cache control ----

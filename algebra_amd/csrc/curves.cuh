@@ -14,6 +14,7 @@ struct BN254_G1 {
   static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 0;
+  static constexpr bool LAZY_A = false;   // Fp256: the saturated product is as fast (100 multiply-adds for 64 + 64)
   typedef Fp<BN254_FQ> F;
   typedef F FA;                           // field type of the bucket-accumulation kernels
   static constexpr bool RELAXED_A = RELAXED;
@@ -23,6 +24,7 @@ struct BLS12_381_G1 {
   static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 1;
+  static constexpr bool LAZY_A = true;    // accumulate kernels on carry-free 28-bit limbs (fp28.cuh / ec28.cuh)
   typedef Fp<BLS12_381_FQ> F;
   typedef F FA;                           // field type of the bucket-accumulation kernels
   static constexpr bool RELAXED_A = RELAXED;
@@ -32,6 +34,7 @@ struct BLS12_377_G1 {
   static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 2;
+  static constexpr bool LAZY_A = true;
   typedef Fp<BLS12_377_FQ> F;
   typedef F FA;                           // field type of the bucket-accumulation kernels
   static constexpr bool RELAXED_A = RELAXED;
@@ -41,6 +44,7 @@ struct BLS12_377_G2 {
   static constexpr int ACC_MIN_WAVES = 1;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 3;
+  static constexpr bool LAZY_A = false;
   typedef Fp2<BLS12_377_FQ, 5> F;
   typedef Fp2Half<BLS12_377_FQ, 5> FA;    // bucket accumulation: one Fp2 element per lane PAIR (fp.cuh)
   static constexpr bool RELAXED_A = true;
@@ -50,6 +54,7 @@ struct BLS12_381_G2 {
   static constexpr int ACC_MIN_WAVES = 1;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 4;
+  static constexpr bool LAZY_A = false;
   typedef Fp2<BLS12_381_FQ, 1> F;
   typedef Fp2Half<BLS12_381_FQ, 1> FA;    // bucket accumulation: one Fp2 element per lane PAIR (fp.cuh)
   static constexpr bool RELAXED_A = true;

@@ -30,6 +30,7 @@
 #include <mutex>
 #include <math.h>
 #include "curves.cuh"
+#include "ec28.cuh"
 #include "msm_sort.cuh"
 
 namespace arkhip {
@@ -384,6 +385,137 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
   }
   if constexpr (C::RELAXED_A) acc = xyzz_canonical<F>(acc);
   acc.store(cell);
+}
+
+// ---- K4 on carry-free 28-bit limbs (Fp384 G1 curves: C::LAZY_A) -----------------------------------------------
+// The same kernel with the accumulator and every product of the mixed addition in fp28.cuh's form: 392 v_mad_u64_u32 per
+// product instead of 288 + 288 carry instructions, no conditional subtractions.  Bases are gathered in the reference's
+// canonical limbs and only repacked (the radix change is a curve isomorphism, ec28.cuh); buckets leave canonical.
+template <class C>
+__global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const char* __restrict__ bases,
+                                                                  const u32* __restrict__ sorted,
+                                                                  const u32* __restrict__ offsets,
+                                                                  const u32* __restrict__ order, u32 nbuckets,
+                                                                  const u32* __restrict__ d_thresh, int HB, int LB,
+                                                                  int accum, char* __restrict__ buckets) {
+  typedef typename C::F F;
+  typedef typename F::P P;
+  typedef FpL<P> FL;
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  u32 g = order ? order[t] : t;
+  u32 j = offsets[g], end = offsets[g + 1];
+  if (end - j > *d_thresh) return;  // left to the heavy-bucket kernels
+  if (accum && j == end) return;    // nothing to add to the stored sum
+  char* cell = buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES;
+  XYZZL<P> acc;
+  if (accum) {
+    acc = lazy_from_bucket<P>(XYZZ<F>::load(cell));
+  } else {
+    acc.inf = true;
+    acc.x = acc.y = acc.zz = acc.zzz = FL::zero();
+  }
+  if (j < end) {
+    u32 e = sorted[j];
+    u32 e1 = j + 1 < end ? sorted[j + 1] : 0;
+    Affine<F> p = Affine<F>::load(bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+    for (;;) {
+      u32 e2 = 0;
+      Affine<F> p_next = p;
+      const bool more = j + 1 < end;
+      if (more) {
+        p_next = Affine<F>::load(bases + (size_t)(e1 & 0x7fffffffu) * Affine<F>::BYTES);
+        if (j + 2 < end) e2 = sorted[j + 2];
+      }
+      if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
+        FL lx, ly;
+        lazy_from_affine<P>(p.x, p.y, lx, ly);
+        xyzz_madd_lazy<P>(acc, lx, ly, (e >> 31) != 0);
+      }
+      if (!more) break;
+      e = e1;
+      e1 = e2;
+      p = p_next;
+      j++;
+    }
+  }
+  lazy_to_bucket<P>(acc).store(cell);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) msm_accumulate_shared_lazy_kernel(
+    const char* __restrict__ table, size_t wstride, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
+    const u32* __restrict__ order, u32 nbuckets, int W, int B, const u32* __restrict__ d_thresh, int HB, int LB,
+    char* __restrict__ buckets) {
+  typedef typename C::F F;
+  typedef typename F::P P;
+  typedef FpL<P> FL;
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  const u32 s = order ? order[t] : t;
+  const u32 heavy_thresh = *d_thresh;
+  XYZZL<P> acc;
+  acc.inf = true;
+  acc.x = acc.y = acc.zz = acc.zzz = FL::zero();
+  int w = 0;
+  u32 na = offsets[s], nb2 = offsets[s + 1];
+  u32 j = 0, end = 0;
+  const char* wbase = table;
+  auto open_next = [&]() -> bool {
+    while (w < W) {
+      const u32 a = na, b = nb2;
+      const char* wb = table + (size_t)w * wstride * Affine<F>::BYTES;
+      w++;
+      if (w < W) {
+        const u32 g = ((u32)w << B) | s;
+        na = offsets[g];
+        nb2 = offsets[g + 1];
+      }
+      if (b - a > heavy_thresh) continue;
+      if (b > a) {
+        j = a;
+        end = b;
+        wbase = wb;
+        return true;
+      }
+    }
+    return false;
+  };
+  auto next_entry = [&](u32& eo, const char*& wbo) -> bool {
+    if (j >= end && !open_next()) return false;
+    eo = sorted[j];
+    wbo = wbase;
+    j++;
+    return true;
+  };
+  u32 e = 0, e1 = 0;
+  const char *wb = table, *wb1 = table;
+  if (next_entry(e, wb)) {
+    Affine<F> p = Affine<F>::load(wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+    bool have1 = next_entry(e1, wb1);
+    for (;;) {
+      u32 e2 = 0;
+      const char* wb2 = table;
+      bool have2 = false;
+      Affine<F> p_next = p;
+      if (have1) {
+        p_next = Affine<F>::load(wb1 + (size_t)(e1 & 0x7fffffffu) * Affine<F>::BYTES);
+        have2 = next_entry(e2, wb2);
+      }
+      if (!p.is_zero()) {
+        FL lx, ly;
+        lazy_from_affine<P>(p.x, p.y, lx, ly);
+        xyzz_madd_lazy<P>(acc, lx, ly, (e >> 31) != 0);
+      }
+      if (!have1) break;
+      e = e1;
+      p = p_next;
+      e1 = e2;
+      wb1 = wb2;
+      have1 = have2;
+    }
+  }
+  lazy_to_bucket<P>(acc).store(buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * XYZZ<F>::BYTES);
 }
 
 // ---- K4s: bucket accumulation over a PREPARED base set ---------------------------------------------
@@ -1192,8 +1324,23 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                          (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted, accum,
                          d_buckets);
   }
+  bool lazy = false;  // Fp384 G1: the accumulate kernels on carry-free 28-bit limbs (fp28.cuh); ARK_HIP_MSM_LAZY=0: saturated
+  if constexpr (C::LAZY_A) {
+    static const bool lazy_on = [] {
+      const char* e = getenv("ARK_HIP_MSM_LAZY");
+      return !(e && e[0] == '0');
+    }();
+    lazy = lazy_on;
+  }
   if (pl.shared)
   {
+    if constexpr (C::LAZY_A) {
+      if (lazy)
+        hipLaunchKernelGGL((msm_accumulate_shared_lazy_kernel<C>), dim3((u32)((nbk + 255) / 256)), dim3(256), 0, stream,
+                           (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, (const u32*)ws.hctr.p + 2,
+                           HB, LB, d_buckets);
+    }
+    if (!lazy)
     hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
                        (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, (const u32*)ws.hctr.p + 2, HB, LB,
                        d_buckets);
@@ -1201,10 +1348,18 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                        (const u32*)ws.hctr.p, (const HeavyEntry*)ws.hlist.p, offsets, sorted, (const char*)ws.hfinal.p, W,
                        Bbits, HB, LB, d_buckets);
   }
-  else
+  else {
+    if constexpr (C::LAZY_A) {
+      if (lazy)
+        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
+                           (const char*)d_points, sorted, offsets, order, (u32)nb, (const u32*)ws.hctr.p + 2, HB, LB, accum,
+                           d_buckets);
+    }
+    if (!lazy)
     hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
                        (const char*)d_points, sorted, offsets, order, (u32)nb, (const u32*)ws.hctr.p + 2, HB, LB, accum,
                        d_buckets);
+  }
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
   if (piece) ARK_HIP_TRY(hipEventRecord(piece->after_this, stream));
   if (piece && !piece->last) {  // the reduction belongs to the last piece: only the scalar-range flag goes back

@@ -302,6 +302,18 @@ class PreparedBases:
         check(L.ark_hip_msm_prepared_async(self._h, sp, n, int(montgomery), C.byref(h)), "ark_hip_msm_prepared_async")
         return MsmJob(self.curve, h, (self, s))
 
+    def msm_small(self, scalars, max_bits=0):
+        """msm_u1 / u8 / u16 / u32 / u64 against this base set: `scalars` is a CUDA tensor of 1-, 2-, 4- or 8-byte
+        integers (ark_hip_msm_prepared_small_device)."""
+        import torch
+        assert _is_torch(scalars) and scalars.is_cuda and scalars.is_contiguous()
+        torch.cuda.current_stream().synchronize()
+        n = min(self.n, scalars.numel())
+        out = np.zeros(cv.projective_words(self.curve), dtype=np.uint64)
+        check(lib().ark_hip_msm_prepared_small_device(self._h, scalars.data_ptr(), n, scalars.element_size(), max_bits,
+                                                      out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_prepared_small_device")
+        return out
+
     def free(self):
         if self._h is not None and self._h.value:
             check(lib().ark_hip_msm_bases_free(self._h), "ark_hip_msm_bases_free")

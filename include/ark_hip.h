@@ -24,9 +24,9 @@
  * Environment: ARK_HIP_WAIT=block makes an MSM wait for the GPU with a blocking hipEventSynchronize; by default the
  * calling thread polls the completion event (the MSM is on its caller's critical path; a sleeping thread was measured
  * to add up to 1 ms per call on some hosts).  ARK_HIP_MSM_C / ARK_HIP_MSM_C_PREPARED force the window size (tuning).
- * ARK_HIP_COPY_THREADS (default 4; 0 = leave it to the HIP runtime): worker threads that stage uploads from ordinary
- * (pageable) host memory through page-locked buffers.  ARK_HIP_STREAM_PIECES: pieces a host-scalar MSM is cut into
- * (default 4 from 2^23 pairs, 2 from 2^21).  ARK_HIP_BASE_CACHE_MB / ARK_HIP_AUTO_PREPARE: see ark_hip_msm_cache_config.
+ * ARK_HIP_COPY_THREADS=n (default 0 = the HIP runtime's own pageable path): n worker threads stage uploads from ordinary
+ * host memory through page-locked buffers.  ARK_HIP_STREAM_PIECES: pieces a host-scalar MSM is cut into (default
+ * n / 2^18, at most 8).  ARK_HIP_BASE_CACHE_MB / ARK_HIP_AUTO_PREPARE: see ark_hip_msm_cache_config.
  */
 #ifndef ARK_HIP_H
 #define ARK_HIP_H
@@ -146,6 +146,10 @@ int ark_hip_msm_prepared(const ark_hip_msm_bases* bases, const uint64_t* scalars
                          uint64_t* out_xyz);
 int ark_hip_msm_prepared_device(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n,
                                 int scalars_are_montgomery, uint64_t* out_xyz);
+/* Narrow scalars (ark_hip_msm_sw_small's scalar_bytes / max_bits) against a prepared base set: runs as a plain MSM over
+ * the base set itself (row 0 of the table) with a window plan for the narrow scalars. */
+int ark_hip_msm_prepared_small_device(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int scalar_bytes,
+                                      int max_bits, uint64_t* out_xyz);
 /* Asynchronous forms.  The host-scalar one uploads through a two-slot ring on a copy stream: the upload of MSM k+1's
  * scalars overlaps MSM k's kernels. */
 int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n,

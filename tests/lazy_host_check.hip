@@ -1,55 +1,131 @@
-// Host-side check of the 28-bit-limb ("lazy") field and mixed addition (algebra_amd/csrc/ubench/lazy.cuh) against the
-// saturated form (fp.cuh / ec.cuh, itself checked against the oracle): conversions, products, lazy add/sub,
-// exact zero tests, and random point sequences that hit the doubling and infinity branches.  The templates are
-// __host__ __device__, so this runs on the CPU.  Built and run by tests/test_lazy_host.py.
-#include "lazy.cuh"
+// Host-side check of the carry-free 28-bit-limb arithmetic of the bucket-accumulation kernel (algebra_amd/csrc/fp28.cuh,
+// ec28.cuh) against the saturated form (fp.cuh / ec.cuh, itself checked against the oracle on the GPU): repacking,
+// products, sums of two products, differences, divisions by powers of two, exact zero tests, and random point sequences
+// through the curve-isomorphism boundary (lazy_from_affine / lazy_from_bucket / lazy_to_bucket) that hit the doubling and
+// infinity branches and the "continue from a stored bucket" path.  The templates are __host__ __device__, so this runs on
+// the CPU.  Built and run by tests/test_lazy_host.py.
+#include "ec28.cuh"
 #include "curves.cuh"
 #include <stdio.h>
 #include <random>
 using namespace arkhip;
-template<class P> Fp<P> rnd(std::mt19937_64& g){ Fp<P> a; for(int i=0;i<P::N;i++) a.l[i]=(u32)g(); a.l[P::N-1]&= (1u<<((P::BITS-1)%32))-1; return a; }
-template<class P> int run(const char* name, const uint64_t* gen){
-  typedef Fp<P> F; typedef FpLazy<P> L;
-  std::mt19937_64 g(7); int bad=0;
-  for(int it=0;it<2000;it++){
-    F a=rnd<P>(g), b=rnd<P>(g);
-    L la=L::from_canonical(a), lb=L::from_canonical(b);
-    if(!F::eq(la.to_canonical(), a)) {bad++; if(bad<5) printf("%s roundtrip fail\n",name);}
-    if(!F::eq(L::mul(la,lb).to_canonical(), F::mul(a,b))) {bad++; if(bad<5) printf("%s mul fail\n",name);}
-    if(!F::eq(L::template sub<1>(la,lb).to_canonical(), F::sub(a,b))) {bad++; if(bad<5) printf("%s sub fail\n",name);}
-    if(!F::eq(L::add_lazy(la,lb).to_canonical(), F::add(a,b))) {bad++; if(bad<5) printf("%s add fail\n",name);}
-    L z=L::template sub<3>(la,la); if(!z.is_zero_mod_p()) {bad++; printf("zero test fail\n");}
-    if(L::template sub<2>(la,lb).is_zero_mod_p() && !F::eq(a,b)) {bad++; printf("false zero\n");}
+template <class P> Fp<P> rnd(std::mt19937_64& g) {
+  Fp<P> a;
+  for (int i = 0; i < P::N; i++) a.l[i] = (u32)g();
+  a.l[P::N - 1] &= (1u << ((P::BITS - 1) % 32)) - 1;   // < 2^(BITS-1) < p
+  return a;
+}
+// the residue a lazy value stands for, as a canonical Fp (radix R): lazy bits b = v R' ; canonical bits = v R = b 2^-8K..
+// generic: multiply the repacked integer by (R / R') mod p through one saturated product with the constant R^2 / R'.
+template <class P> Fp<P> lazy_value(const FpL<P>& a) {  // value v (mod p) in canonical Montgomery form
+  typedef Fp<P> F;
+  // reduce the (possibly > p) integer first: pack needs < 2^(32N); all test values are < 9p < 2^(32N)
+  u32 w[P::N];
+  a.pack32(w);
+  F t = F::reduce_full(*(const F*)w);   // integer a mod p, = v R' mod p
+  // v R = t * (R / R') = t * 2^-(28L - 32N): repeated halving mod p
+  for (int k = 0; k < 28 * FpL<P>::L - 32 * P::N; k++) {
+    // t/2 mod p
+    u32 c = 0;
+    F x = t;
+    if (x.l[0] & 1) { for (int i = 0; i < P::N; i++) { u64 s = (u64)x.l[i] + P::P[i] + c; x.l[i] = (u32)s; c = (u32)(s >> 32); } }
+    for (int i = 0; i < P::N - 1; i++) x.l[i] = (x.l[i] >> 1) | (x.l[i + 1] << 31);
+    x.l[P::N - 1] = (x.l[P::N - 1] >> 1) | (c << 31);
+    t = x;
   }
-  // point sequences: start from generator G, build multiples by madd both ways
-  F gx=F::load(gen), gy=F::load((const char*)gen+F::BYTES);
-  // points: P_k = k*G affine via canonical arithmetic (xyzz then normalise using inverse)
-  const int NP=40; F px[NP], py[NP];
-  XYZZ<F> acc=XYZZ<F>::zero();
-  for(int k=0;k<NP;k++){ xyzz_madd<F>(acc,gx,gy); F zi=F::inverse(acc.zzz); F zzi=F::sqr(F::mul(acc.zz,zi)); px[k]=F::mul(acc.x,zzi); py[k]=F::mul(acc.y,zi); }
-  for(int trial=0;trial<200;trial++){
-    XYZZ<F> c=XYZZ<F>::zero(); XYZZLazy<P> lz; lz.inf=true; lz.x=lz.y=lz.zz=lz.zzz=L::zero();
-    int len = 1 + g()%12;
-    for(int s=0;s<len;s++){
-      int k=g()%NP; bool neg=g()&1;
-      if(trial%5==0 && s==1) { /* force same point twice or inverse */ }
-      F y=F::cond_neg(py[k],neg);
-      xyzz_madd<F>(c,px[k],y);
-      xyzz_madd_lazy<P>(lz, L::from_canonical(px[k]), L::from_canonical(py[k]), neg);
-      if(trial%3==0){ // repeat the same point: doubling; then its inverse twice
-        xyzz_madd<F>(c,px[k],y); xyzz_madd_lazy<P>(lz, L::from_canonical(px[k]), L::from_canonical(py[k]), neg);
-      }
-      if(trial%7==0){ F ny=F::neg(y); xyzz_madd<F>(c,px[k],ny); xyzz_madd_lazy<P>(lz, L::from_canonical(px[k]), L::from_canonical(py[k]), !neg); }
+  return t;
+}
+template <class P> FpL<P> to_lazy(const Fp<P>& a) {  // canonical a -> lazy value a (radix R'): bits = a 2^(28L-32N) mod p
+  typedef Fp<P> F;
+  F t = a;
+  for (int k = 0; k < 28 * FpL<P>::L - 32 * P::N; k++) t = F::dbl(t);
+  return FpL<P>::unpack32(t.l);
+}
+template <class P> int run(const char* name, const uint64_t* gen) {
+  typedef Fp<P> F;
+  typedef FpL<P> L;
+  std::mt19937_64 g(7);
+  int bad = 0;
+  for (int it = 0; it < 2000; it++) {
+    F a = rnd<P>(g), b = rnd<P>(g), c = rnd<P>(g), d = rnd<P>(g);
+    L la = to_lazy<P>(a), lb = to_lazy<P>(b), lc = to_lazy<P>(c), ld = to_lazy<P>(d);
+    if (!F::eq(lazy_value<P>(la), a)) { bad++; if (bad < 5) printf("%s roundtrip fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul(la, lb)), F::mul(a, b))) { bad++; if (bad < 5) printf("%s mul fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::sop2(la, lb, lc, ld)), F::add(F::mul(a, b), F::mul(c, d)))) { bad++; if (bad < 5) printf("%s sop2 fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::template sub<1>(la, lb)), F::sub(a, b))) { bad++; if (bad < 5) printf("%s sub fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::template sub_b_2c<4>(la, lb, lc)), F::sub(F::sub(a, b), F::dbl(c)))) { bad++; if (bad < 5) printf("%s sub_b_2c fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::template negsub<4>(la, lb)), F::neg(F::add(a, b)))) { bad++; if (bad < 5) printf("%s negsub fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul(L::add_lazy(la, lb), lc)), F::mul(F::add(a, b), c))) { bad++; if (bad < 5) printf("%s lazy-add operand fail\n", name); }
+    // v 2^-K: compare through 2^K * result == v
+    {
+      F h = lazy_value<P>(la.template shr_mod<4>());
+      for (int k = 0; k < 4; k++) h = F::dbl(h);  // 16 * (a / 16)
+      if (!F::eq(h, a)) { bad++; if (bad < 5) printf("%s shr_mod<4> fail\n", name); }
+      L h20 = la.template shr_mod<20>(), h16 = la.template shr_mod<16>().template shr_mod<4>();
+      if (!F::eq(lazy_value<P>(h20), lazy_value<P>(h16))) { bad++; if (bad < 5) printf("%s shr_mod<20> fail\n", name); }
     }
-    XYZZ<F> d=xyzz_from_lazy<P>(lz);
-    // compare as group elements: cross-multiply
-    bool same;
-    if(c.is_zero()||d.is_zero()) same = c.is_zero()&&d.is_zero();
-    else same = F::eq(F::mul(c.x,d.zz),F::mul(d.x,c.zz)) && F::eq(F::mul(c.y,d.zzz),F::mul(d.y,c.zzz));
-    if(!same){bad++; if(bad<8) printf("%s point seq mismatch trial %d\n",name,trial);}
+    L z = L::template sub<3>(la, la);
+    if (!z.is_zero_mod_p()) { bad++; printf("zero test fail\n"); }
+    if (L::template sub<2>(la, lb).is_zero_mod_p() && !F::eq(a, b)) { bad++; printf("false zero\n"); }
   }
-  printf("%s: %s (%d bad)\n", name, bad?"FAIL":"ok", bad);
+  // point sequences: multiples of the generator as affine points of E (canonical form, as they sit in HBM)
+  F gx = F::load(gen), gy = F::load((const char*)gen + F::BYTES);
+  const int NP = 40;
+  F px[NP], py[NP];
+  XYZZ<F> acc = XYZZ<F>::zero();
+  for (int k = 0; k < NP; k++) {
+    xyzz_madd<F>(acc, gx, gy);
+    F zi = F::inverse(acc.zzz);
+    F zzi = F::sqr(F::mul(acc.zz, zi));
+    px[k] = F::mul(acc.x, zzi);
+    py[k] = F::mul(acc.y, zi);
+  }
+  for (int trial = 0; trial < 300; trial++) {
+    XYZZ<F> c = XYZZ<F>::zero();
+    XYZZL<P> lz;
+    lz.inf = true;
+    lz.x = lz.y = lz.zz = lz.zzz = L::zero();
+    int len = 1 + g() % 12;
+    for (int s = 0; s < len; s++) {
+      int k = g() % NP;
+      bool neg = g() & 1;
+      F y = F::cond_neg(py[k], neg);
+      L lx, ly;
+      lazy_from_affine<P>(px[k], py[k], lx, ly);
+      xyzz_madd<F>(c, px[k], y);
+      xyzz_madd_lazy<P>(lz, lx, ly, neg);
+      if (trial % 3 == 0) {  // the same point again: the doubling branch
+        xyzz_madd<F>(c, px[k], y);
+        xyzz_madd_lazy<P>(lz, lx, ly, neg);
+      }
+      if (trial % 7 == 0) {  // then its inverse: cancels (possibly to infinity)
+        F ny = F::neg(y);
+        xyzz_madd<F>(c, px[k], ny);
+        xyzz_madd_lazy<P>(lz, lx, ly, !neg);
+      }
+      if (trial % 4 == 1 && s == len / 2) {  // a streamed MSM's later piece: store the bucket, load it back, go on
+        XYZZ<F> stored = lazy_to_bucket<P>(lz);  // what reaches HBM is canonical
+        lz = lazy_from_bucket<P>(stored);
+      }
+    }
+    XYZZ<F> d = lazy_to_bucket<P>(lz);
+    // the stored bucket must be canonical (every coordinate < p) and the same group element
+    bool canon = true;
+    F* cs[4] = {&d.x, &d.y, &d.zz, &d.zzz};
+    for (F* f : cs) { F r = F::reduce_once(f->l); if (!F::eq(r, *f)) canon = false; }
+    bool same;
+    if (c.is_zero() || d.is_zero()) same = c.is_zero() && d.is_zero();
+    else same = F::eq(F::mul(c.x, d.zz), F::mul(d.x, c.zz)) && F::eq(F::mul(c.y, d.zzz), F::mul(d.y, c.zzz)) &&
+                F::eq(F::mul(F::sqr(d.zz), d.zz), F::sqr(d.zzz));  // and a valid XYZZ: ZZ^3 = ZZZ^2
+    if (!same || !canon) { bad++; if (bad < 8) printf("%s point seq mismatch trial %d (same=%d canon=%d)\n", name, trial, (int)same, (int)canon); }
+  }
+  printf("%s: %s (%d bad)\n", name, bad ? "FAIL" : "ok", bad);
   return bad;
 }
 #include "curve_consts.hpp"
-int main(){ int b=0; b+=run<BLS12_381_FQ>("BLS12_381_FQ",GEN_BLS12_381_G1); b+=run<BN254_FQ>("BN254_FQ",GEN_BN254_G1); b+=run<BLS12_377_FQ>("BLS12_377_FQ",GEN_BLS12_377_G1); return b!=0; }
+int main() {
+  int b = 0;
+  b += run<BLS12_381_FQ>("BLS12_381_FQ", GEN_BLS12_381_G1);
+  b += run<BLS12_377_FQ>("BLS12_377_FQ", GEN_BLS12_377_G1);
+  return b != 0;
+}

@@ -1,5 +1,6 @@
-"""ubench/lazy.cuh (28-bit-limb field: a measured alternative to the shipped 32-bit-limb arithmetic, not part of
-the product library -- see DESIGN.md) is kept parity-green by compiling its host build and checking it against the saturated-limb arithmetic."""
+"""csrc/fp28.cuh + ec28.cuh (the carry-free 28-bit-limb arithmetic of the Fp384 bucket-accumulation kernels, and the
+curve-isomorphism boundary that lets it consume / produce the reference's canonical limbs) checked on the HOST against
+the saturated-limb arithmetic: the templates are __host__ __device__, so the very code of the kernel runs here."""
 import os
 import shutil
 import subprocess
@@ -14,8 +15,7 @@ def test_lazy_field_and_madd_match_saturated_form(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     exe = str(tmp_path / "lazy_check")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "algebra_amd", "csrc"), "-I", os.path.join(ROOT, "algebra_amd", "csrc", "ubench"),
-                           os.path.join(ROOT, "tests", "lazy_host_check.hip"), "-o", exe], timeout=600)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "algebra_amd", "csrc"),                            os.path.join(ROOT, "tests", "lazy_host_check.hip"), "-o", exe], timeout=600)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count(": ok") == 3, out.stdout
+    assert out.stdout.count(": ok") == 2, out.stdout

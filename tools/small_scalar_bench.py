@@ -89,6 +89,13 @@ def main():
             dt = (time.perf_counter() - t0) / 3
             line += "  msm_%s-direct %6.2f ms (exact=%s)" % (name if name != "bool" else "u1", dt * 1e3,
                                                              bool(np.array_equal(A.into_affine(cid, res), kg)))
+            mb = 1 if name == "bool" else 0
+            pb.msm_small(dn, mb)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                res = pb.msm_small(dn, mb)
+            dt = (time.perf_counter() - t0) / 3
+            line += "  prepared-direct %6.2f ms (exact=%s)" % (dt * 1e3, bool(np.array_equal(A.into_affine(cid, res), kg)))
         print(line, flush=True)
     pb.free()
 
