@@ -15,8 +15,9 @@
 //
 // Role in the reference: the same field, ff/src/fields/models/fp/montgomery_backend.rs:129-246 -- there with R = 2^(64 N)
 // and canonical results.  This form never leaves the accumulate kernel: bases enter through a repacking of their
-// canonical limbs (the change of Montgomery radix is absorbed by a curve isomorphism, ec28.cuh) and buckets are stored
-// in the reference's canonical form again, so everything downstream -- and every result -- is bit-identical.
+// canonical limbs shifted left by 28 L - 32 N = 8 bits (x R 2^8 = x R': the SAME residue in the new radix, merely not
+// reduced -- below 256 p, which a multiplication operand may be) and buckets are stored in the reference's canonical
+// form again, so everything downstream -- and every result -- is bit-identical.
 #pragma once
 #include "fp.cuh"
 
@@ -41,9 +42,47 @@ struct FpL {
   ARK_HD static FpL one() { return unpack32(P::LZ_CIN); }
 
   // Montgomery product a b 2^(-28 L) mod p: normalised output below a b / 2^(28 L) + p.
-  // Column bound: 14 products a_i b_j + 14 products m_i p_j + carry < 14 (2^30 2^28 + 2^56) + 2^36 < 2^62: one operand may
-  // carry limbs up to 2^30 (an unnormalised sum / difference), the other must be normalised.
+  // Column bound: 14 products a_i b_j + 14 products m_i p_j + carry: with both operands semi-normalised (limbs < 3 2^28,
+  // sub_semi below) 14 x 9 2^56 + 14 x 2^56 + 2^36 < 2^63.2; one normalised operand admits limbs up to 2^31 on the other.
+  //
+  // Two accumulator chains per column.  v_mad_u64_u32 into ONE accumulator is a serial dependency, and with the two
+  // waves per SIMD the accumulate kernel's registers allow the multiplier's latency is exposed (product rate at 1 / 2 /
+  // 4 / 8 waves per SIMD with a single chain: 53.8 / 62.8 / 70.0 / 74.3 G/s, profiles/r3_ubench_product_rate.txt).  The
+  // operand part A_k = sum a_i b_(k-i) of a column depends on nothing but the inputs, the reduction part
+  // B_k = carry + sum m_i p_(k-i) on the earlier columns: written as separate sums (one 64-bit addition joins them) the
+  // scheduler interleaves column k's reduction chain with column k+1's operand chain.
   ARK_HD static FpL mul(const FpL& a, const FpL& b) {
+    u32 m[L];
+    FpL r;
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+      u64 A = 0, B = carry;
+#pragma unroll
+      for (int i = 0; i <= k; i++) A += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = 0; i < k; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
+      u64 t = A + B;
+      m[k] = ((u32)t * P::LZ_INV) & MASK;
+      t += (u64)m[k] * P::LZ_KP[1][0];
+      carry = t >> 28;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+      u64 A = 0, B = carry;
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) A += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
+      const u64 t = A + B;
+      r.l[k - L] = (u32)t & MASK;
+      carry = t >> 28;
+    }
+    r.l[L - 1] = (u32)carry;
+    return r;
+  }
+  // the single-chain form (kept for the microbenchmark's A/B: csrc/ubench/mulbench.hip)
+  ARK_HD static FpL mul_chain1(const FpL& a, const FpL& b) {
     u32 m[L];
     FpL r;
     u64 acc = 0;
@@ -69,38 +108,78 @@ struct FpL {
     r.l[L - 1] = (u32)acc;
     return r;
   }
-  ARK_HD static FpL sqr(const FpL& a) { return mul(a, a); }
+  // a^2 of a normalised or semi-normalised a (limbs < 3 2^28): every cross product once, against the doubled limb (< 6 2^28;
+  // per column at most 7 x 18 2^56 + 9 2^56 + 14 x 2^56 + carry < 2^63.3).  105 + 196 multiply-adds instead of 392.
+  // (The saturated form's dedicated square lost to mul(a, a) on its doubling carries -- DESIGN 4; here doubling is a shift.)
+  ARK_HD static FpL sqr(const FpL& a) {
+    u32 m[L], d[L];
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < L; i++) d[i] = a.l[i] << 1;
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+      u64 A = 0, B = carry;
+#pragma unroll
+      for (int i = 0; 2 * i < k; i++) A += (u64)a.l[i] * d[k - i];
+      if (k % 2 == 0) A += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+      for (int i = 0; i < k; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
+      u64 t = A + B;
+      m[k] = ((u32)t * P::LZ_INV) & MASK;
+      t += (u64)m[k] * P::LZ_KP[1][0];
+      carry = t >> 28;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+      u64 A = 0, B = carry;
+#pragma unroll
+      for (int i = k - L + 1; 2 * i < k; i++) A += (u64)a.l[i] * d[k - i];
+      if (k % 2 == 0) A += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
+      const u64 t = A + B;
+      r.l[k - L] = (u32)t & MASK;
+      carry = t >> 28;
+    }
+    r.l[L - 1] = (u32)carry;
+    return r;
+  }
   // a b + c d under ONE reduction (montgomery_backend.rs:415-516 sum_of_products, M = 2): the Y3 of every bucket
   // addition.  All four operands normalised (28 products + 14 reduction terms of < 2^56 per column: < 2^62);
   // output normalised, below (a b + c d) / 2^(28 L) + p.
   ARK_HD static FpL sop2(const FpL& a, const FpL& b, const FpL& c, const FpL& d) {
     u32 m[L];
     FpL r;
-    u64 acc = 0;
+    u64 carry = 0;
 #pragma unroll
     for (int k = 0; k < L; k++) {
+      u64 A = 0, C = 0, B = carry;   // three independent chains (see mul)
 #pragma unroll
-      for (int i = 0; i <= k; i++) acc += (u64)a.l[i] * b.l[k - i];
+      for (int i = 0; i <= k; i++) A += (u64)a.l[i] * b.l[k - i];
 #pragma unroll
-      for (int i = 0; i <= k; i++) acc += (u64)c.l[i] * d.l[k - i];
+      for (int i = 0; i <= k; i++) C += (u64)c.l[i] * d.l[k - i];
 #pragma unroll
-      for (int i = 0; i < k; i++) acc += (u64)m[i] * P::LZ_KP[1][k - i];
-      m[k] = ((u32)acc * P::LZ_INV) & MASK;
-      acc += (u64)m[k] * P::LZ_KP[1][0];
-      acc >>= 28;
+      for (int i = 0; i < k; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
+      u64 t = A + C + B;
+      m[k] = ((u32)t * P::LZ_INV) & MASK;
+      t += (u64)m[k] * P::LZ_KP[1][0];
+      carry = t >> 28;
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
+      u64 A = 0, C = 0, B = carry;
 #pragma unroll
-      for (int i = k - L + 1; i < L; i++) acc += (u64)a.l[i] * b.l[k - i];
+      for (int i = k - L + 1; i < L; i++) A += (u64)a.l[i] * b.l[k - i];
 #pragma unroll
-      for (int i = k - L + 1; i < L; i++) acc += (u64)c.l[i] * d.l[k - i];
+      for (int i = k - L + 1; i < L; i++) C += (u64)c.l[i] * d.l[k - i];
 #pragma unroll
-      for (int i = k - L + 1; i < L; i++) acc += (u64)m[i] * P::LZ_KP[1][k - i];
-      r.l[k - L] = (u32)acc & MASK;
-      acc >>= 28;
+      for (int i = k - L + 1; i < L; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
+      const u64 t = A + C + B;
+      r.l[k - L] = (u32)t & MASK;
+      carry = t >> 28;
     }
-    r.l[L - 1] = (u32)acc;
+    r.l[L - 1] = (u32)carry;
     return r;
   }
 
@@ -156,6 +235,66 @@ struct FpL {
     for (int i = 0; i < L; i++) d[i] = (int)P::LZ_KP[K][i] - (int)a.l[i];
     return normalise(d);
   }
+  // ---- differences WITHOUT a carry sweep ----------------------------------------------------------------------
+  // K p written with limbs d_i in [H 2^28 - H, (H + 1) 2^28) (every limb lends H 2^28 to the one below it): for normalised
+  // subtrahends a limb-wise  a_i - b_i + d_i  can then not go negative, so the difference needs no signed carry sweep at
+  // all: 2 instructions per limb.  The result is "semi-normalised" -- limbs below (H + 2) 2^28 -- which a product accepts
+  // on BOTH sides for H = 1 (14 x (3 2^28)^2 + 14 x 2^56 < 2^63.1).  The top limb lends nothing and must dominate the
+  // subtrahend's: floor(K p / 2^364) - H >= floor(b / 2^364), true whenever K exceeds the subtrahend's bound by >= 1/2.
+  template <int K, int H>
+  static constexpr u32 kp_spread(int i) {
+    return P::LZ_KP[K][i] + (i < L - 1 ? ((u32)H << 28) : 0u) - (i > 0 ? (u32)H : 0u);
+  }
+  // a - b + K p, semi-normalised (a, b normalised)
+  template <int K>
+  ARK_HD static FpL sub_semi(const FpL& a, const FpL& b) {
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] - b.l[i] + kp_spread<K, 1>(i);
+    return r;
+  }
+  // K p - a, limbs below 2^29 (a normalised)
+  template <int K>
+  ARK_HD static FpL neg_semi(const FpL& a) {
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = kp_spread<K, 1>(i) - a.l[i];
+    return r;
+  }
+  // neg ? K p - a : a    (a normalised; limbs below 2^29)
+  template <int K>
+  ARK_HD static FpL cond_neg_semi(const FpL& a, bool neg) {
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = neg ? kp_spread<K, 1>(i) - a.l[i] : a.l[i];
+    return r;
+  }
+  // a - b - 2 c + K p, NORMALISED (a, b, c normalised): limbs a_i - b_i - 2 c_i + d_i with d_i >= 3 2^28 - 3 stay
+  // non-negative, so the carry sweep is unsigned
+  template <int K>
+  ARK_HD static FpL sub_b_2c_norm(const FpL& a, const FpL& b, const FpL& c) {
+    FpL r;
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+      const u32 v = a.l[i] - b.l[i] - 2u * c.l[i] + kp_spread<K, 3>(i) + carry;
+      r.l[i] = v & MASK;
+      carry = v >> 28;
+    }
+    r.l[L - 1] = a.l[L - 1] - b.l[L - 1] - 2u * c.l[L - 1] + kp_spread<K, 3>(L - 1) + carry;
+    return r;
+  }
+  // is the normalised value, known to lie below 2 p, zero mod p (i.e. 0 or p)?  One-limb filter, exact compare behind it.
+  ARK_HD bool is_zero_or_p() const {
+    if (l[0] != 0u && l[0] != P::LZ_KP[1][0]) return false;
+    u32 o0 = 0, o1 = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      o0 |= l[i];
+      o1 |= l[i] ^ P::LZ_KP[1][i];
+    }
+    return o0 == 0u || o1 == 0u;
+  }
   // is the (normalised, < 9 p) value a multiple of p?  One-limb filter, exact compare behind it.
   ARK_HD bool is_zero_mod_p() const {
     bool hit = false;
@@ -186,6 +325,27 @@ struct FpL {
       if (j < N) v = (u64)in[j] >> sh;
       if (j + 1 < N) v |= (u64)in[j + 1] << (32 - sh);
       r.l[i] = (u32)v & MASK;
+    }
+    return r;
+  }
+  // the canonical limbs shifted left by SH = 28 L - 32 N bits: x R 2^SH = x R', i.e. the residue x itself in this form's
+  // radix, unreduced (below 2^SH p; normalised limbs) -- good as ONE operand of a product: x y / R' < 2^SH y p / R'
+  static constexpr int SH = 28 * L - 32 * N;
+  ARK_HD static FpL unpack32_shl(const u32* in) {
+    static_assert(SH >= 0 && SH < 28, "shift within the lowest limb");
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const int bit = 28 * i - SH;   // input bit that lands at this limb's bit 0
+      if (bit < 0) {
+        r.l[i] = (in[0] << SH) & MASK;
+      } else {
+        const int j = bit / 32, sh = bit % 32;
+        u64 v = 0;
+        if (j < N) v = (u64)in[j] >> sh;
+        if (j + 1 < N) v |= (u64)in[j + 1] << (32 - sh);
+        r.l[i] = (u32)v & MASK;
+      }
     }
     return r;
   }

@@ -388,11 +388,14 @@ __global__ void __launch_bounds__(256, C::ACC_MIN_WAVES) msm_accumulate_kernel(c
 }
 
 // ---- K4 on carry-free 28-bit limbs (Fp384 G1 curves: C::LAZY_A) -----------------------------------------------
+#ifndef ARK_LAZY_MIN_WAVES
+#define ARK_LAZY_MIN_WAVES 2   // waves per SIMD the register allocation must leave room for
+#endif
 // The same kernel with the accumulator and every product of the mixed addition in fp28.cuh's form: 392 v_mad_u64_u32 per
 // product instead of 288 + 288 carry instructions, no conditional subtractions.  Bases are gathered in the reference's
 // canonical limbs and only repacked (the radix change is a curve isomorphism, ec28.cuh); buckets leave canonical.
 template <class C>
-__global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const char* __restrict__ bases,
+__global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_lazy_kernel(const char* __restrict__ bases,
                                                                   const u32* __restrict__ sorted,
                                                                   const u32* __restrict__ offsets,
                                                                   const u32* __restrict__ order, u32 nbuckets,
@@ -429,8 +432,12 @@ __global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const char* __
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
         FL lx, ly;
-        lazy_from_affine<P>(p.x, p.y, lx, ly);
-        xyzz_madd_lazy<P>(acc, lx, ly, (e >> 31) != 0);
+        lazy_from_affine<P>(p.x, F::cond_neg(p.y, (e >> 31) != 0), lx, ly);  // negative digit: -P
+        if (xyzz_madd_lazy<P>(acc, lx, ly)) {  // the base equals the accumulated point (duplicate bases): doubling
+          XYZZL<P> dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
+          xyzz_mdbl_lazy<P>(dbl, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
+          acc = dbl;
+        }
       }
       if (!more) break;
       e = e1;
@@ -443,7 +450,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_lazy_kernel(const char* __
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) msm_accumulate_shared_lazy_kernel(
+__global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_shared_lazy_kernel(
     const char* __restrict__ table, size_t wstride, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
     const u32* __restrict__ order, u32 nbuckets, int W, int B, const u32* __restrict__ d_thresh, int HB, int LB,
     char* __restrict__ buckets) {
@@ -504,8 +511,12 @@ __global__ void __launch_bounds__(256) msm_accumulate_shared_lazy_kernel(
       }
       if (!p.is_zero()) {
         FL lx, ly;
-        lazy_from_affine<P>(p.x, p.y, lx, ly);
-        xyzz_madd_lazy<P>(acc, lx, ly, (e >> 31) != 0);
+        lazy_from_affine<P>(p.x, F::cond_neg(p.y, (e >> 31) != 0), lx, ly);  // negative digit: -P
+        if (xyzz_madd_lazy<P>(acc, lx, ly)) {  // the base equals the accumulated point (duplicate bases): doubling
+          XYZZL<P> dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
+          xyzz_mdbl_lazy<P>(dbl, wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
+          acc = dbl;
+        }
       }
       if (!have1) break;
       e = e1;

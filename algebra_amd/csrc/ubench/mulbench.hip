@@ -1,31 +1,66 @@
-#include "lazy.cuh"
-using namespace arkhip;
-template<class P> __global__ void __launch_bounds__(256) k_lazy(u32* out, int iters){
-  typedef FpLazy<P> L; L a,b; u32 tid=blockIdx.x*blockDim.x+threadIdx.x;
-  for(int i=0;i<L::L;i++){a.l[i]=(tid*2654435761u*(i+1))&L::MASK; b.l[i]=((tid^77)*40503u*(i+3))&L::MASK;}
-  for(int k=0;k<iters;k++) a=L::mul(a,b);
-  u32 r=0; for(int i=0;i<L::L;i++) r^=a.l[i]; out[tid]=r;
-}
-template<class P> __global__ void __launch_bounds__(256) k_sat(u32* out, int iters){
-  typedef Fp<P> F; F a,b; u32 tid=blockIdx.x*blockDim.x+threadIdx.x;
-  for(int i=0;i<F::N;i++){a.l[i]=(tid*2654435761u*(i+1)); b.l[i]=((tid^77)*40503u*(i+3));} a.l[F::N-1]&=0xfffffff; b.l[F::N-1]&=0xfffffff;
-  for(int k=0;k<iters;k++) a=F::mul(a,b);
-  u32 r=0; for(int i=0;i<F::N;i++) r^=a.l[i]; out[tid]=r;
-}
-template __global__ void k_lazy<BLS12_381_FQ>(u32*,int);
-template __global__ void k_sat<BLS12_381_FQ>(u32*,int);
+// Product-rate microbenchmark of the two Fp384 multiplications the accumulate kernels can run on (BLS12-381 Fq):
+// fp.cuh's saturated 32-bit Comba product against fp28.cuh's carry-free 28-bit forms (single chain, two chains,
+// dedicated square, sum of two products), back to back in a loop at 1 / 2 / 4 / 8 waves per SIMD.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I.. mulbench.hip -o mulbench.bin
+#include "../fp28.cuh"
 #include <stdio.h>
-int main(){
-  u32* out; hipMalloc(&out, 256*8*256*4*4); hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int iters=2000;
-  for(int w: {1,2,4,8}){
-    for(int v=0; v<2; v++){
-      int b=256*w;
-      if(v==0) hipLaunchKernelGGL((k_lazy<BLS12_381_FQ>), dim3(b), dim3(256),0,0,out,10); else hipLaunchKernelGGL((k_sat<BLS12_381_FQ>), dim3(b), dim3(256),0,0,out,10);
-      hipDeviceSynchronize(); hipEventRecord(e0);
-      if(v==0) hipLaunchKernelGGL((k_lazy<BLS12_381_FQ>), dim3(b), dim3(256),0,0,out,iters); else hipLaunchKernelGGL((k_sat<BLS12_381_FQ>), dim3(b), dim3(256),0,0,out,iters);
-      hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1);
-      printf("%s blocks/CU=%d  %8.3f ms  %8.2f Gmul/s\n", v==0?"lazy28":"sat32 ", w, ms, (double)b*256*iters/(ms*1e-3)*1e-9);
+using namespace arkhip;
+typedef BLS12_381_FQ P;
+template <int V> __global__ void __launch_bounds__(256) k_lazy(u32* out, int iters) {
+  typedef FpL<P> L;
+  L a, b;
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; i < L::L; i++) { a.l[i] = (tid * 2654435761u * (i + 1)) & L::MASK; b.l[i] = ((tid ^ 77) * 40503u * (i + 3)) & L::MASK; }
+  a.l[L::L - 1] &= 0xffff; b.l[L::L - 1] &= 0xffff;
+  for (int k = 0; k < iters; k++) {
+    if constexpr (V == 0) a = L::mul_chain1(a, b);
+    else if constexpr (V == 1) a = L::mul(a, b);
+    else if constexpr (V == 2) a = L::sqr(a);
+    else a = L::sop2(a, b, b, a);
+  }
+  u32 r = 0;
+  for (int i = 0; i < L::L; i++) r ^= a.l[i];
+  out[tid] = r;
+}
+__global__ void __launch_bounds__(256) k_sat(u32* out, int iters) {
+  typedef Fp<P> F;
+  F a, b;
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; i < F::N; i++) { a.l[i] = (tid * 2654435761u * (i + 1)); b.l[i] = ((tid ^ 77) * 40503u * (i + 3)); }
+  a.l[F::N - 1] &= 0xfffffff; b.l[F::N - 1] &= 0xfffffff;
+  for (int k = 0; k < iters; k++) a = F::mul(a, b);
+  u32 r = 0;
+  for (int i = 0; i < F::N; i++) r ^= a.l[i];
+  out[tid] = r;
+}
+int main() {
+  u32* out;
+  if (hipMalloc(&out, 256 * 8 * 256 * 4 * 4) != hipSuccess) return 1;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 2000;
+  const char* names[5] = {"lazy28 mul, one chain ", "lazy28 mul, two chains", "lazy28 sqr            ", "lazy28 sop2 (a b + c d)", "sat32  mul (fp.cuh)   "};
+  for (int w : {1, 2, 4, 8}) {
+    for (int v = 0; v < 5; v++) {
+      int b = 256 * w;
+      auto launch = [&](int it) {
+        switch (v) {
+          case 0: hipLaunchKernelGGL((k_lazy<0>), dim3(b), dim3(256), 0, 0, out, it); break;
+          case 1: hipLaunchKernelGGL((k_lazy<1>), dim3(b), dim3(256), 0, 0, out, it); break;
+          case 2: hipLaunchKernelGGL((k_lazy<2>), dim3(b), dim3(256), 0, 0, out, it); break;
+          case 3: hipLaunchKernelGGL((k_lazy<3>), dim3(b), dim3(256), 0, 0, out, it); break;
+          default: hipLaunchKernelGGL(k_sat, dim3(b), dim3(256), 0, 0, out, it);
+        }
+      };
+      launch(10);
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      launch(iters);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("%s waves/SIMD=%d  %8.3f ms  %8.2f G/s\n", names[v], w, ms, (double)b * 256 * iters / (ms * 1e-3) * 1e-9);
     }
   }
   return 0;

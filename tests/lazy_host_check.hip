@@ -51,6 +51,9 @@ template <class P> int run(const char* name, const uint64_t* gen) {
     L la = to_lazy<P>(a), lb = to_lazy<P>(b), lc = to_lazy<P>(c), ld = to_lazy<P>(d);
     if (!F::eq(lazy_value<P>(la), a)) { bad++; if (bad < 5) printf("%s roundtrip fail\n", name); }
     if (!F::eq(lazy_value<P>(L::mul(la, lb)), F::mul(a, b))) { bad++; if (bad < 5) printf("%s mul fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul_chain1(la, lb)), F::mul(a, b))) { bad++; if (bad < 5) printf("%s mul_chain1 fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::sqr(la)), F::mul(a, a))) { bad++; if (bad < 5) printf("%s sqr fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::sqr(L::template sub<6>(la, lb))), F::mul(F::sub(a, b), F::sub(a, b)))) { bad++; if (bad < 5) printf("%s sqr(sub<6>) fail\n", name); }
     if (!F::eq(lazy_value<P>(L::sop2(la, lb, lc, ld)), F::add(F::mul(a, b), F::mul(c, d)))) { bad++; if (bad < 5) printf("%s sop2 fail\n", name); }
     if (!F::eq(lazy_value<P>(L::template sub<1>(la, lb)), F::sub(a, b))) { bad++; if (bad < 5) printf("%s sub fail\n", name); }
     if (!F::eq(lazy_value<P>(L::template sub_b_2c<4>(la, lb, lc)), F::sub(F::sub(a, b), F::dbl(c)))) { bad++; if (bad < 5) printf("%s sub_b_2c fail\n", name); }
@@ -64,6 +67,17 @@ template <class P> int run(const char* name, const uint64_t* gen) {
       L h20 = la.template shr_mod<20>(), h16 = la.template shr_mod<16>().template shr_mod<4>();
       if (!F::eq(lazy_value<P>(h20), lazy_value<P>(h16))) { bad++; if (bad < 5) printf("%s shr_mod<20> fail\n", name); }
     }
+    // differences without a carry sweep (semi-normalised), as products' operands; the shifted repack
+    if (!F::eq(lazy_value<P>(L::mul(L::template sub_semi<2>(la, lb), L::template sub_semi<6>(lc, ld))), F::mul(F::sub(a, b), F::sub(c, d)))) { bad++; if (bad < 5) printf("%s sub_semi fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::sqr(L::template sub_semi<6>(la, lb))), F::sqr(F::sub(a, b)))) { bad++; if (bad < 5) printf("%s sqr(sub_semi) fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul(L::template neg_semi<2>(la), lb)), F::mul(F::neg(a), b))) { bad++; if (bad < 5) printf("%s neg_semi fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::template sub_b_2c_norm<4>(la, lb, lc)), F::sub(F::sub(a, b), F::dbl(c)))) { bad++; if (bad < 5) printf("%s sub_b_2c_norm fail\n", name); }
+    { L n = L::template sub_b_2c_norm<4>(la, lb, lc); for (int i = 0; i < L::L - 1; i++) if (n.l[i] > L::MASK) { bad++; printf("%s sub_b_2c_norm not normalised\n", name); break; } }
+    if (!F::eq(lazy_value<P>(L::sop2(L::template sub_semi<2>(la, lb), L::template sub_semi<6>(lc, ld), L::template neg_semi<2>(la), lb)),
+               F::sub(F::mul(F::sub(a, b), F::sub(c, d)), F::mul(a, b)))) { bad++; if (bad < 5) printf("%s sop2(semi) fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul(L::unpack32_shl(a.l), lb)), F::mul(a, b))) { /* a.l 2^8 = a R': the same residue, unreduced */ bad++; if (bad < 5) printf("%s unpack32_shl fail\n", name); }
+    if (!L::mul(L::template sub_semi<1>(la, la), lb).is_zero_or_p()) { bad++; printf("%s is_zero_or_p miss\n", name); }
+    if (L::mul(la, lb).is_zero_or_p() && !(F::eq(a, F::zero()) || F::eq(b, F::zero()))) { bad++; printf("%s is_zero_or_p false hit\n", name); }
     L z = L::template sub<3>(la, la);
     if (!z.is_zero_mod_p()) { bad++; printf("zero test fail\n"); }
     if (L::template sub<2>(la, lb).is_zero_mod_p() && !F::eq(a, b)) { bad++; printf("false zero\n"); }
@@ -90,19 +104,26 @@ template <class P> int run(const char* name, const uint64_t* gen) {
       int k = g() % NP;
       bool neg = g() & 1;
       F y = F::cond_neg(py[k], neg);
-      L lx, ly;
-      lazy_from_affine<P>(px[k], py[k], lx, ly);
-      xyzz_madd<F>(c, px[k], y);
-      xyzz_madd_lazy<P>(lz, lx, ly, neg);
-      if (trial % 3 == 0) {  // the same point again: the doubling branch
-        xyzz_madd<F>(c, px[k], y);
-        xyzz_madd_lazy<P>(lz, lx, ly, neg);
-      }
-      if (trial % 7 == 0) {  // then its inverse: cancels (possibly to infinity)
-        F ny = F::neg(y);
-        xyzz_madd<F>(c, px[k], ny);
-        xyzz_madd_lazy<P>(lz, lx, ly, !neg);
-      }
+      // what the kernel does with one sorted entry: sign onto the canonical y, repack, add; "equal points" comes back
+      // to the caller, which doubles the base re-read from memory (here: a two-coordinate buffer in the bases' layout)
+      auto add_entry = [&](bool ng) {
+        F yy = F::cond_neg(py[k], ng);
+        L lx, ly;
+        lazy_from_affine<P>(px[k], yy, lx, ly);
+        xyzz_madd<F>(c, px[k], yy);
+        if (xyzz_madd_lazy<P>(lz, lx, ly)) {
+          char raw[2 * F::BYTES];
+          px[k].store(raw);
+          py[k].store(raw + F::BYTES);
+          XYZZL<P> dbl;
+          xyzz_mdbl_lazy<P>(dbl, raw, ng);
+          lz = dbl;
+        }
+      };
+      (void)y;
+      add_entry(neg);
+      if (trial % 3 == 0) add_entry(neg);    // the same point again: the doubling branch
+      if (trial % 7 == 0) add_entry(!neg);   // then its inverse: cancels (possibly to infinity)
       if (trial % 4 == 1 && s == len / 2) {  // a streamed MSM's later piece: store the bucket, load it back, go on
         XYZZ<F> stored = lazy_to_bucket<P>(lz);  // what reaches HBM is canonical
         lz = lazy_from_bucket<P>(stored);
