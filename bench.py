@@ -45,7 +45,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # hardware-anchored multiply bound: v_mad_u64_u32 issues at 27.73e12 lane-ops/s on this chip
 # (profiles/r1_ubench_instruction_rates.txt, line 1); a Montgomery Fp384 product needs 2 * 12^2 = 288 of them
 MAD_U64_U32_PER_S = 27.73e12
-MADS_PER_MIXED_ADD = 8 * 288 + 432  # 8 products + one sum of two products under a single reduction (ec.cuh)
+# multiply-adds per mixed addition.  Saturated 32-bit limbs (ec.cuh): 8 products of 2 * 12^2 + one sum of two products
+# under a single reduction (3 * 12^2), each followed by a carry instruction.  Carry-free 28-bit limbs (ec28.cuh, the
+# default for the Fp384 G1 curves): 6 products of 2 * 14^2, 2 squares of 105 + 14^2, one two-product sum of 3 * 14^2.
+MADS_PER_MIXED_ADD = {"saturated": 8 * 288 + 432, "lazy28": 6 * 392 + 2 * 301 + 588}
+LAZY = not os.environ.get("ARK_HIP_MSM_LAZY", "1").startswith("0")   # the library's own switch (msm.cuh)
+ACC_KERNEL = "msm_accumulate_lazy_kernel" if LAZY else "msm_accumulate_kernel"
 LOG_PER_GPU = 24                    # pairs per GPU of the headline job (BASELINE config 2)
 LOG_CONFIG4 = 26                    # BASELINE config 4: one 2^26 MSM over all ranks
 limbs4 = S.limbs4
@@ -53,6 +58,26 @@ limbs4 = S.limbs4
 
 def gen_scalars(n, seed):
     return S.gen_scalars(n, seed, R_MOD)
+
+
+def usable_cores():
+    """Host cores this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs behind a 16-core quota; 256 threads on 16 cores' worth of time run 4x slower than 16:
+    profiles/r3_cpu_baseline_host_scaling.txt)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + per // 2) // per))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def pmc_traffic(kernel, log_n):
@@ -411,16 +436,17 @@ def main():
         if bases is None or bases.numel() < ns * ab:
             bases, scalars_h, scalars = make_inputs(ns, 0, 0xA11CE)
         hb = bases[: ns * ab].cpu().numpy().view(np.uint64).reshape(ns, -1)
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         t1 = time.perf_counter()
         ref = O.msm(O.CID[CURVE], hb, scalars_h[:ns], O.WNAF, cores)
         cpu_s = time.perf_counter() - t1
         same = bool(np.array_equal(O.to_affine(O.CID[CURVE], ref),
                                    A.into_affine(cid, A.msm_bigint(cid, bases[: ns * ab], scalars[:ns]))))
         cpu = {"value": ns / cpu_s, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
-               "sample": "%s 2^%d of the same bases/scalars, msm_bigint_wnaf restatement (oracle/), %.1f s; "
-                         "GPU result on the sample bit-exact: %s"
-                         % ("all" if ns == n else "first", int(np.log2(ns)), cpu_s, same)}
+               "sample": "%s 2^%d of the same bases/scalars, msm_bigint_wnaf restatement (oracle/), %.1f s on %d threads "
+                         "(%d logical CPUs visible, affinity / cgroup quota allow %d); GPU result on the sample "
+                         "bit-exact: %s"
+                         % ("all" if ns == n else "first", int(np.log2(ns)), cpu_s, cores, os.cpu_count() or 1, cores, same)}
 
     if rank == 0:
         acc_ms = float(phases[3])
@@ -432,8 +458,9 @@ def main():
         entries = n * W * (1.0 - 2.0 ** -cbits)
         nbuckets = W * (1 << (cbits - 1))
         madds = entries - nbuckets * (1.0 - np.exp(-entries / nbuckets))
-        mads_per_s = madds * MADS_PER_MIXED_ADD / (acc_ms * 1e-3)
-        traffic, traffic_src = pmc_traffic("msm_accumulate_kernel", log_local)
+        mads_per_add = MADS_PER_MIXED_ADD["lazy28" if LAZY else "saturated"]
+        mads_per_s = madds * mads_per_add / (acc_ms * 1e-3)
+        traffic, traffic_src = pmc_traffic(ACC_KERNEL, log_local)
         out = {
             "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (int(np.log2(n_total)), "" if world == 1 else " over %d GPUs" % world),
             "value": n_total * args.steps / elapsed,
@@ -449,19 +476,23 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BLS12-381 G1 MSM, one job of 2^%d random bases/scalars, device resident, plain entry "
                                    "(raw bases, nothing precomputed: VariableBaseMSM::msm_bigint)" % int(np.log2(n_total)),
-                       "arithmetic": "Montgomery Fp384 on 32-bit limbs (v_mad_u64_u32), exact integers",
+                       "arithmetic": "exact integers on v_mad_u64_u32: Montgomery Fp384, bucket accumulation on %s, "
+                                     "everything else on saturated 32-bit limbs" %
+                                     ("carry-free 28-bit limbs" if LAZY else "saturated 32-bit limbs"),
                        "curve": CURVE, "window_bits": cbits, "windows": W,
                        "pairs_per_gpu": n, "sharding": "base-range, %d rank(s), partials all-gathered" % world},
             "bit_exact_vs_kG": exact,
             "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
                           "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel",
+            "roofline": {"bound": "hbm", "kernel": ACC_KERNEL,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "alu": {"what": "v_mad_u64_u32 lane-ops/s issued by the mixed additions the accumulate kernel "
-                                         "executes (%d per addition: 8 Montgomery products + one two-product sum) vs the "
-                                         "instruction's measured issue rate on this chip" % MADS_PER_MIXED_ADD,
+                                         "executes (%d per addition, %s) vs the instruction's measured issue rate on "
+                                         "this chip" % (mads_per_add, "carry-free 28-bit limbs: 6 products, 2 squares, "
+                                                        "one two-product sum" if LAZY else
+                                                        "saturated 32-bit limbs: 8 products + one two-product sum"),
                                  "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
                                  "frac": mads_per_s / MAD_U64_U32_PER_S,
                                  "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32)"},
