@@ -65,6 +65,12 @@ extern "C" {
     pub fn ark_hip_host_free(ptr: *mut c_void) -> c_int;
     pub fn ark_hip_msm_sw(curve: c_int, bases: *const u64, scalars: *const u64, n: usize,
                           scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    /// VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64: n unsigned scalars of `scalar_bytes` (1, 2, 4, 8)
+    /// bytes with at most `max_bits` significant bits (0 = all); `&[bool]` is one byte per scalar, max_bits = 1.
+    pub fn ark_hip_msm_sw_small(curve: c_int, bases: *const u64, scalars: *const c_void, n: usize, scalar_bytes: c_int,
+                                max_bits: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_sw_small_device(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,
+                                       scalar_bytes: c_int, max_bits: c_int, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_msm_cache_config(budget_bytes: c_longlong, auto_prepare_after: c_int) -> c_int;
     pub fn ark_hip_msm_cache_clear() -> c_int;
     pub fn ark_hip_msm_cache_stats(out: *mut u64) -> c_int;

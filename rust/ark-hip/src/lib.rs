@@ -18,3 +18,5 @@ pub mod msm;
 pub use ark_hip_sys as sys;
 pub use ark_hip_sys::{BLS12_377_G1, BLS12_377_G2, BLS12_381_G1, BLS12_381_G2, BN254_G1};
 pub use msm::{sw_msm, sw_msm_bigint};
+#[cfg(feature = "ec-hook")]
+pub use msm::sw_msm_small;

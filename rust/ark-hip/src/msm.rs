@@ -2,7 +2,8 @@
 //!
 //! Reference surface replaced (ec/src/scalar_mul/variable_base/mod.rs:59-150, short_weierstrass/mod.rs:112-119,
 //! group.rs:650-657):  `msm` -> [`sw_msm`], `msm_bigint` (and through it `msm_unchecked`, `msm_chunks`,
-//! `ChunkedPippenger`, `HashMapPippenger`) -> [`sw_msm_bigint`].
+//! `ChunkedPippenger`, `HashMapPippenger`) -> [`sw_msm_bigint`], `msm_u1` / `msm_u8` / `msm_u16` / `msm_u32` / `msm_u64`
+//! -> [`sw_msm_small`].
 use ark_ec::short_weierstrass::{Affine, Projective, SWCurveConfig};
 use ark_ec::scalar_mul::variable_base::VariableBaseMSM;
 use ark_ff::PrimeField;
@@ -91,6 +92,37 @@ pub fn sw_msm<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalars: &[P:
 /// `VariableBaseMSM::msm_bigint` (variable_base/mod.rs:80-85): truncates to the shorter input like the reference.
 pub fn sw_msm_bigint<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Projective<P> {
     device_msm::<P, BigIntOf<P>>(curve, bases, bigints, false).unwrap_or_else(|| cpu_msm_bigint::<P>(bases, bigints))
+}
+
+/// `VariableBaseMSM::msm_u1` / `msm_u8` / `msm_u16` / `msm_u32` / `msm_u64` (variable_base/mod.rs:87-117) behind the
+/// `SWCurveConfig::msm_small` hook of patches/0001: the scalars cross the boundary as they are (1 / 2 / 4 / 8 bytes each,
+/// `bool` = one byte) and the device builds only the windows their bits reach; truncates to the shorter input like the
+/// reference's `preamble` (:349-369).  Any device or layout problem falls back to the reference's CPU bodies.
+#[cfg(feature = "ec-hook")]
+pub fn sw_msm_small<P: SWCurveConfig>(
+    curve: c_int,
+    bases: &[Affine<P>],
+    scalars: ark_ec::scalar_mul::variable_base::SmallScalars<'_>,
+) -> Projective<P> {
+    use ark_ec::scalar_mul::variable_base::SmallScalars as S;
+    let (ptr, len, bytes, bits): (*const c_void, usize, c_int, c_int) = match scalars {
+        S::U1(s) => (s.as_ptr() as *const c_void, s.len(), 1, 1), // bool: guaranteed 0x00 / 0x01, one byte
+        S::U8(s) => (s.as_ptr() as *const c_void, s.len(), 1, 0),
+        S::U16(s) => (s.as_ptr() as *const c_void, s.len(), 2, 0),
+        S::U32(s) => (s.as_ptr() as *const c_void, s.len(), 4, 0),
+        S::U64(s) => (s.as_ptr() as *const c_void, s.len(), 8, 0),
+    };
+    let n = bases.len().min(len);
+    if layout_ok::<P, BigIntOf<P>>(curve) {
+        let mut out = MaybeUninit::<Projective<P>>::uninit();
+        let rc = unsafe {
+            sys::ark_hip_msm_sw_small(curve, bases.as_ptr() as *const u64, ptr, n, bytes, bits, out.as_mut_ptr() as *mut u64)
+        };
+        if rc == 0 {
+            return unsafe { out.assume_init() };
+        }
+    }
+    ark_ec::scalar_mul::variable_base::msm_small_default(bases, scalars)
 }
 
 /// `VariableBaseMSM::msm_chunks` (variable_base/mod.rs:119-150) over slices: streams aligned at their end, steps of
@@ -287,7 +319,7 @@ impl<S: Copy> Drop for PinnedScalars<S> {
 /// (short_weierstrass/mod.rs:34-203: the three constants, `ZeroFlag`, `mul_by_a`, `add_b`, the subgroup check,
 /// cofactor clearing, both scalar multiplications, serialisation) is delegated, so points serialise in the upstream
 /// format and keep the upstream's endomorphism-based checks -- except that `msm` (and, with patches/0001,
-/// `msm_bigint`) run on the MI355X.  For unmodified arkworks; with patches/0002 the upstream configs do this
+/// `msm_bigint` and the narrow-scalar `msm_small`) run on the MI355X.  For unmodified arkworks; with patches/0002 the upstream configs do this
 /// themselves and `G1Projective` stays the same type.
 #[macro_export]
 macro_rules! hip_sw_config {
@@ -368,6 +400,12 @@ macro_rules! hip_sw_config {
                           bigints: &[<Self::ScalarField as ark_ff::PrimeField>::BigInt])
                           -> ark_ec::short_weierstrass::Projective<Self> {
                 $crate::msm::sw_msm_bigint::<Self>($id, bases, bigints)
+            }
+            #[cfg(feature = "ec-hook")]
+            fn msm_small(bases: &[ark_ec::short_weierstrass::Affine<Self>],
+                         scalars: ark_ec::scalar_mul::variable_base::SmallScalars<'_>)
+                         -> ark_ec::short_weierstrass::Projective<Self> {
+                $crate::msm::sw_msm_small::<Self>($id, bases, scalars)
             }
             #[inline]
             fn serialize_with_mode<W: ark_serialize::Write>(item: &ark_ec::short_weierstrass::Affine<Self>, writer: W,

@@ -137,3 +137,21 @@ def test_crates_target_the_reference_version():
         deps = re.findall(r'^(ark-(?:ff|ec|poly|serialize|std|bls12-381|bls12-377|bn254)) = \{ version = "([^"]+)"', toml, flags=re.M)
         assert deps, crate
         assert all(v == "0.6.0" for _, v in deps), (crate, deps)
+
+
+def test_narrow_scalar_entries_are_hooked():
+    """VariableBaseMSM::msm_u1 / u8 / u16 / u32 / u64 (variable_base/mod.rs:87-117) reach the device: patches/0001 routes
+    all five through ONE SWCurveConfig hook, the wrapper macro and patches/0002 override it, the shim hands the scalars
+    over unwidened (ark_hip_msm_sw_small)."""
+    p1 = open(os.path.join(ROOT, "patches", "0001-ark-ec-msm_bigint-hook.patch")).read()
+    assert "+    fn msm_small(" in p1 and "+pub enum SmallScalars<'a>" in p1 and "+pub fn msm_small_default" in p1
+    for k in ("u1", "u8", "u16", "u32", "u64"):
+        assert "+    fn msm_%s(bases: &[Self::MulBase]" % k in p1, k
+    p2 = open(os.path.join(ROOT, "patches", "0002-curves-hip-feature.patch")).read()
+    assert p2.count("ark_hip::sw_msm_small::<Self>") == 5          # five curve groups
+    assert "prime-order" in p2                                       # the device path's precondition is stated (ADVICE r2)
+    msm_rs = open(os.path.join(ROOT, "rust", "ark-hip", "src", "msm.rs")).read()
+    assert "pub fn sw_msm_small<" in msm_rs and "sys::ark_hip_msm_sw_small(" in msm_rs
+    assert "fn msm_small(" in msm_rs[msm_rs.index("macro_rules! hip_sw_config"):]
+    # the five (bytes, max_bits) pairs of the shim are the ones the library documents
+    assert re.search(r"S::U1\(s\) => \(.*, 1, 1\)", msm_rs) and re.search(r"S::U64\(s\) => \(.*, 8, 0\)", msm_rs)
