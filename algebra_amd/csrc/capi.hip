@@ -1,6 +1,8 @@
 // C ABI of libark_hip.so (see include/ark_hip.h for the contract and the reference items replaced).
 #include "../../include/ark_hip.h"
 #include <string.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and signatures only: the library is opened at run time (RcclApi)
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -181,6 +183,7 @@ struct BaseCacheStats { uint64_t hits = 0, misses = 0, refreshed = 0, evicted = 
 // current device (ark_hip_set_device / ark_hip_init; default: the first device initialised) and holds that
 // context's lock for its whole body, so the library can be called from any number of host threads (rayon workers,
 // Python threads): calls on one device serialise, calls on different devices run concurrently.
+constexpr int COMM_MAX_SLICES = 16;
 struct Context {
   int logical = -1, physical = -1;
   hipStream_t stream = nullptr;        // compute
@@ -208,6 +211,13 @@ struct Context {
   uint64_t cache_clock = 0;
   long long cache_budget = -1;         // bytes; -1: not configured yet (env / default on first use); 0: disabled
   int auto_prepare = -1;               // hits after which a cached base set is prepared; 0: never; -1: env / default
+  // one process per GPU: this device's RCCL communicator (ark_hip_comm_init) and what its exchanges need
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  hipStream_t comm_stream = nullptr;   // exchange slices travel here while the compute stream works on the previous slice
+  hipEvent_t comm_ev[2][COMM_MAX_SLICES] = {};
+  DevBuf comm_tmp, comm_small;         // receive side of the FFT exchange; MSM partials
+  void* comm_pinned = nullptr;         // host mirror of comm_small
   bool msm_timing = false, fft_timing = false;
   MsmTimings msm_tm;
   FftTimings fft_tm;
@@ -362,8 +372,20 @@ int fr_mul_dispatch(int field, const void* a, const void* b, void* r, size_t n, 
   ARK_FIELD_SWITCH(field, X);
 #undef X
 }
-int fft_axis_dispatch(int field, FftWorkspace& ws, void* d, unsigned G, size_t cols, const uint64_t* root, hipStream_t st) {
-#define X(NAME) fft_axis_##NAME(ws, d, G, cols, root, st)
+int fft_axis_dispatch(int field, FftWorkspace& ws, const void* src, void* dst, unsigned G, size_t cols, const uint64_t* root,
+                      hipStream_t st) {
+#define X(NAME) fft_axis_##NAME(ws, src, dst, G, cols, root, st)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+int fft_axis_prepare_dispatch(int field, FftWorkspace& ws, unsigned G, const uint64_t* root, hipStream_t st, const uint32_t** pw) {
+#define X(NAME) fft_axis_prepare_##NAME(ws, G, root, st, pw)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+int fft_axis_launch_dispatch(int field, const void* src, void* dst, unsigned G, size_t stride, size_t cols, const uint32_t* pw,
+                             hipStream_t st) {
+#define X(NAME) fft_axis_launch_##NAME(src, dst, G, stride, cols, pw, st)
   ARK_FIELD_SWITCH(field, X);
 #undef X
 }
@@ -884,6 +906,200 @@ size_t msm_stream_step(size_t n) {
   return (n + pieces - 1) / pieces;
 }
 
+
+// ---- RCCL, opened at run time ------------------------------------------------------------------------------
+// librccl.so.1 by SONAME: a process that already carries a copy (PyTorch ships its own) gets that one, so two RCCL
+// instances never meet in one process; otherwise the ROCm installation's.  ARK_HIP_RCCL_LIB overrides.
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool tried = false;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+const RcclApi* rccl_api() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.tried) return g_rccl.handle ? &g_rccl : nullptr;
+  g_rccl.tried = true;
+  const char* names[4] = {getenv("ARK_HIP_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  void* h = nullptr;
+  for (const char* nm : names) {
+    if (!nm || !*nm) continue;
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    fprintf(stderr, "ark_hip: RCCL not found (librccl.so.1): %s\n", dlerror());
+    return nullptr;
+  }
+  RcclApi a;
+  a.handle = h;
+#define ARK_RCCL_SYM(field, name)                                  \
+  a.field = (decltype(a.field))dlsym(h, name);                     \
+  if (!a.field) {                                                  \
+    fprintf(stderr, "ark_hip: %s missing from RCCL\n", name);      \
+    return nullptr;                                                \
+  }
+  ARK_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+  ARK_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+  ARK_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+  ARK_RCCL_SYM(AllGather, "ncclAllGather")
+  ARK_RCCL_SYM(Send, "ncclSend")
+  ARK_RCCL_SYM(Recv, "ncclRecv")
+  ARK_RCCL_SYM(GroupStart, "ncclGroupStart")
+  ARK_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+  ARK_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef ARK_RCCL_SYM
+  a.tried = true;
+  g_rccl = a;
+  return &g_rccl;
+}
+#define ARK_RCCL_TRY(api, expr)                                                                         \
+  do {                                                                                                  \
+    ncclResult_t _r = (expr);                                                                           \
+    if (_r != ncclSuccess) {                                                                            \
+      fprintf(stderr, "ark_hip: %s failed: %s (%s:%d)\n", #expr, (api)->GetErrorString(_r), __FILE__, __LINE__); \
+      return ARK_HIP_ERR_COMM;                                                                          \
+    }                                                                                                   \
+  } while (0)
+
+// all-gather of one Projective per rank, summed in rank order: the same group element on every rank
+int msm_sharded_combine(Context* c, int curve, const uint64_t* part, uint64_t* out_xyz) {
+  const size_t pw = (size_t)CURVES[curve].fe_words * 3;
+  if (!c->comm || c->comm_world == 1) {
+    memcpy(out_xyz, part, pw * 8);
+    return 0;
+  }
+  const RcclApi* api = rccl_api();
+  if (!api) return ARK_HIP_ERR_COMM;
+  const size_t G = (size_t)c->comm_world;
+  if (c->comm_small.ensure((G + 1) * 36 * 8)) return ARK_HIP_ERR_NOMEM;
+  if (!c->comm_pinned) ARK_HIP_TRY(hipHostMalloc(&c->comm_pinned, (size_t)(64 + 1) * 36 * 8));
+  if (G > 64) return ARK_HIP_ERR_ARG;
+  uint64_t* hp = (uint64_t*)c->comm_pinned;
+  uint64_t* dsend = (uint64_t*)c->comm_small.p;
+  uint64_t* dall = dsend + 36;
+  memcpy(hp, part, pw * 8);
+  ARK_HIP_TRY(hipMemcpyAsync(dsend, hp, pw * 8, hipMemcpyHostToDevice, c->stream));
+  ARK_RCCL_TRY(api, api->AllGather(dsend, dall, pw, ncclUint64, c->comm, c->stream));
+  ARK_HIP_TRY(hipMemcpyAsync(hp + 36, dall, G * pw * 8, hipMemcpyDeviceToHost, c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ark_hip_sw_sum(curve, hp + 36, G, out_xyz);
+}
+
+// ---- sharded FFT: constants of one rank's local transform and of the cross transform -------------------------
+struct ShardConsts {
+  int km = 0;                 // log2 of the local size m
+  unsigned G = 1;
+  size_t m = 0, sub = 0;
+  uint64_t root_m[4], root_G[4], pre[4], post[4], postc[4];
+  bool has_pre = false, has_post = false, has_postc = false;
+};
+template <class FP>
+int shard_consts(const ark_hip_radix2_domain* dom, int rank, int world, int inverse, ShardConsts* o) {
+  typedef Fp<FP> F;
+  const int k = (int)dom->log_size_of_group;
+  if (dom->size != ((uint64_t)1 << k) || k > FP::TWO_ADICITY) return ARK_HIP_ERR_ARG;
+  if (world < 1 || world > 16 || (world & (world - 1)) || rank < 0 || rank >= world) return ARK_HIP_ERR_ARG;
+  int lg = 0;
+  while ((1 << lg) < world) lg++;
+  if (2 * lg > k) return ARK_HIP_ERR_SIZE;   // G^2 must divide the size
+  o->G = (unsigned)world;
+  o->km = k - lg;
+  o->m = (size_t)1 << o->km;
+  o->sub = o->m >> lg;
+  const bool coset = !host_is_one<FP>(dom->offset);
+  const F w = F::load(inverse ? dom->group_gen_inv : dom->group_gen);
+  const uint64_t eG[1] = {(uint64_t)world}, em[1] = {(uint64_t)o->m}, er[1] = {(uint64_t)rank};
+  host_pow<FP>(w, eG, 1).store(o->root_m);    // generator of the size-m subgroup (or its inverse)
+  host_pow<FP>(w, em, 1).store(o->root_G);    // primitive G-th root (or its inverse)
+  const F tw = host_pow<FP>(w, er, 1);        // the rank's twiddle base: w_n^(+-rank)
+  if (!inverse) {
+    // local transform over i2 of x[rank + G i2] * g^(rank + G i2), then out[j2] *= w_n^(rank j2)
+    if (coset) {
+      const F g = F::load(dom->offset);
+      host_pow<FP>(g, eG, 1).store(o->pre);
+      o->has_pre = true;
+      host_pow<FP>(g, er, 1).store(o->postc);
+      o->has_postc = rank != 0;
+    }
+    tw.store(o->post);
+    o->has_post = rank != 0;
+    if (o->has_postc && !o->has_post) {  // (unreachable: both hinge on rank != 0) keep the pair consistent for fft_run_device
+      F::one().store(o->post);
+      o->has_post = true;
+    }
+  } else {
+    // in[j2] *= w_n^(-rank j2), inverse transform over j2, then out[i2] *= n^-1 * g^-(rank + G i2)
+    tw.store(o->pre);
+    o->has_pre = rank != 0;
+    F sc = F::load(dom->size_inv);
+    if (coset) {
+      const F gi = F::load(dom->offset_inv);
+      host_pow<FP>(gi, eG, 1).store(o->post);
+      o->has_post = true;
+      sc = F::mul(sc, host_pow<FP>(gi, er, 1));
+    }
+    sc.store(o->postc);
+    o->has_postc = true;
+  }
+  return 0;
+}
+int shard_consts_any(int field, const ark_hip_radix2_domain* dom, int rank, int world, int inverse, ShardConsts* o) {
+  switch (field) {
+#ifndef ARK_HIP_DEV
+    case ARK_HIP_BN254_FR: return shard_consts<BN254_FR>(dom, rank, world, inverse, o);
+    case ARK_HIP_BLS12_377_FR: return shard_consts<BLS12_377_FR>(dom, rank, world, inverse, o);
+#endif
+    case ARK_HIP_BLS12_381_FR: return shard_consts<BLS12_381_FR>(dom, rank, world, inverse, o);
+  }
+  return ARK_HIP_ERR_ARG;
+}
+// the size-m transform of one rank, twiddle and scalings fused into its first / last pass
+int shard_local(Context* c, int field, const ShardConsts& sc, void* d_local, hipStream_t st) {
+  return fft_dispatch(field, c->fft, d_local, sc.km, sc.root_m, sc.has_pre ? sc.pre : nullptr, sc.has_post ? sc.post : nullptr,
+                      sc.has_postc ? sc.postc : nullptr, 0, st, nullptr);
+}
+int comm_streams(Context* c) {
+  if (!c->comm_stream) ARK_HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  for (int a = 0; a < 2; a++)
+    for (int i = 0; i < COMM_MAX_SLICES; i++)
+      if (!c->comm_ev[a][i]) ARK_HIP_TRY(hipEventCreateWithFlags(&c->comm_ev[a][i], hipEventDisableTiming));
+  return 0;
+}
+// one slice of the all-to-all: columns [c0, c0 + cs) of block q go to rank q / come from rank q
+int exchange_slice(Context* c, const RcclApi* api, const char* send, char* recv, size_t sub, size_t c0, size_t cs, hipStream_t st) {
+  const int G = c->comm_world, me = c->comm_rank;
+  ARK_RCCL_TRY(api, api->GroupStart());
+  for (int q = 0; q < G; q++) {
+    const size_t off = ((size_t)q * sub + c0) * 32;
+    if (q == me) continue;
+    ARK_RCCL_TRY(api, api->Send(send + off, cs * 32, ncclUint8, q, c->comm, st));
+    ARK_RCCL_TRY(api, api->Recv(recv + off, cs * 32, ncclUint8, q, c->comm, st));
+  }
+  ARK_RCCL_TRY(api, api->GroupEnd());
+  const size_t off = ((size_t)me * sub + c0) * 32;   // own block: a device copy
+  ARK_HIP_TRY(hipMemcpyAsync(recv + off, send + off, cs * 32, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+int comm_slices(size_t sub) {
+  int s = sub >= ((size_t)1 << 15) ? 4 : 1;   // slices of >= 256 KiB per peer
+  if (const char* e = getenv("ARK_HIP_COMM_SLICES")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= COMM_MAX_SLICES) s = v;
+  }
+  while (s > 1 && (sub % (size_t)s)) s >>= 1;
+  return s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1396,6 +1612,40 @@ int ark_hip_msm_sw_multi(int curve, int n_gpus, const uint64_t* bases, const uin
   return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);
 }
 
+// The same split over PREPARED shards (a fixed SRS, one prepared base set per GPU): one host thread per device, each
+// through the pinned-ring upload of the prepared entry; the shard sizes cut the scalar vector in order.
+int ark_hip_msm_prepared_multi(int n_gpus, const ark_hip_msm_bases* const* shards, const uint64_t* scalars, size_t n, int mont,
+                               uint64_t* out_xyz) {
+  if (n_gpus < 1 || n_gpus > MAX_DEV || !shards || !out_xyz || (n && !scalars)) return ARK_HIP_ERR_ARG;
+  size_t total = 0;
+  for (int g = 0; g < n_gpus; g++) {
+    if (!shards[g]) return ARK_HIP_ERR_ARG;
+    const PreparedBases* pb = (const PreparedBases*)shards[g];
+    if (pb->curve != ((const PreparedBases*)shards[0])->curve) return ARK_HIP_ERR_ARG;
+    total += pb->n;
+  }
+  if (n > total) return ARK_HIP_ERR_ARG;   // like msm_unchecked: the scalars may be fewer than the bases, never more
+  const int curve = ((const PreparedBases*)shards[0])->curve;
+  const size_t pw = (size_t)CURVES[curve].fe_words * 3;
+  std::vector<uint64_t> partials((size_t)n_gpus * pw);
+  std::vector<int> rcs((size_t)n_gpus, 0);
+  std::vector<std::thread> th;
+  size_t lo = 0;
+  for (int g = 0; g < n_gpus; g++) {
+    const PreparedBases* pb = (const PreparedBases*)shards[g];
+    const size_t cnt = lo >= n ? 0 : (n - lo < pb->n ? n - lo : pb->n);
+    const uint64_t* sc = scalars + lo * 4;
+    th.emplace_back([&, g, cnt, sc]() {
+      rcs[(size_t)g] = ark_hip_msm_prepared(shards[g], sc, cnt, mont, &partials[(size_t)g * pw]);  // runs on the shard's device
+    });
+    lo += pb->n;
+  }
+  for (auto& t : th) t.join();
+  for (int g = 0; g < n_gpus; g++)
+    if (rcs[(size_t)g]) return rcs[(size_t)g];
+  return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);
+}
+
 // ---- fixed-base batch multiplication (ScalarMul::batch_mul / BatchMulPreprocessing, ec/src/scalar_mul/mod.rs:104-251) ----
 int ark_hip_batch_mul_table_new(int curve, const uint64_t* base_xyz, size_t num_scalars, ark_hip_batch_mul_table** out) {
   (void)num_scalars;  // the reference sizes its window from it (:222-228); the device table has a fixed geometry
@@ -1595,7 +1845,7 @@ int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out)
 int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, const uint64_t* root) {
   if (!d_data || !root) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
-  if (int rc = fft_axis_dispatch(field, sc.c->fft, d_data, G, cols, root, sc.c->stream)) return rc;
+  if (int rc = fft_axis_dispatch(field, sc.c->fft, d_data, d_data, G, cols, root, sc.c->stream)) return rc;
   return mark_producer(sc.c);
 }
 
@@ -1611,6 +1861,144 @@ int ark_hip_fft_last_timing(double out[10]) {
   out[1] = sc.c->fft_tm.npass;
   for (int i = 0; i < 8; i++) out[2 + i] = sc.c->fft_tm.pass[i];
   return 0;
+}
+
+// ---- one process per GPU: RCCL inside the library ----------------------------------------------------------
+int ark_hip_comm_unique_id(void* out_id) {
+  if (!out_id) return ARK_HIP_ERR_ARG;
+  const RcclApi* api = rccl_api();
+  if (!api) return ARK_HIP_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) == ARK_HIP_COMM_ID_BYTES, "ARK_HIP_COMM_ID_BYTES");
+  ncclUniqueId id;
+  ARK_RCCL_TRY(api, api->GetUniqueId(&id));
+  memcpy(out_id, &id, sizeof(id));
+  return 0;
+}
+int ark_hip_comm_init(const void* id, int rank, int world) {
+  if (!id || world < 1 || rank < 0 || rank >= world) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  if (c->comm) return ARK_HIP_ERR_BUSY;   // one communicator per device: destroy first
+  const RcclApi* api = rccl_api();
+  if (!api) return ARK_HIP_ERR_COMM;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm = nullptr;
+  ARK_RCCL_TRY(api, api->CommInitRank(&comm, world, uid, rank));
+  c->comm = comm;
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return comm_streams(c);
+}
+int ark_hip_comm_info(int* rank, int* world) {
+  ARK_SCOPE(sc);
+  if (rank) *rank = sc.c->comm ? sc.c->comm_rank : 0;
+  if (world) *world = sc.c->comm ? sc.c->comm_world : 1;
+  return 0;
+}
+int ark_hip_comm_destroy(void) {
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  if (!c->comm) return 0;
+  if (int rc = sync_compute(c)) return rc;
+  if (c->comm_stream) ARK_HIP_TRY(hipStreamSynchronize(c->comm_stream));
+  const RcclApi* api = rccl_api();
+  if (!api) return ARK_HIP_ERR_COMM;
+  ARK_RCCL_TRY(api, api->CommDestroy(c->comm));
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  return 0;
+}
+
+int ark_hip_msm_sw_device_sharded(int curve, const void* d_bases, const void* d_scalars, size_t n_local, int mont,
+                                  uint64_t* out_xyz) {
+  if (curve < 0 || curve > 4 || !out_xyz || (n_local && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  uint64_t part[36];
+  int slot = msm_enqueue_ctx(sc.c, curve, d_bases, 0, nullptr, d_scalars, n_local, mont);
+  if (slot < 0) return slot;
+  if (int rc = msm_finish_ctx(sc.c, curve, slot, part)) return rc;   // every rank reaches the collective or none: a
+  return msm_sharded_combine(sc.c, curve, part, out_xyz);            // local failure is the caller's to broadcast
+}
+int ark_hip_msm_prepared_device_sharded(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n_local, int mont,
+                                        uint64_t* out_xyz) {
+  if (!bases || !out_xyz) return ARK_HIP_ERR_ARG;
+  const PreparedBases* pb = (const PreparedBases*)bases;
+  uint64_t part[36];
+  if (int rc = ark_hip_msm_prepared_device(bases, d_scalars, n_local, mont, part)) return rc;
+  Scope sc;
+  if (int rc = sc.enter(pb->logical)) return rc;
+  return msm_sharded_combine(sc.c, pb->curve, part, out_xyz);
+}
+
+int ark_hip_fft_shard_local_device(int field, const ark_hip_radix2_domain* dom, int rank, int world, void* d_local,
+                                   int inverse) {
+  if (!dom || !d_local) return ARK_HIP_ERR_ARG;
+  ShardConsts k;
+  if (int rc = shard_consts_any(field, dom, rank, world, inverse, &k)) return rc;
+  ARK_SCOPE(sc);
+  if (int rc = shard_local(sc.c, field, k, d_local, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+int ark_hip_fft_shard_cross_device(int field, const ark_hip_radix2_domain* dom, int world, const void* d_src, void* d_dst,
+                                   int inverse) {
+  if (!dom || !d_src || !d_dst) return ARK_HIP_ERR_ARG;
+  ShardConsts k;
+  if (int rc = shard_consts_any(field, dom, 0, world, inverse, &k)) return rc;
+  ARK_SCOPE(sc);
+  if (int rc = fft_axis_dispatch(field, sc.c->fft, d_src, d_dst, k.G, k.sub, k.root_G, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+int ark_hip_fft_sharded_device(int field, const ark_hip_radix2_domain* dom, void* d_local, int inverse) {
+  if (!dom || !d_local) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  if (!c->comm || c->comm_world == 1) {   // no communicator: the single-GPU transform
+    if (int rc = fft_any(c, field, dom, d_local, inverse, 0)) return rc;
+    return mark_producer(c);
+  }
+  const RcclApi* api = rccl_api();
+  if (!api) return ARK_HIP_ERR_COMM;
+  ShardConsts k;
+  if (int rc = shard_consts_any(field, dom, c->comm_rank, c->comm_world, inverse, &k)) return rc;
+  if (int rc = comm_streams(c)) return rc;
+  if (c->comm_tmp.cap < k.m * 32) {
+    if (int rc = sync_compute(c)) return rc;
+    ARK_HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    if (c->comm_tmp.ensure(k.m * 32)) return ARK_HIP_ERR_NOMEM;
+  }
+  char* loc = (char*)d_local;
+  char* tmp = (char*)c->comm_tmp.p;
+  const int S = comm_slices(k.sub);
+  const size_t cs = k.sub / (size_t)S;
+  const uint32_t* pw = nullptr;
+  if (int rc = fft_axis_prepare_dispatch(field, c->fft, k.G, k.root_G, c->stream, &pw)) return rc;
+  if (!inverse) {
+    if (int rc = shard_local(c, field, k, d_local, c->stream)) return rc;
+    ARK_HIP_TRY(hipEventRecord(c->comm_ev[0][0], c->stream));
+    ARK_HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->comm_ev[0][0], 0));
+    for (int i = 0; i < S; i++) {   // slice i+1 travels while the G-point kernel works on slice i
+      if (int rc = exchange_slice(c, api, loc, tmp, k.sub, (size_t)i * cs, cs, c->comm_stream)) return rc;
+      ARK_HIP_TRY(hipEventRecord(c->comm_ev[1][i], c->comm_stream));
+      ARK_HIP_TRY(hipStreamWaitEvent(c->stream, c->comm_ev[1][i], 0));
+      if (int rc = fft_axis_launch_dispatch(field, tmp + (size_t)i * cs * 32, loc + (size_t)i * cs * 32, k.G, k.sub, cs, pw, c->stream))
+        return rc;
+    }
+  } else {
+    for (int i = 0; i < S; i++) {   // the exchange of slice i travels while the G-point kernel works on slice i+1
+      if (int rc = fft_axis_launch_dispatch(field, loc + (size_t)i * cs * 32, tmp + (size_t)i * cs * 32, k.G, k.sub, cs, pw, c->stream))
+        return rc;
+      ARK_HIP_TRY(hipEventRecord(c->comm_ev[0][i], c->stream));
+      ARK_HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->comm_ev[0][i], 0));
+      if (int rc = exchange_slice(c, api, tmp, loc, k.sub, (size_t)i * cs, cs, c->comm_stream)) return rc;
+    }
+    ARK_HIP_TRY(hipEventRecord(c->comm_ev[1][0], c->comm_stream));
+    ARK_HIP_TRY(hipStreamWaitEvent(c->stream, c->comm_ev[1][0], 0));
+    if (int rc = shard_local(c, field, k, d_local, c->stream)) return rc;
+  }
+  ARK_HIP_TRY(hipGetLastError());
+  return mark_producer(c);
 }
 
 // ---- host-side group helpers (no device involved) ----

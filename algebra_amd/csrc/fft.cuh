@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <map>
+#include <string.h>
 #include <array>
 #include <mutex>
 #include "msm.cuh"  // DevBuf, ARK_HIP_TRY
@@ -366,13 +367,16 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
 // values travel through registers (radix-2 decimation in frequency, then a bit-reversed write-back).
 // `pw` holds root^k for k < G/2.
 template <class FP, int G>
-__global__ void __launch_bounds__(256) fft_axis_kernel(u32* __restrict__ data, size_t cols, const u32* __restrict__ pw) {
+__global__ void __launch_bounds__(256) fft_axis_kernel(const u32* src, u32* dst, size_t stride, size_t cols,
+                                                       const u32* __restrict__ pw) {
+  // rows are `stride` elements apart (>= cols: a column slice of a wider array); src may equal dst -- a lane reads its
+  // whole column before it writes
   typedef Fp<FP> F;
   size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   F v[G];
 #pragma unroll
-  for (int i = 0; i < G; i++) v[i] = F::load(data + ((size_t)i * cols + c) * F::N);
+  for (int i = 0; i < G; i++) v[i] = F::load(src + ((size_t)i * stride + c) * F::N);
 #pragma unroll
   for (int gap = G / 2; gap >= 1; gap >>= 1) {
 #pragma unroll
@@ -394,7 +398,7 @@ __global__ void __launch_bounds__(256) fft_axis_kernel(u32* __restrict__ data, s
     int r = 0;
 #pragma unroll
     for (int b = 0; b < LG; b++) r |= ((i >> b) & 1) << (LG - 1 - b);
-    v[i].store(data + ((size_t)r * cols + c) * F::N);  // position i holds X[bitrev(i)]
+    v[i].store(dst + ((size_t)r * stride + c) * F::N);  // position i holds X[bitrev(i)]
   }
 }
 
@@ -430,6 +434,8 @@ struct FftWorkspace {
   std::map<FftPwKey, DevBuf> powers;   // per (field, log n, offset[, constant]): [lo (1024) | hi (n >> 10)]
   std::map<hipStream_t, DevBuf> tmps;  // ping buffer of the multi-pass transform, one per stream (transforms in flight)
   DevBuf pw;                           // coset power tables + constants
+  DevBuf axis_pw;                      // G-point cross transform: root and its first G/2 powers
+  uint64_t axis_root[4] = {0, 0, 0, 0};
   DevBuf stage;                        // host-pointer entry: device copy of the data
   hipEvent_t ev[10] = {};              // pass timing (created on first use, reused)
   std::mutex mu;
@@ -440,32 +446,59 @@ struct FftWorkspace {
     powers.clear();
     for (auto& kv : tmps) kv.second.release();
     tmps.clear();
-    pw.release(); stage.release();
+    pw.release(); stage.release(); axis_pw.release();
     for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   }
 };
 struct FftTimings { float total = 0; float pass[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int npass = 0; };
 
+// root^k, k < G/2, for fft_axis_launch: built into the workspace's own small buffer (stream-ordered; `root4` is host
+// memory and is consumed before the call returns only if the caller synchronises -- pass memory that outlives the stream
+// work, e.g. a field of the domain struct copied into the workspace, as fft_axis_prepare does)
 template <class FP>
-int fft_axis_run(FftWorkspace& ws, void* d_data, unsigned G, size_t cols, const uint64_t* root4, hipStream_t stream) {
+int fft_axis_prepare(FftWorkspace& ws, unsigned G, const uint64_t* root4, hipStream_t stream, const u32** out_pw) {
   typedef Fp<FP> F;
-  std::lock_guard<std::mutex> lock(ws.mu);
-  if (G == 1 || cols == 0) return 0;
   if (G != 2 && G != 4 && G != 8 && G != 16) return -2;
-  if (ws.pw.ensure((2 * (((size_t)1 << PW_LO_BITS) + 1) + 3 + 16) * F::BYTES)) return -3;
-  u32* d_root = (u32*)ws.pw.p;
+  if (ws.axis_pw.ensure((1 + 16) * F::BYTES)) return -3;
+  u32* d_root = (u32*)ws.axis_pw.p;
   u32* d_pw = d_root + F::N;
-  ARK_HIP_TRY(hipMemcpyAsync(d_root, root4, F::BYTES, hipMemcpyHostToDevice, stream));
+  memcpy(ws.axis_root, root4, 32);  // stable host copy for the asynchronous upload
+  ARK_HIP_TRY(hipMemcpyAsync(d_root, ws.axis_root, F::BYTES, hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3(1), dim3(256), 0, stream, d_root, (u64)1, (u32)(G / 2),
                      (const u32*)nullptr, d_pw);
+  *out_pw = d_pw;
+  return 0;
+}
+template <class FP>
+int fft_axis_launch(const void* d_src, void* d_dst, unsigned G, size_t stride, size_t cols, const u32* d_pw,
+                    hipStream_t stream) {
+  if (cols == 0) return 0;
   const unsigned blocks = (unsigned)((cols + 255) / 256);
+  const u32* s = (const u32*)d_src;
+  u32* d = (u32*)d_dst;
   switch (G) {
-    case 2: hipLaunchKernelGGL((fft_axis_kernel<FP, 2>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
-    case 4: hipLaunchKernelGGL((fft_axis_kernel<FP, 4>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
-    case 8: hipLaunchKernelGGL((fft_axis_kernel<FP, 8>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
-    default: hipLaunchKernelGGL((fft_axis_kernel<FP, 16>), dim3(blocks), dim3(256), 0, stream, (u32*)d_data, cols, d_pw); break;
+    case 2: hipLaunchKernelGGL((fft_axis_kernel<FP, 2>), dim3(blocks), dim3(256), 0, stream, s, d, stride, cols, d_pw); break;
+    case 4: hipLaunchKernelGGL((fft_axis_kernel<FP, 4>), dim3(blocks), dim3(256), 0, stream, s, d, stride, cols, d_pw); break;
+    case 8: hipLaunchKernelGGL((fft_axis_kernel<FP, 8>), dim3(blocks), dim3(256), 0, stream, s, d, stride, cols, d_pw); break;
+    case 16: hipLaunchKernelGGL((fft_axis_kernel<FP, 16>), dim3(blocks), dim3(256), 0, stream, s, d, stride, cols, d_pw); break;
+    default: return -2;
   }
-  ARK_HIP_TRY(hipStreamSynchronize(stream));  // root4 is caller memory; pw is shared scratch
+  return 0;
+}
+// the whole [G][cols] array at once (d_src -> d_dst, may alias); `pw_stream`: the stream the table is built on (the
+// launch follows on `stream` behind `after_table`, which is recorded here when the two differ)
+template <class FP>
+int fft_axis_run(FftWorkspace& ws, const void* d_src, void* d_dst, unsigned G, size_t cols, const uint64_t* root4,
+                 hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(ws.mu);
+  if (G == 1 || cols == 0) {
+    if (d_src != d_dst && cols) ARK_HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)G * cols * Fp<FP>::BYTES, hipMemcpyDeviceToDevice, stream));
+    return 0;
+  }
+  const u32* d_pw = nullptr;
+  if (int rc = fft_axis_prepare<FP>(ws, G, root4, stream, &d_pw)) return rc;
+  if (int rc = fft_axis_launch<FP>(d_src, d_dst, G, cols, cols, d_pw, stream)) return rc;
+  ARK_HIP_TRY(hipGetLastError());
   return 0;
 }
 

@@ -10,7 +10,14 @@ int fft_run_BLS12_377_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* 
 int test_field_op_BLS12_377_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<Fp<BLS12_377_FR>, true>(op, a, b, r, n, s);
 }
-int fft_axis_BLS12_377_FR(FftWorkspace& ws, void* d_data, unsigned G, size_t cols, const uint64_t* root4, hipStream_t s) {
-  return fft_axis_run<BLS12_377_FR>(ws, d_data, G, cols, root4, s);
+int fft_axis_BLS12_377_FR(FftWorkspace& ws, const void* d_src, void* d_dst, unsigned G, size_t cols, const uint64_t* root4, hipStream_t s) {
+  return fft_axis_run<BLS12_377_FR>(ws, d_src, d_dst, G, cols, root4, s);
+}
+int fft_axis_prepare_BLS12_377_FR(FftWorkspace& ws, unsigned G, const uint64_t* root4, hipStream_t s, const uint32_t** pw) {
+  std::lock_guard<std::mutex> lock(ws.mu);
+  return fft_axis_prepare<BLS12_377_FR>(ws, G, root4, s, pw);
+}
+int fft_axis_launch_BLS12_377_FR(const void* d_src, void* d_dst, unsigned G, size_t stride, size_t cols, const uint32_t* pw, hipStream_t s) {
+  return fft_axis_launch<BLS12_377_FR>(d_src, d_dst, G, stride, cols, pw, s);
 }
 }  // namespace arkhip

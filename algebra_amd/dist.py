@@ -1,4 +1,5 @@
-"""Multi-GPU MSM: one process per GPU, base-range sharding, RCCL all-gather of the per-rank partials.
+"""Multi-GPU MSM and FFT: one process per GPU; the exchanges run on RCCL inside libark_hip.so (comm_init) or, without
+it, on torch.distributed.
 
 The reference itself splits an MSM by base range and sums the chunk results
 (ec/src/scalar_mul/variable_base/mod.rs:521-557); across GPUs the same split needs exactly one exchange:
@@ -36,43 +37,110 @@ def combine_partials(curve, partial, group=None):
     return sum_projective(curve, allp)
 
 
+def _is_cuda(t):
+    return hasattr(t, "is_cuda") and t.is_cuda
+
+
+def _sharded_in_library(curve, bases_shard, scalars_shard, mont):
+    """local MSM + all-gather + sum, all inside libark_hip.so (ark_hip_msm_sw_device_sharded: RCCL)"""
+    import ctypes as C
+    from ._lib import check, lib
+    cid = cv.curve_id(curve)
+    out = np.zeros(cv.projective_words(cid), dtype=np.uint64)
+    n = min(bases_shard.numel() * 8 // cv.affine_bytes(cid), scalars_shard.numel() // 4)
+    check(lib().ark_hip_msm_sw_device_sharded(cid, bases_shard.data_ptr(), scalars_shard.data_ptr(), n, mont,
+                                              out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_sw_device_sharded")
+    return out
+
+
 def msm_bigint_sharded(curve, bases_shard, bigints_shard, group=None, local_msm=msm_bigint):
-    """MSM over the union of all ranks' shards; each rank passes only its own (base, scalar) range."""
+    """MSM over the union of all ranks' shards; each rank passes only its own (base, scalar) range.  With the library's
+    RCCL communicator up (comm_init) and device-resident shards the whole call is one C entry point."""
+    if library_comm_active() and local_msm is msm_bigint and _is_cuda(bases_shard) and _is_cuda(bigints_shard):
+        return _sharded_in_library(curve, bases_shard, bigints_shard, 0)
     return combine_partials(curve, local_msm(curve, bases_shard, bigints_shard), group)
 
 
 def msm_sharded(curve, bases_shard, scalars_shard, group=None):
     """Same for Fr (Montgomery) scalars: the sharded form of VariableBaseMSM::msm_unchecked."""
+    if library_comm_active() and _is_cuda(bases_shard) and _is_cuda(scalars_shard):
+        return _sharded_in_library(curve, bases_shard, scalars_shard, 1)
     return combine_partials(curve, msm_unchecked(curve, bases_shard, scalars_shard), group)
 
 
-# ---- radix-2 FFT sharded by coefficient range ---------------------------------------------------------------
-# n = 2^k coefficients, G = world_size ranks (a power of two <= 16), rank r holds x[r*m .. (r+1)*m), m = n/G, and
-# receives X[r*m .. (r+1)*m) (natural order, block layout in and out).  With i = i1*m + i2 and j = j1 + G*j2:
-#     X[j1 + G j2] = sum_{i2 < m} w_m^(i2 j2) * w_n^(i2 j1) * ( sum_{i1 < G} w_G^(i1 j1) x[i1 m + i2] )
-#   exchange 1  all-to-all: rank q collects, for its i2 range, the values of every i1
-#   local       G-point transform over i1 (ark_hip_fft_axis_device)
-#   exchange 2  all-to-all: rank j1 collects u[j1][all i2]
-#   local       size-m FFT with the coset pre-scaling h = w_n^j1 fused into its first pass (the single-GPU kernel)
-#   exchange 3  all-to-all back to block layout (a pipeline that multiplies pointwise and transforms back can skip it)
-# Three all-to-alls of (G-1)/G of the data each; over xGMI (7 links x ~153 GB/s per GPU) a 2^26-point transform moves
-# 3 x 224 MiB per GPU.  The butterflies themselves never cross GPUs except in the G-point stage.
-def _all_to_all(t, group, backend):
-    import torch
+# ---- the library's own RCCL communicator ------------------------------------------------------------------------------
+# The data-path collectives run INSIDE libark_hip.so (capi.hip, "one process per GPU"): torch.distributed is only the
+# control plane that carries rank 0's RCCL unique id to the other ranks -- exactly what an MPI or Rust host would do with
+# its own broadcast.  With the gloo backend (CPU tests, ranks sharing one GPU) there is no RCCL: the same algorithms run
+# with torch.distributed as the transport.
+_LIB_COMM = {"world": 0}
+
+
+def comm_init(group=None):
+    """Collective: create this rank's RCCL communicator inside the library.  Returns True when the library owns the
+    exchange from now on (backend nccl, world > 1), False otherwise."""
+    import ctypes as C
     import torch.distributed as dist
-    if backend == "nccl":
-        out = torch.empty_like(t)
-        dist.all_to_all_single(out, t, group=group)
-        return out
-    src = t.cpu()
-    out = torch.empty_like(src)
-    dist.all_to_all_single(out, src, group=group)
-    return out.to(t.device)
+    from ._lib import check, lib
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or dist.get_backend(group) != "nccl":
+        return False
+    if _LIB_COMM["world"] == dist.get_world_size(group):
+        return True
+    L = lib()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        check(L.ark_hip_comm_unique_id(buf), "ark_hip_comm_unique_id")
+    box = [bytes(buf)]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    check(L.ark_hip_comm_init(ident, rank, world), "ark_hip_comm_init")
+    _LIB_COMM["world"] = world
+    return True
 
 
-def fft_sharded(field, n, x_local, inverse=False, group=None):
-    """Forward (or inverse) radix-2 FFT of size n over all ranks' shards; x_local: CUDA int64 tensor [n/G, 4]
-    (Montgomery Fr).  Returns this rank's block of the result (new tensor)."""
+def comm_destroy():
+    from ._lib import check, lib
+    if _LIB_COMM["world"]:
+        check(lib().ark_hip_comm_destroy(), "ark_hip_comm_destroy")
+        _LIB_COMM["world"] = 0
+
+
+def library_comm_active():
+    return _LIB_COMM["world"] > 1
+
+
+# ---- radix-2 FFT sharded by coefficient range: ONE exchange -----------------------------------------------------------
+# n = 2^k coefficients over G ranks (a power of two <= 16, G^2 | n), m = n/G per rank, sub = m/G.  With i = i1 + G i2 and
+# j = j1 m + j2:
+#     X[j1 m + j2] = sum_{i1 < G} w_G^(i1 j1) * w_n^(i1 j2) * ( sum_{i2 < m} w_m^(i2 j2) x[i1 + G i2] )
+#   forward  in:  x_local[i2] = x[rank + G i2]                      (cyclic by coefficient index)
+#            out: y_local[j1 sub + t] = X[j1 m + rank sub + t]      (G rows of the rank's j2 range)
+#            = local size-m transform (twiddle w_n^rank fused into its last pass), all-to-all, G-point transform
+#   inverse  takes the forward's output layout back to the forward's input layout.
+# (ark_hip_fft_sharded_device, include/ark_hip.h.)  One all-to-all of (G-1)/G of the data per transform: 224 MiB per GPU
+# at 2^26 over 8 GPUs, ~0.2 ms over 7 xGMI links; the reference's CPU counterpart of the split is the recursion of
+# radix2/fft.rs:190-349 cut after log2 G stages.
+def shard_input(x_full, rank, world):
+    """rank's slice of a full coefficient vector [n, 4] in the forward transform's input layout"""
+    return x_full[rank::world]
+
+
+def unshard_output(y_locals):
+    """full evaluation vector [n, 4] from the ranks' forward outputs (list of [m, 4] arrays, rank order)"""
+    G = len(y_locals)
+    m = y_locals[0].shape[0]
+    sub = m // G
+    out = np.empty((G * m,) + tuple(y_locals[0].shape[1:]), dtype=y_locals[0].dtype)
+    for r, y in enumerate(y_locals):
+        for j1 in range(G):
+            out[j1 * m + r * sub: j1 * m + (r + 1) * sub] = y[j1 * sub:(j1 + 1) * sub]
+    return out
+
+
+def fft_sharded(field, n, x_local, inverse=False, group=None, offset=None):
+    """Forward (or inverse) radix-2 FFT of size n over all ranks' shards; x_local: CUDA int64 tensor [n/G, 4] (Montgomery
+    Fr) in the layouts above.  offset: coset offset (4 limbs) or None.  Returns this rank's part of the result (new tensor)."""
     import ctypes as C
     import torch
     import torch.distributed as dist
@@ -80,51 +148,47 @@ def fft_sharded(field, n, x_local, inverse=False, group=None):
     from .domain import Radix2EvaluationDomain
     fid = cv.field_id(field)
     L = lib()
-    dom_n = Radix2EvaluationDomain.new(fid, n)
-    if dom_n is None or dom_n.size() != n:
+    dom = Radix2EvaluationDomain.new(fid, n)
+    if dom is None or dom.size() != n:
         raise ValueError("n must be a power of two within the field's two-adicity")
+    if offset is not None:
+        dom = dom.get_coset(offset)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return dom_n.ifft(x_local) if inverse else dom_n.fft(x_local)
+        return dom.ifft(x_local) if inverse else dom.fft(x_local)
     G = dist.get_world_size(group)
     r = dist.get_rank(group)
-    backend = dist.get_backend(group)
     if G & (G - 1) or G > 16 or n % (G * G):
         raise ValueError("world size must be a power of two <= 16 with G^2 dividing n")
     m = n // G
-    sub = m // G
     assert x_local.is_cuda and x_local.numel() == 4 * m
-    w = dom_n.group_gen_inv() if inverse else dom_n.group_gen()
-
-    def fr_pow(base, e):
-        out = np.zeros(4, dtype=np.uint64)
-        b = np.ascontiguousarray(base, dtype=np.uint64)
-        check(L.ark_hip_fr_pow(fid, b.ctypes.data_as(C.c_void_p), e, out.ctypes.data_as(C.c_void_p)), "fr_pow")
-        return out
-
-    # exchange 1: sub-block q of my block (i2 in [q*sub, (q+1)*sub)) goes to rank q
-    recv = _all_to_all(x_local.reshape(G * sub, 4).contiguous(), group, backend)        # [i1][t]
+    y = x_local.clone().contiguous()
     torch.cuda.current_stream().synchronize()
-    root_g = fr_pow(w, n // G)                                                          # primitive G-th root
-    check(L.ark_hip_fft_axis_device(fid, recv.data_ptr(), G, sub, root_g.ctypes.data_as(C.c_void_p)), "fft_axis")
-    # exchange 2: row j1 goes to rank j1; what arrives is u[r][q*sub + t], i.e. i2 order
-    col = _all_to_all(recv, group, backend)
-    torch.cuda.current_stream().synchronize()
-    # local size-m transform with the pre-scaling (w_n^r)^i2 fused in: a forward "coset FFT" whose generator is
-    # w_m (or w_m^-1) and whose offset is w_n^r (or w_n^-r)
-    dom_m = Radix2EvaluationDomain.new(fid, m)
-    s = dom_m._s
-    if inverse:
-        for k in range(4):
-            s.group_gen[k] = s.group_gen_inv[k]
-    h = fr_pow(w, r)
-    for k in range(4):
-        s.offset[k] = int(h[k])
-    check(L.ark_hip_fft_in_place_device(fid, C.byref(s), col.data_ptr()), "local fft")
-    if inverse:  # the 1/n of the inverse transform
-        sinv = torch.from_numpy(np.tile(dom_n.size_inv(), (m, 1)).view(np.int64)).cuda()
-        torch.cuda.current_stream().synchronize()
-        check(L.ark_hip_fr_mul_device(fid, col.data_ptr(), sinv.data_ptr(), col.data_ptr(), m), "scale")
+    sref = C.byref(dom._s)
+    inv = 1 if inverse else 0
+    if library_comm_active():
+        check(L.ark_hip_fft_sharded_device(fid, sref, y.data_ptr(), inv), "ark_hip_fft_sharded_device")
+        check(L.ark_hip_synchronize(), "sync")
+        return y
+
+    def exchange(t):  # block q of every rank to rank q, carried by torch.distributed (gloo: through host memory)
+        check(L.ark_hip_synchronize(), "sync")
+        if dist.get_backend(group) == "nccl":
+            out = torch.empty_like(t)
+            dist.all_to_all_single(out, t, group=group)
+            torch.cuda.current_stream().synchronize()
+            return out
+        src = t.cpu()
+        out = torch.empty_like(src)
+        dist.all_to_all_single(out, src, group=group)
+        return out.to(t.device)
+
+    if not inverse:
+        check(L.ark_hip_fft_shard_local_device(fid, sref, r, G, y.data_ptr(), 0), "shard_local")
+        z = exchange(y)
+        check(L.ark_hip_fft_shard_cross_device(fid, sref, G, z.data_ptr(), z.data_ptr(), 0), "shard_cross")
+    else:
+        check(L.ark_hip_fft_shard_cross_device(fid, sref, G, y.data_ptr(), y.data_ptr(), 1), "shard_cross")
+        z = exchange(y)
+        check(L.ark_hip_fft_shard_local_device(fid, sref, r, G, z.data_ptr(), 1), "shard_local")
     check(L.ark_hip_synchronize(), "sync")
-    # exchange 3: I hold X[r + G*j2]; block q of j2 goes to rank q, which interleaves the G residues
-    z = _all_to_all(col, group, backend)                                                # [j1][t] = X[j1 + G (r*sub + t)]
-    return z.reshape(G, sub, 4).permute(1, 0, 2).contiguous().reshape(m, 4)
+    return z

@@ -44,7 +44,8 @@ enum { ARK_HIP_BN254_G1 = 0, ARK_HIP_BLS12_381_G1 = 1, ARK_HIP_BLS12_377_G1 = 2,
        ARK_HIP_BLS12_381_G2 = 4 };
 /* error codes */
 enum { ARK_HIP_OK = 0, ARK_HIP_ERR_ARG = -1, ARK_HIP_ERR_SIZE = -2, ARK_HIP_ERR_NOMEM = -3,
-       ARK_HIP_ERR_SCALAR_RANGE = -4, ARK_HIP_ERR_NO_DEVICE = -5, ARK_HIP_ERR_BUSY = -6 /* HIP runtime errors: <= -1000 */ };
+       ARK_HIP_ERR_SCALAR_RANGE = -4, ARK_HIP_ERR_NO_DEVICE = -5, ARK_HIP_ERR_BUSY = -6,
+       ARK_HIP_ERR_COMM = -7 /* RCCL missing or failed */ /* HIP runtime errors: <= -1000 */ };
 
 /* ---- runtime ---- */
 int ark_hip_device_count(void);
@@ -170,6 +171,11 @@ int ark_hip_msm_sw_multi(int curve, int n_gpus, const uint64_t* bases, const uin
                          int scalars_are_montgomery, uint64_t* out_xyz);
 int ark_hip_msm_sw_multi_device(int curve, int n_gpus, const void* const* d_bases, const void* const* d_scalars,
                                 const size_t* n_per_gpu, int scalars_are_montgomery, uint64_t* out_xyz);
+/* The same over PREPARED shards: shards[g] was prepared on GPU g (ark_hip_set_device(g); ark_hip_msm_bases_prepare over
+ * the g-th base range); the scalars are host memory, cut at the shards' sizes in order, uploaded and run on all devices
+ * concurrently (the asynchronous prepared entry per device), partial results summed on the host. */
+int ark_hip_msm_prepared_multi(int n_gpus, const ark_hip_msm_bases* const* shards, const uint64_t* scalars, size_t n,
+                               int scalars_are_montgomery, uint64_t* out_xyz);
 
 /* The window plan (widest window in bits, number of windows) the library picks for an MSM of n pairs on `curve`, plain
  * (prepared = 0) or over a prepared base set; pure host arithmetic. */
@@ -257,11 +263,53 @@ int ark_hip_fft_batch_in_place_device(int field, const ark_hip_radix2_domain* do
  * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
  * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */
 int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
-/* ---- multi-GPU FFT building blocks (the exchange itself is the host's: RCCL all-to-all, algebra_amd/dist.py) ----
- * base^exp in Fr on the host (twiddle w_n^j for the per-rank coset), and the G-point transform along the slow
- * axis of a [G][cols] device array (G = 2, 4, 8 or 16): out[j][c] = sum_i root^(i j) in[i][c]. */
+/* base^exp in Fr on the host (domain elements / twiddles for hosts without field code of their own) */
 int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out);
+/* the G-point transform along the slow axis of a [G][cols] device array (G = 2, 4, 8 or 16), in place:
+ * out[j][c] = sum_i root^(i j) in[i][c] */
 int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, const uint64_t* root);
+
+/* ---- one process per GPU: RCCL inside the library ---------------------------------------------------------------
+ * The reference chunks an MSM by base range and sums the chunk results (variable_base/mod.rs:521-557); an FFT shards by
+ * coefficient range with ONE transpose between two rounds of local butterflies (the four-step form of the radix-2
+ * recursion, radix2/fft.rs:190-349).  Across the GPUs of a node both need exactly one exchange, and the library runs it
+ * itself on RCCL (loaded at run time: librccl.so.1, the copy the process already has if any -- e.g. PyTorch's):
+ *   id:    rank 0 calls ark_hip_comm_unique_id and ships the ARK_HIP_COMM_ID_BYTES to the other ranks by any means the
+ *          host has (MPI, a TCP socket, torch.distributed's store);
+ *   init:  every rank calls ark_hip_comm_init(id, rank, world) on its device (collective: ncclCommInitRank);
+ *   then the *_sharded entries below are collective calls: every rank makes the same sequence of them.
+ * Without a communicator (or with world = 1) they run the single-GPU path. */
+#define ARK_HIP_COMM_ID_BYTES 128
+int ark_hip_comm_unique_id(void* out_id);
+int ark_hip_comm_init(const void* id, int rank, int world);
+int ark_hip_comm_info(int* rank, int* world);   /* (0, 1) when this device has no communicator */
+int ark_hip_comm_destroy(void);
+/* One MSM over the union of all ranks' (base, scalar) shards, device-resident; every rank receives the same sum.  The
+ * exchange is an all-gather of one Projective per rank (3 field elements: elliptic-curve addition is not an RCCL reduce
+ * op) followed by world - 1 point additions in rank order.  _prepared_: this rank's shard as a prepared base set. */
+int ark_hip_msm_sw_device_sharded(int curve, const void* d_bases, const void* d_scalars, size_t n_local,
+                                  int scalars_are_montgomery, uint64_t* out_xyz);
+int ark_hip_msm_prepared_device_sharded(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n_local,
+                                        int scalars_are_montgomery, uint64_t* out_xyz);
+/* Radix-2 FFT / IFFT of dom->size = G m elements over G = world ranks (G a power of two <= 16, G^2 | size), m per rank,
+ * in place on d_local, ONE all-to-all.  With i = i1 + G i2 and j = j1 m + j2 (i1, j1 < G; i2, j2 < m; sub = m / G):
+ *     X[j1 m + j2] = sum_i1 w_G^(i1 j1) * w_n^(i1 j2) * ( sum_i2 w_m^(i2 j2) x[i1 + G i2] )
+ *   forward  in:  d_local[i2] = x[rank + G i2]                       (cyclic by coefficient index)
+ *            out: d_local[j1 sub + t] = X[j1 m + rank sub + t]       (G rows of the rank's j2 range)
+ *            = size-m transform with the twiddle w_n^rank fused into its last pass, all-to-all, G-point transform
+ *   inverse  takes the forward's output layout back to the forward's input layout (G-point transform, all-to-all,
+ *            twiddle fused into the first pass of the size-m inverse transform, 1/n into its last).
+ * A coset domain (dom->offset != 1) is honoured as in the single-GPU transform.  The exchange is cut into slices that
+ * travel on a second stream while the G-point kernel works on the previous slice.  Asynchronous on the context stream. */
+int ark_hip_fft_sharded_device(int field, const ark_hip_radix2_domain* dom, void* d_local, int inverse);
+/* The two local halves of that transform for a host that brings its own exchange (MPI, gloo, ...), and for testing the
+ * decomposition on one GPU:  _local: the size-m transform with the per-rank twiddle (forward: first step; inverse: last
+ * step);  _cross: the G-point transform of a [G][sub] array, d_src -> d_dst (may alias).  Forward = local, all-to-all
+ * (block q of every rank to rank q), cross;  inverse = cross, all-to-all, local. */
+int ark_hip_fft_shard_local_device(int field, const ark_hip_radix2_domain* dom, int rank, int world, void* d_local,
+                                   int inverse);
+int ark_hip_fft_shard_cross_device(int field, const ark_hip_radix2_domain* dom, int world, const void* d_src, void* d_dst,
+                                   int inverse);
 int ark_hip_fft_set_timing(int enable);
 /* [total_ms, npass, pass0_ms, pass1_ms, ...] of the last timed device transform */
 int ark_hip_fft_last_timing(double out[10]);

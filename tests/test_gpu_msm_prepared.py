@@ -258,6 +258,27 @@ def test_msm_multi_one_process_many_devices(monkeypatch):
         check(L.ark_hip_free(d_b[g]), "free")
         check(L.ark_hip_free(d_s[g]), "free")
     check(L.ark_hip_set_device(0), "set_device")
+    # prepared shards, one per (logical) device: ark_hip_msm_prepared_multi cuts the host scalars at the shard sizes
+    G = 3
+    shards = []
+    for g in range(G):
+        lo, hi = shard_bounds(n, g, G)
+        check(L.ark_hip_set_device(g), "set_device")
+        shards.append(A.PreparedBases(cid, bases[lo:hi]))
+    check(L.ark_hip_set_device(0), "set_device")
+    hs = (C.c_void_p * G)(*[sh._h for sh in shards])
+    out = np.zeros(18, dtype=np.uint64)
+    check(L.ark_hip_msm_prepared_multi(G, hs, scalars.ctypes.data_as(C.c_void_p), n, 0, out.ctypes.data_as(C.c_void_p)),
+          "prepared_multi")
+    assert np.array_equal(aff(cid, out), exp)
+    # fewer scalars than bases (msm_unchecked truncates): the last shard gets a short / empty piece
+    k = shard_bounds(n, 1, G)[1] + 5
+    check(L.ark_hip_msm_prepared_multi(G, hs, scalars.ctypes.data_as(C.c_void_p), k, 0, out.ctypes.data_as(C.c_void_p)),
+          "prepared_multi short")
+    assert np.array_equal(aff(cid, out), oracle_aff(cid, bases[:k], scalars[:k]))
+    assert L.ark_hip_msm_prepared_multi(G, hs, scalars.ctypes.data_as(C.c_void_p), n + 1, 0, out.ctypes.data_as(C.c_void_p)) != 0
+    for sh in shards:
+        sh.free()
 
 
 def test_hashmap_pippenger_matches_naive_sum():
