@@ -138,9 +138,23 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-        # bring the communicator up outside the timed region (RCCL initialises lazily on the first collective)
+        # bring the communicators up outside the timed region (RCCL initialises lazily on the first collective): the
+        # library's own (the data path: ark_hip_msm_sw_device_sharded / ark_hip_fft_sharded_device) and, as the fallback
+        # exchange should that fail on this box, torch.distributed's
         D.combine_partials(cid, np.zeros(cv.projective_words(cid), dtype=np.uint64))
+        try:
+            ok = D.comm_init()
+            exchange = "RCCL inside libark_hip.so (ark_hip_msm_sw_device_sharded)" if ok else \
+                "torch.distributed all_gather (%s backend)" % backend
+        except Exception as e:  # noqa: BLE001 -- the headline must survive a communicator problem
+            exchange = "torch.distributed all_gather (library communicator failed: %s)" % repr(e)[:120]
+        flags = torch.tensor([1.0 if D.library_comm_active() else 0.0], device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)   # all ranks or none
+        if flags.item() == 0.0 and D.library_comm_active():
+            D.comm_destroy()
 
+    if world == 1:
+        exchange = "none (one GPU)"
     log_local = args.log_n if args.log_n is not None else LOG_PER_GPU
     n = 1 << log_local                      # pairs on this GPU
     n_total = n * world                     # pairs of the one MSM
@@ -176,9 +190,11 @@ def main():
             k = sum(ks) % R_MOD
         return S.mul_gen(cid, k, R_MOD) if rank == 0 else None
 
-    def run_timed(local_msm, sc, warmup, steps):
+    def run_timed(local_msm, sc, warmup, steps, sharded=None):
         """K steps of: local MSM on this rank's shard, then (N > 1) all-gather of the partials + EC sum"""
         def step():
+            if sharded is not None and D.library_comm_active():
+                return sharded(sc)             # local MSM + all-gather + sum inside the library
             return D.combine_partials(cid, local_msm(sc))
         for _ in range(warmup):
             res = step()
@@ -199,7 +215,8 @@ def main():
     # ---- the headline job: ONE MSM of n_total pairs through the plain entry, base-range shards ----------------
     first = rank * n
     bases, scalars_h, scalars = make_inputs(n, first, 0xA11CE + rank)
-    result, elapsed, phases = run_timed(lambda sc: A.msm_bigint(cid, bases, sc), scalars, args.warmup, args.steps)
+    result, elapsed, phases = run_timed(lambda sc: A.msm_bigint(cid, bases, sc), scalars, args.warmup, args.steps,
+                                        sharded=lambda sc: D.msm_bigint_sharded(cid, bases, sc))
     want = expected_affine(scalars_h, first)
     exact = bool(np.array_equal(A.into_affine(cid, result), want)) if rank == 0 else None
     extras = not args.no_extras
@@ -288,7 +305,8 @@ def main():
                 torch.cuda.empty_cache()
                 bb, bsh, bs = make_inputs(nb_, rank * nb_, 0xB16 + rank)
             st = 2 if world == 1 else min(args.steps, 5)
-            res_b, el_b, ph_b = run_timed(lambda sc: A.msm_bigint(cid, bb, sc), bs, 1, st)
+            res_b, el_b, ph_b = run_timed(lambda sc: A.msm_bigint(cid, bb, sc), bs, 1, st,
+                                          sharded=lambda sc: D.msm_bigint_sharded(cid, bb, sc))
             kb = expected_affine(bsh, rank * nb_)
             if rank == 0:
                 config4 = {"what": "one 2^%d MSM, plain entry, %d pairs per GPU over %d GPU(s)" % (LOG_CONFIG4, nb_, world),
@@ -407,23 +425,37 @@ def main():
         try:
             nloc = 1 << args.fft_log_n
             ntot = nloc * world
-            xs = torch.from_numpy(gen_scalars(nloc, 11 + rank).view(np.int64)).cuda()
+            xs = torch.from_numpy(gen_scalars(nloc, 11 + rank).view(np.int64)).cuda()   # this rank's cyclic slice
             ys = D.fft_sharded(FIELD, ntot, xs)                       # warm-up (tables, communicator)
             back = D.fft_sharded(FIELD, ntot, ys, inverse=True)
             rt_ok = bool(torch.equal(back, xs))
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.fft_steps):
-                ys = D.fft_sharded(FIELD, ntot, xs)
-            barrier()
-            dt = time.perf_counter() - t1
+            if D.library_comm_active():   # timed in place through the C entry: no clone, no host synchronisation per step
+                domt = A.Radix2EvaluationDomain.new(FIELD, ntot)
+                sref_t = C.byref(domt._s)
+                buf = xs.clone()
+                torch.cuda.synchronize()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.fft_steps):
+                    check(L.ark_hip_fft_sharded_device(domt.field, sref_t, buf.data_ptr(), 0), "fft sharded")
+                barrier()
+                dt = time.perf_counter() - t1
+            else:
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.fft_steps):
+                    ys = D.fft_sharded(FIELD, ntot, xs)
+                barrier()
+                dt = time.perf_counter() - t1
             tt = torch.tensor([dt, 0.0 if rt_ok else 1.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            fft_sharded = {"metric": "BLS12-381 Fr radix-2 FFT elements/sec (2^%d per GPU, sharded, block layout in/out)"
+            fft_sharded = {"metric": "BLS12-381 Fr radix-2 FFT elements/sec (2^%d per GPU, sharded: ONE all-to-all, cyclic in / row-block out)"
                                      % args.fft_log_n,
                            "value": ntot * args.fft_steps / float(tt[0].item()), "unit": "elements/s",
                            "ms_per_step": float(tt[0].item()) * 1e3 / args.fft_steps, "log_n_total": int(np.log2(ntot)),
-                           "ifft_fft_roundtrip_exact": float(tt[1].item()) == 0.0}
+                           "ifft_fft_roundtrip_exact": float(tt[1].item()) == 0.0,
+                           "exchange": "RCCL inside libark_hip.so (ark_hip_fft_sharded_device)" if D.library_comm_active()
+                                       else "torch.distributed all_to_all_single"}
         except Exception as e:  # never lose the MSM line to the secondary leg
             fft_sharded = {"error": repr(e)[:300]}
 
@@ -480,7 +512,8 @@ def main():
                                      "everything else on saturated 32-bit limbs" %
                                      ("carry-free 28-bit limbs" if LAZY else "saturated 32-bit limbs"),
                        "curve": CURVE, "window_bits": cbits, "windows": W,
-                       "pairs_per_gpu": n, "sharding": "base-range, %d rank(s), partials all-gathered" % world},
+                       "pairs_per_gpu": n, "sharding": "base-range, %d rank(s), partials all-gathered" % world,
+                       "exchange": exchange},
             "bit_exact_vs_kG": exact,
             "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
                           "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},

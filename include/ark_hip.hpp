@@ -296,6 +296,34 @@ class HashMapPippenger {
   std::vector<P> partials_;
 };
 
+// ---- one process per GPU: the library's RCCL communicator ------------------------------------------------------------
+// Rank 0 creates the id, the host ships its bytes to the other ranks (MPI_Bcast, a socket ...), every rank constructs a
+// Communicator on its device (collective).  While it lives, msm_sharded / fft_sharded_in_place_device are collective
+// calls; the reference's counterpart of the split is its own chunking by base range (variable_base/mod.rs:521-557).
+class Communicator {
+ public:
+  using Id = std::array<unsigned char, ARK_HIP_COMM_ID_BYTES>;
+  static Id unique_id() {
+    Id id{};
+    check(ark_hip_comm_unique_id(id.data()), "ark_hip_comm_unique_id");
+    return id;
+  }
+  Communicator(const Id& id, int rank, int world) { check(ark_hip_comm_init(id.data(), rank, world), "ark_hip_comm_init"); }
+  ~Communicator() { (void)ark_hip_comm_destroy(); }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  int rank() const { int r = 0, w = 1; check(ark_hip_comm_info(&r, &w), "ark_hip_comm_info"); return r; }
+  int world() const { int r = 0, w = 1; check(ark_hip_comm_info(&r, &w), "ark_hip_comm_info"); return w; }
+  // the sum over ALL ranks' (base, scalar) shards; d_bases / d_scalars: this rank's shard in device memory
+  template <class Curve>
+  typename Curve::ProjectiveT msm_bigint_sharded(const void* d_bases, const void* d_scalars, size_t n_local) const {
+    typename Curve::ProjectiveT out;
+    check(ark_hip_msm_sw_device_sharded(Curve::ID, d_bases, d_scalars, n_local, 0, reinterpret_cast<uint64_t*>(&out)),
+          "ark_hip_msm_sw_device_sharded");
+    return out;
+  }
+};
+
 // ---- Radix2EvaluationDomain ------------------------------------------------------------------------------------------
 template <int FIELD_ID>
 class Radix2EvaluationDomain {
@@ -359,6 +387,13 @@ class Radix2EvaluationDomain {
   void fft_batch_in_place_device(const std::vector<void*>& d_polys, bool inverse = false) const {
     check(ark_hip_fft_batch_in_place_device(FIELD_ID, &s_, d_polys.data(), d_polys.size(), inverse ? 1 : 0),
           "ark_hip_fft_batch_in_place_device");
+  }
+  // One process per GPU (Communicator below): this rank's m = size() / world elements, in THIS GPU's memory, of ONE
+  // transform over all ranks -- forward: d_local[i2] = x[rank + world i2] in, d_local[j1 sub + t] = X[j1 m + rank sub + t]
+  // out (sub = m / world); inverse: the other way round.  One all-to-all over RCCL inside the library.  Collective;
+  // asynchronous on the device (ark_hip_synchronize() before the results are read).
+  void fft_sharded_in_place_device(void* d_local, bool inverse = false) const {
+    check(ark_hip_fft_sharded_device(FIELD_ID, &s_, d_local, inverse ? 1 : 0), "ark_hip_fft_sharded_device");
   }
   const ark_hip_radix2_domain& raw() const { return s_; }
 

@@ -118,7 +118,26 @@ extern "C" {
     pub fn ark_hip_fft_batch_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *const *mut c_void,
                                              count: usize, inverse: c_int) -> c_int;
     pub fn ark_hip_fr_mul_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    pub fn ark_hip_msm_prepared_multi(n_gpus: c_int, shards: *const *const ark_hip_msm_bases, scalars: *const u64, n: usize,
+                                      scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    // one process per GPU: the library's own RCCL communicator (include/ark_hip.h, "RCCL inside the library")
+    pub fn ark_hip_comm_unique_id(out_id: *mut c_void) -> c_int;
+    pub fn ark_hip_comm_init(id: *const c_void, rank: c_int, world: c_int) -> c_int;
+    pub fn ark_hip_comm_info(rank: *mut c_int, world: *mut c_int) -> c_int;
+    pub fn ark_hip_comm_destroy() -> c_int;
+    pub fn ark_hip_msm_sw_device_sharded(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n_local: usize,
+                                         scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_msm_prepared_device_sharded(bases: *const ark_hip_msm_bases, d_scalars: *const c_void, n_local: usize,
+                                               scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
+    pub fn ark_hip_fft_sharded_device(field: c_int, dom: *const ark_hip_radix2_domain, d_local: *mut c_void,
+                                      inverse: c_int) -> c_int;
+    pub fn ark_hip_fft_shard_local_device(field: c_int, dom: *const ark_hip_radix2_domain, rank: c_int, world: c_int,
+                                          d_local: *mut c_void, inverse: c_int) -> c_int;
+    pub fn ark_hip_fft_shard_cross_device(field: c_int, dom: *const ark_hip_radix2_domain, world: c_int,
+                                          d_src: *const c_void, d_dst: *mut c_void, inverse: c_int) -> c_int;
 }
+/// Size of the opaque RCCL unique id rank 0 ships to the other ranks (`ark_hip_comm_unique_id` -> `ark_hip_comm_init`).
+pub const ARK_HIP_COMM_ID_BYTES: usize = 128;
 
 const BN254_FR_MODULUS: [u64; 4] = [0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029];
 const BLS12_381_FR_MODULUS: [u64; 4] = [0xffffffff00000001, 0x53bda402fffe5bfe, 0x3339d80809a1d805, 0x73eda753299d7d48];

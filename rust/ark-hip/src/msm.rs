@@ -174,6 +174,21 @@ pub fn msm_multi<P: SWCurveConfig>(curve: c_int, n_gpus: usize, bases: &[Affine<
     (rc == 0).then(|| unsafe { out.assume_init() })
 }
 
+/// One process per GPU: the library's own RCCL communicator.  Rank 0 creates the id and the host ships it to the other
+/// ranks by whatever it already has (MPI broadcast, a TCP socket); every rank then calls [`comm_init`] on its device
+/// (collective).  From then on [`PreparedBases::msm_bigint_sharded`] and the `*_sharded` C entry points are collective
+/// calls over all ranks; without a communicator they run the single-GPU path.
+pub fn comm_unique_id() -> Option<[u8; sys::ARK_HIP_COMM_ID_BYTES]> {
+    let mut id = [0u8; sys::ARK_HIP_COMM_ID_BYTES];
+    (unsafe { sys::ark_hip_comm_unique_id(id.as_mut_ptr() as *mut c_void) } == 0).then_some(id)
+}
+pub fn comm_init(id: &[u8; sys::ARK_HIP_COMM_ID_BYTES], rank: usize, world: usize) -> bool {
+    unsafe { sys::ark_hip_comm_init(id.as_ptr() as *const c_void, rank as c_int, world as c_int) == 0 }
+}
+pub fn comm_destroy() -> bool {
+    unsafe { sys::ark_hip_comm_destroy() == 0 }
+}
+
 /// An MSM in flight on the device.  `wait` blocks until the result is there.
 pub struct MsmJob<'a, P: SWCurveConfig> {
     job: *mut sys::ark_hip_msm_job,
@@ -241,6 +256,17 @@ impl<P: SWCurveConfig> PreparedBases<P> {
     }
     pub fn msm_bigint(&self, bigints: &[BigIntOf<P>]) -> Option<Projective<P>> {
         self.run(bigints, false)
+    }
+    /// This rank's shard of ONE MSM over all ranks (base-range shards, variable_base/mod.rs:521-557): the scalars are this
+    /// rank's range, already in device memory (`d_scalars`: a device pointer to `n` canonical `BigInt`s); the partials
+    /// are all-gathered over RCCL inside the library and every rank receives the same sum.  Collective.
+    ///
+    /// # Safety
+    /// `d_scalars` must point to `n * 32` readable bytes of this GPU's memory.
+    pub unsafe fn msm_bigint_sharded(&self, d_scalars: *const c_void, n: usize) -> Option<Projective<P>> {
+        let mut out = MaybeUninit::<Projective<P>>::uninit();
+        let rc = sys::ark_hip_msm_prepared_device_sharded(self.handle, d_scalars, n.min(self.n), 0, out.as_mut_ptr() as *mut u64);
+        (rc == 0).then(|| out.assume_init())
     }
     /// Enqueue and return: the scalars upload on the copy stream while the previous MSM computes.
     pub fn msm_bigint_async<'a>(&'a self, bigints: &'a [BigIntOf<P>]) -> Option<MsmJob<'a, P>> {

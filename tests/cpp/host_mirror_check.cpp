@@ -126,12 +126,56 @@ void check_fft(const char* name, unsigned log_n) {
   std::printf("%s fft 2^%u checked\n", name, log_n);
 }
 
+// the library's RCCL communicator from a compiled host: a world of one on the test box's single GPU (dlopen of librccl,
+// ncclCommInitRank, the sharded MSM and FFT entries through it)
+void check_communicator() {
+  using M = VariableBaseMSM<Bls12_381G1>;
+  const size_t n = 1500;
+  std::vector<Bls12_381G1::AffineT> bases(n);
+  std::vector<BigInt4> big(n);
+  uint64_t a4[4] = {0xA11CE, 1, 2, 0}, b4[4] = {0xB0B, 3, 0, 0};
+  ark_oracle_gen_bases(Bls12_381G1::ID, a4, b4, n, reinterpret_cast<uint64_t*>(bases.data()));
+  ark_oracle_gen_scalars(Bls12_381G1::SCALAR_FIELD, 21, n, 0, reinterpret_cast<uint64_t*>(big.data()));
+  auto ref_aff = M::into_affine(M::msm_bigint(bases, big));
+  void *db = nullptr, *ds = nullptr, *dx = nullptr;
+  check(ark_hip_malloc(n * sizeof(bases[0]), &db), "malloc");
+  check(ark_hip_malloc(n * 32, &ds), "malloc");
+  check(ark_hip_memcpy_h2d(db, bases.data(), n * sizeof(bases[0])), "h2d");
+  check(ark_hip_memcpy_h2d(ds, big.data(), n * 32), "h2d");
+  {
+    Communicator comm(Communicator::unique_id(), 0, 1);
+    EXPECT(comm.rank() == 0 && comm.world() == 1, "communicator geometry");
+    auto got = comm.msm_bigint_sharded<Bls12_381G1>(db, ds, n);
+    EXPECT(M::into_affine(got) == ref_aff, "sharded msm through the communicator");
+    using D = Radix2EvaluationDomain<ARK_HIP_BLS12_381_FR>;
+    auto dom = D::new_(1 << 11);
+    std::vector<Fr> x(1 << 11), ref;
+    ark_oracle_gen_scalars(ARK_HIP_BLS12_381_FR, 8, x.size(), 1, reinterpret_cast<uint64_t*>(x.data()));
+    ref = x;
+    ark_oracle_fft(ARK_HIP_BLS12_381_FR, reinterpret_cast<uint64_t*>(ref.data()), 11, nullptr, 0, 2);
+    check(ark_hip_malloc(x.size() * 32, &dx), "malloc");
+    check(ark_hip_memcpy_h2d(dx, x.data(), x.size() * 32), "h2d");
+    dom->fft_sharded_in_place_device(dx);
+    check(ark_hip_synchronize(), "sync");
+    check(ark_hip_memcpy_d2h(x.data(), dx, x.size() * 32), "d2h");
+    EXPECT(std::memcmp(x.data(), ref.data(), x.size() * 32) == 0, "sharded fft through the communicator");
+  }
+  int r = -1, w = -1;
+  check(ark_hip_comm_info(&r, &w), "info");
+  EXPECT(r == 0 && w == 1, "communicator gone after scope");
+  check(ark_hip_free(db), "free");
+  check(ark_hip_free(ds), "free");
+  check(ark_hip_free(dx), "free");
+  std::printf("communicator (world of one) checked\n");
+}
+
 int main() {
   if (ark_hip_device_count() <= 0) { std::printf("no GPU\n"); return 2; }
   check_msm<Bls12_381G1>("BLS12_381_G1", 2000);
   check_msm<Bn254G1>("BN254_G1", 1024);
   check_msm<Bls12_377G2>("BLS12_377_G2", 300);
   check_fft<ARK_HIP_BLS12_381_FR>("BLS12_381_FR", 12);
+  check_communicator();
   check_fft<ARK_HIP_BN254_FR>("BN254_FR", 9);
   EXPECT(!Radix2EvaluationDomain<ARK_HIP_BN254_FR>::new_(((size_t)1 << 28) + 1).has_value(), "too large -> None");
   std::printf(fails ? "FAILED (%d)\n" : "all ok\n", fails);
