@@ -1167,7 +1167,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   int HB, LB;
   msm_part_split(n, Bbits, &HB, &LB);
   const u32 nsuper = (u32)W << HB;
-  const u32 ntiles = (u32)((n + PART_TILE - 1) / PART_TILE);
+  const u32 ptile = msm_part_tile(HB);
+  const u32 ntiles = (u32)((n + ptile - 1) / ptile);
   const size_t nthist = (size_t)nsuper * ntiles;
   if (ws.keys.ensure((size_t)W * n * 4)) return -3;
   if (ws.sorted.ensure((size_t)W * n * 4)) return -3;
@@ -1280,12 +1281,12 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[1], stream));
   // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
   hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
-                     ntiles, thist);
+                     ntiles, ptile, thist);
   scan_exclusive(thist, nthist, sums, toff, stream);
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[2], stream));
   {
     // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device; the workspace is per device)
-    const size_t lds_a = ((size_t)8 << HB) + (size_t)PART_TILE * 8;
+    const size_t lds_a = ((size_t)8 << HB) + (size_t)ptile * 8;
     const u32 stage_cap = msm_part_stage_cap(LB);
     const size_t lds_b = ((size_t)(1 << LB) + 1024 + stage_cap) * 4;
     if (!ws.attr_set) {
@@ -1296,7 +1297,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
       ws.attr_set = true;
     }
     hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, W), dim3(1024), lds_a, stream, keys, (u32)n, HB, LB, ntiles,
-                       toff, part);
+                       ptile, toff, part);
     hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper), dim3(1024), lds_b, stream, part, toff, ntiles, LB, nsuper,
                        stage_cap, offsets, sorted);
   }

@@ -22,6 +22,7 @@
 // `buckets[|digit|-1]` directly, ec/src/scalar_mul/variable_base/mod.rs:464-475.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "fp.cuh"
 
 namespace arkhip {
@@ -47,13 +48,27 @@ static inline void msm_part_split(size_t n, int B, int* HB, int* LB) {
     while (((size_t)1 << lg) < n) lg++;
     if (hb < lg - 15) hb = lg - 15;              // super-bucket (n / 2^hb entries) within the LDS staging area
     if (hb > B) hb = B;
+    if (const char* e = getenv("ARK_HIP_MSM_HB")) {   // tuning knob (tools/): super-bucket bits of pass A
+      const int v = atoi(e);
+      if (v >= 0 && v <= B && B - v <= PART_LO_BITS_MAX) hb = v;
+    }
   }
   *HB = hb;
   *LB = B - hb;
 }
 // staging entries of the finish kernel for a given LB
 static inline u32 msm_part_stage_cap(int LB) { return PART_LDS_WORDS - 1024u - (1u << LB) - 16u; }
-static constexpr int PART_TILE = 8192;         // keys per workgroup in pass A (64 KiB of staged pairs)
+static constexpr int PART_TILE = 8192;         // keys per workgroup in pass A (64 KiB of staged pairs) ...
+static constexpr int PART_TILE_BIG = 16384;    // ... 128 KiB where pass A has >= 2^11 super-buckets (n >= 2^26): the per-tile
+                                               // histogram array halves and the runs a tile writes per super-bucket double
+                                               // (2^26, c = 22: 4 entries = 32 B per run with 8192 keys)
+static inline u32 msm_part_tile(int HB) {
+  if (const char* e = getenv("ARK_HIP_MSM_TILE")) {   // tuning knob
+    const int v = atoi(e);
+    if (v == PART_TILE || v == PART_TILE_BIG) return (u32)v;
+  }
+  return HB >= 11 ? (u32)PART_TILE_BIG : (u32)PART_TILE;
+}
 static constexpr u32 PART_KEY_NONE = 0xffffffffu;
 
 // slot index (sort order) -> bucket index (window-major, weight order)
@@ -68,7 +83,7 @@ __host__ __device__ __forceinline__ u32 msm_slot_to_bucket(u32 slot, int HB, int
 
 // A1: per-workgroup histogram over the high bits.  grid = (tiles, W); dynamic LDS = 4 << HB bytes.
 static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __restrict__ keys, u32 n, int HB, int LB,
-                                                                   u32 ntiles, u32* __restrict__ tile_hist) {
+                                                                   u32 ntiles, u32 tile, u32* __restrict__ tile_hist) {
   extern __shared__ u32 part_lds[];
   const u32 nbins = 1u << HB;
   const u32 hmask = nbins - 1u;  // super-bucket = LOW HB bits of the bucket id (see header)
@@ -76,8 +91,8 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
   __syncthreads();
   const u32 w = blockIdx.y;
   const size_t base = (size_t)w * n;
-  const u32 lo = blockIdx.x * PART_TILE;
-  const u32 hi = lo + PART_TILE < n ? lo + PART_TILE : n;
+  const u32 lo = blockIdx.x * tile;
+  const u32 hi = lo + tile < n ? lo + tile : n;
   for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     u32 key = keys[base + i];
     if (key != PART_KEY_NONE) atomicAdd(&part_lds[key & hmask], 1u);
@@ -90,9 +105,9 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
 
 // A2: second sweep over the same tile.  Pairs are staged in LDS grouped by super-bucket and then written
 // out in order, so that each (super-bucket, tile) run leaves as contiguous 8-byte elements.
-// dynamic LDS: (2 << HB) counters + PART_TILE pairs.
+// dynamic LDS: (2 << HB) counters + `tile` pairs.
 static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32* __restrict__ keys, u32 n, int HB,
-                                                                       int LB, u32 ntiles,
+                                                                       int LB, u32 ntiles, u32 tile,
                                                                        const u32* __restrict__ tile_off,
                                                                        uint2* __restrict__ part) {
   extern __shared__ u32 part_lds[];
@@ -103,8 +118,8 @@ static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32
   __shared__ u32 wsum[1024];
   const u32 w = blockIdx.y;
   const size_t base = (size_t)w * n;
-  const u32 lo = blockIdx.x * PART_TILE;
-  const u32 hi = lo + PART_TILE < n ? lo + PART_TILE : n;
+  const u32 lo = blockIdx.x * tile;
+  const u32 hi = lo + tile < n ? lo + tile : n;
   const u32 hmask = nbins - 1u;
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
