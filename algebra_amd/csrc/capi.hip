@@ -2067,10 +2067,11 @@ static int run_elementwise(size_t abytes, size_t bbytes, size_t rbytes, const vo
 }
 
 int ark_hip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n) {
-  if (!a || !r || op < 0 || op > 8 || op == 6) return ARK_HIP_ERR_ARG;
+  const bool lazy_op = op >= 20 && op <= 22;   // the 28-bit-limb device forms (testops.cuh)
+  if (!a || !r || op < 0 || (op > 8 && !lazy_op) || op == 6) return ARK_HIP_ERR_ARG;
   size_t fb = field_bytes(field);
   if (field < 0 || field > 5) return ARK_HIP_ERR_ARG;
-  if ((field == ARK_HIP_BN254_FQ || field == ARK_HIP_BLS12_381_FQ || field == ARK_HIP_BLS12_377_FQ) && op > 5)
+  if ((field == ARK_HIP_BN254_FQ || field == ARK_HIP_BLS12_381_FQ || field == ARK_HIP_BLS12_377_FQ) && op > 5 && !lazy_op)
     return ARK_HIP_ERR_ARG;
   return run_elementwise(n * fb, b ? n * fb : 0, n * fb, a, b, r, field_op_fn(field), op, n);
 }

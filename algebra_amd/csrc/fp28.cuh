@@ -23,6 +23,72 @@
 
 namespace arkhip {
 
+// ---- 64-bit column accumulator, multiply-adds only (device) ----------------------------------------------------
+// One column of a product as ONE dependency chain of v_mad_u64_u32 into a 64-bit accumulator that starts from the
+// previous column's carry: no instruction joins partial sums (the compiler, left to itself, splits a column into two
+// chains and adds them: +27 64-bit additions per product).  Up to 13 products per asm statement (30 operands); hipcc
+// pads statement boundaries with wait states, so a column is at most three statements.
+#define ARK_LM(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\t"
+#define ARK_LT1 ARK_LM(1, 2)
+#define ARK_LT2 ARK_LT1 ARK_LM(3, 4)
+#define ARK_LT3 ARK_LT2 ARK_LM(5, 6)
+#define ARK_LT4 ARK_LT3 ARK_LM(7, 8)
+#define ARK_LT5 ARK_LT4 ARK_LM(9, 10)
+#define ARK_LT6 ARK_LT5 ARK_LM(11, 12)
+#define ARK_LT7 ARK_LT6 ARK_LM(13, 14)
+#define ARK_LT8 ARK_LT7 ARK_LM(15, 16)
+#define ARK_LT9 ARK_LT8 ARK_LM(17, 18)
+#define ARK_LT10 ARK_LT9 ARK_LM(19, 20)
+#define ARK_LT11 ARK_LT10 ARK_LM(21, 22)
+#define ARK_LT12 ARK_LT11 ARK_LM(23, 24)
+#define ARK_LT13 ARK_LT12 ARK_LM(25, 26)
+#define ARK_LOP(i) "v"(x[LO + i]), "s"(PLZ<P, K - LO - i>::v)
+#define ARK_LOP1 ARK_LOP(0)
+#define ARK_LOP2 ARK_LOP1, ARK_LOP(1)
+#define ARK_LOP3 ARK_LOP2, ARK_LOP(2)
+#define ARK_LOP4 ARK_LOP3, ARK_LOP(3)
+#define ARK_LOP5 ARK_LOP4, ARK_LOP(4)
+#define ARK_LOP6 ARK_LOP5, ARK_LOP(5)
+#define ARK_LOP7 ARK_LOP6, ARK_LOP(6)
+#define ARK_LOP8 ARK_LOP7, ARK_LOP(7)
+#define ARK_LOP9 ARK_LOP8, ARK_LOP(8)
+#define ARK_LOP10 ARK_LOP9, ARK_LOP(9)
+#define ARK_LOP11 ARK_LOP10, ARK_LOP(10)
+#define ARK_LOP12 ARK_LOP11, ARK_LOP(11)
+#define ARK_LOP13 ARK_LOP12, ARK_LOP(12)
+#define ARK_LSTMT(n, OPS) \
+  if constexpr (HIX - LO + 1 == n) asm(ARK_LT##n : "+v"(c) : OPS##n : "vcc")
+#define ARK_LALL(OPS)                                                                                       \
+  ARK_LSTMT(1, OPS); ARK_LSTMT(2, OPS); ARK_LSTMT(3, OPS); ARK_LSTMT(4, OPS); ARK_LSTMT(5, OPS); ARK_LSTMT(6, OPS); \
+  ARK_LSTMT(7, OPS); ARK_LSTMT(8, OPS); ARK_LSTMT(9, OPS); ARK_LSTMT(10, OPS); ARK_LSTMT(11, OPS); ARK_LSTMT(12, OPS); \
+  ARK_LSTMT(13, OPS)
+// modulus limbs (28-bit form) as immediates -> SGPRs
+template <class P, int I> struct PLZ { static constexpr u32 v = P::LZ_KP[1][I]; };
+// c += sum_{i = LO..HIX} x[i] * y[K - i]
+template <int LO, int HIX, int K>
+ARK_DEV void lcol_vv(u64& c, const u32* x, const u32* y) {
+  if constexpr (HIX >= LO) {
+    if constexpr (HIX - LO + 1 > 13) {
+      lcol_vv<LO, LO + 12, K>(c, x, y);
+      lcol_vv<LO + 13, HIX, K>(c, x, y);
+    } else {
+      ARK_LALL(ARK_OV);
+    }
+  }
+}
+// c += sum_{i = LO..HIX} m[i] * p[K - i]
+template <class P, int LO, int HIX, int K>
+ARK_DEV void lcol_vp(u64& c, const u32* x) {
+  if constexpr (HIX >= LO) {
+    if constexpr (HIX - LO + 1 > 13) {
+      lcol_vp<P, LO, LO + 12, K>(c, x);
+      lcol_vp<P, LO + 13, HIX, K>(c, x);
+    } else {
+      ARK_LALL(ARK_LOP);
+    }
+  }
+}
+
 template <class P_>
 struct FpL {
   typedef P_ P;
@@ -51,7 +117,7 @@ struct FpL {
   // operand part A_k = sum a_i b_(k-i) of a column depends on nothing but the inputs, the reduction part
   // B_k = carry + sum m_i p_(k-i) on the earlier columns: written as separate sums (one 64-bit addition joins them) the
   // scheduler interleaves column k's reduction chain with column k+1's operand chain.
-  ARK_HD static FpL mul(const FpL& a, const FpL& b) {
+  ARK_HD static FpL mul_c(const FpL& a, const FpL& b) {
     u32 m[L];
     FpL r;
     u64 carry = 0;
@@ -81,37 +147,89 @@ struct FpL {
     r.l[L - 1] = (u32)carry;
     return r;
   }
-  // the single-chain form (kept for the microbenchmark's A/B: csrc/ubench/mulbench.hip)
-  ARK_HD static FpL mul_chain1(const FpL& a, const FpL& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // ---- device forms: every column ONE multiply-add chain (lcol_vv / lcol_vp above) -------------------------------
+  // Product rate at the accumulate kernel's two waves per SIMD (profiles/r3_ubench_product_rate.txt): 75.6 G/s against
+  // 69.3 for the compiler's scheduling of mul_c (which splits each column in two chains and joins them with a 64-bit
+  // addition) and 58.7 for the saturated product.
+  template <int K, int NP>
+  ARK_DEV static void asm_cols_lo(u64& c, const u32* a, const u32* b, const u32* a2, const u32* b2, u32* m) {
+    lcol_vv<0, K, K>(c, a, b);
+    if constexpr (NP == 2) lcol_vv<0, K, K>(c, a2, b2);
+    lcol_vp<P, 0, K - 1, K>(c, m);
+    m[K] = ((u32)c * P::LZ_INV) & MASK;
+    lcol_vp<P, K, K, K>(c, m);
+    c >>= 28;
+    if constexpr (K + 1 < L) asm_cols_lo<K + 1, NP>(c, a, b, a2, b2, m);
+  }
+  template <int K, int NP>
+  ARK_DEV static void asm_cols_hi(u64& c, const u32* a, const u32* b, const u32* a2, const u32* b2, const u32* m, u32* r) {
+    lcol_vv<K - L + 1, L - 1, K>(c, a, b);
+    if constexpr (NP == 2) lcol_vv<K - L + 1, L - 1, K>(c, a2, b2);
+    lcol_vp<P, K - L + 1, L - 1, K>(c, m);
+    r[K - L] = (u32)c & MASK;
+    c >>= 28;
+    if constexpr (K + 1 < 2 * L - 1) asm_cols_hi<K + 1, NP>(c, a, b, a2, b2, m, r);
+  }
+  // squaring columns: cross products a_i * (2 a_(K-i)) for i < K - i, then the diagonal
+  template <int K>
+  ARK_DEV static void asm_sq_lo(u64& c, const u32* a, const u32* d, u32* m) {
+    if constexpr (K >= 1) lcol_vv<0, (K - 1) / 2, K>(c, a, d);
+    if constexpr (K % 2 == 0) lcol_vv<K / 2, K / 2, K>(c, a, a);
+    lcol_vp<P, 0, K - 1, K>(c, m);
+    m[K] = ((u32)c * P::LZ_INV) & MASK;
+    lcol_vp<P, K, K, K>(c, m);
+    c >>= 28;
+    if constexpr (K + 1 < L) asm_sq_lo<K + 1>(c, a, d, m);
+  }
+  template <int K>
+  ARK_DEV static void asm_sq_hi(u64& c, const u32* a, const u32* d, const u32* m, u32* r) {
+    lcol_vv<K - L + 1, (K - 1) / 2, K>(c, a, d);
+    if constexpr (K % 2 == 0) lcol_vv<K / 2, K / 2, K>(c, a, a);
+    lcol_vp<P, K - L + 1, L - 1, K>(c, m);
+    r[K - L] = (u32)c & MASK;
+    c >>= 28;
+    if constexpr (K + 1 < 2 * L - 1) asm_sq_hi<K + 1>(c, a, d, m, r);
+  }
+  ARK_DEV static FpL mul(const FpL& a, const FpL& b) {
     u32 m[L];
     FpL r;
-    u64 acc = 0;
-#pragma unroll
-    for (int k = 0; k < L; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) acc += (u64)a.l[i] * b.l[k - i];
-#pragma unroll
-      for (int i = 0; i < k; i++) acc += (u64)m[i] * P::LZ_KP[1][k - i];
-      m[k] = ((u32)acc * P::LZ_INV) & MASK;
-      acc += (u64)m[k] * P::LZ_KP[1][0];
-      acc >>= 28;
-    }
-#pragma unroll
-    for (int k = L; k < 2 * L - 1; k++) {
-#pragma unroll
-      for (int i = k - L + 1; i < L; i++) acc += (u64)a.l[i] * b.l[k - i];
-#pragma unroll
-      for (int i = k - L + 1; i < L; i++) acc += (u64)m[i] * P::LZ_KP[1][k - i];
-      r.l[k - L] = (u32)acc & MASK;
-      acc >>= 28;
-    }
-    r.l[L - 1] = (u32)acc;
+    u64 c = 0;
+    asm_cols_lo<0, 1>(c, a.l, b.l, nullptr, nullptr, m);
+    asm_cols_hi<L, 1>(c, a.l, b.l, nullptr, nullptr, m, r.l);
+    r.l[L - 1] = (u32)c;
     return r;
   }
+  ARK_DEV static FpL sop2(const FpL& a, const FpL& b, const FpL& x, const FpL& y) {
+    u32 m[L];
+    FpL r;
+    u64 c = 0;
+    asm_cols_lo<0, 2>(c, a.l, b.l, x.l, y.l, m);
+    asm_cols_hi<L, 2>(c, a.l, b.l, x.l, y.l, m, r.l);
+    r.l[L - 1] = (u32)c;
+    return r;
+  }
+  ARK_DEV static FpL sqr(const FpL& a) {
+    u32 m[L], d[L];
+    FpL r;
+#pragma unroll
+    for (int i = 0; i < L; i++) d[i] = a.l[i] << 1;
+    u64 c = 0;
+    asm_sq_lo<0>(c, a.l, d, m);
+    asm_sq_hi<L>(c, a.l, d, m, r.l);
+    r.l[L - 1] = (u32)c;
+    return r;
+  }
+#else
+  // host (tests/lazy_host_check.hip; the window combine never uses this form): the portable statements
+  static FpL mul(const FpL& a, const FpL& b) { return mul_c(a, b); }
+  static FpL sqr(const FpL& a) { return sqr_c(a); }
+  static FpL sop2(const FpL& a, const FpL& b, const FpL& x, const FpL& y) { return sop2_c(a, b, x, y); }
+#endif
   // a^2 of a normalised or semi-normalised a (limbs < 3 2^28): every cross product once, against the doubled limb (< 6 2^28;
   // per column at most 7 x 18 2^56 + 9 2^56 + 14 x 2^56 + carry < 2^63.3).  105 + 196 multiply-adds instead of 392.
   // (The saturated form's dedicated square lost to mul(a, a) on its doubling carries -- DESIGN 4; here doubling is a shift.)
-  ARK_HD static FpL sqr(const FpL& a) {
+  ARK_HD static FpL sqr_c(const FpL& a) {
     u32 m[L], d[L];
     FpL r;
 #pragma unroll
@@ -148,7 +266,7 @@ struct FpL {
   // a b + c d under ONE reduction (montgomery_backend.rs:415-516 sum_of_products, M = 2): the Y3 of every bucket
   // addition.  All four operands normalised (28 products + 14 reduction terms of < 2^56 per column: < 2^62);
   // output normalised, below (a b + c d) / 2^(28 L) + p.
-  ARK_HD static FpL sop2(const FpL& a, const FpL& b, const FpL& c, const FpL& d) {
+  ARK_HD static FpL sop2_c(const FpL& a, const FpL& b, const FpL& c, const FpL& d) {
     u32 m[L];
     FpL r;
     u64 carry = 0;
@@ -365,7 +483,14 @@ struct FpL {
   template <int K>
   ARK_HD FpL shr_mod() const {
     static_assert(K >= 1 && K <= 24, "single-limb step");
-    const u32 m = (l[0] * P::LZ_INV) & ((1u << K) - 1u);   // v + m p = 0 mod 2^K
+    u32 m = (l[0] * P::LZ_INV) & ((1u << K) - 1u);   // v + m p = 0 mod 2^K
+#if defined(__HIP_DEVICE_COMPILE__)
+    // hipcc (ROCm 7.2) miscompiles  (u64)(x & 0xffffff) * c  for a constant c < 2^24: both operands qualify for the 24-bit
+    // multiplier, whose demanded-bits rule drops the mask, and the product is then emitted as a full v_mad_u64_u32 on
+    // the UNMASKED x (seen with K = 24 on the 256-bit fields: csrc/ubench/lazycheck.hip; with K <= 8, the only case the
+    // accumulate kernels use, the product fits 32 bits and a genuine 24-bit multiply is emitted).  Hide the known bits.
+    asm volatile("" : "+v"(m));
+#endif
     u32 t[L + 1];
     u64 acc = 0;
 #pragma unroll

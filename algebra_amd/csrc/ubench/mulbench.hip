@@ -1,6 +1,6 @@
 // Product-rate microbenchmark of the two Fp384 multiplications the accumulate kernels can run on (BLS12-381 Fq):
-// fp.cuh's saturated 32-bit Comba product against fp28.cuh's carry-free 28-bit forms (single chain, two chains,
-// dedicated square, sum of two products), back to back in a loop at 1 / 2 / 4 / 8 waves per SIMD.
+// fp.cuh's saturated 32-bit Comba product against fp28.cuh's carry-free 28-bit forms (compiler-scheduled and asm
+// columns, dedicated square, sum of two products), back to back in a loop at 1 / 2 / 4 / 8 waves per SIMD.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I.. mulbench.hip -o mulbench.bin
 #include "../fp28.cuh"
 #include <stdio.h>
@@ -13,10 +13,11 @@ template <int V> __global__ void __launch_bounds__(256) k_lazy(u32* out, int ite
   for (int i = 0; i < L::L; i++) { a.l[i] = (tid * 2654435761u * (i + 1)) & L::MASK; b.l[i] = ((tid ^ 77) * 40503u * (i + 3)) & L::MASK; }
   a.l[L::L - 1] &= 0xffff; b.l[L::L - 1] &= 0xffff;
   for (int k = 0; k < iters; k++) {
-    if constexpr (V == 0) a = L::mul_chain1(a, b);
+    if constexpr (V == 0) a = L::mul_c(a, b);
     else if constexpr (V == 1) a = L::mul(a, b);
     else if constexpr (V == 2) a = L::sqr(a);
-    else a = L::sop2(a, b, b, a);
+    else if constexpr (V == 3) a = L::sop2(a, b, b, a);
+    else a = L::sqr_c(a);
   }
   u32 r = 0;
   for (int i = 0; i < L::L; i++) r ^= a.l[i];
@@ -39,9 +40,9 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 2000;
-  const char* names[5] = {"lazy28 mul, one chain ", "lazy28 mul, two chains", "lazy28 sqr            ", "lazy28 sop2 (a b + c d)", "sat32  mul (fp.cuh)   "};
+  const char* names[6] = {"lazy28 mul, compiler-scheduled columns", "lazy28 mul  (asm: one chain per column)", "lazy28 sqr  (asm)                      ", "lazy28 sop2 (asm: a b + c d)           ", "lazy28 sqr, compiler-scheduled         ", "sat32  mul  (fp.cuh)                   "};
   for (int w : {1, 2, 4, 8}) {
-    for (int v = 0; v < 5; v++) {
+    for (int v = 0; v < 6; v++) {
       int b = 256 * w;
       auto launch = [&](int it) {
         switch (v) {
@@ -49,6 +50,7 @@ int main() {
           case 1: hipLaunchKernelGGL((k_lazy<1>), dim3(b), dim3(256), 0, 0, out, it); break;
           case 2: hipLaunchKernelGGL((k_lazy<2>), dim3(b), dim3(256), 0, 0, out, it); break;
           case 3: hipLaunchKernelGGL((k_lazy<3>), dim3(b), dim3(256), 0, 0, out, it); break;
+          case 4: hipLaunchKernelGGL((k_lazy<4>), dim3(b), dim3(256), 0, 0, out, it); break;
           default: hipLaunchKernelGGL(k_sat, dim3(b), dim3(256), 0, 0, out, it);
         }
       };

@@ -142,16 +142,37 @@ def main():
         # library's own (the data path: ark_hip_msm_sw_device_sharded / ark_hip_fft_sharded_device) and, as the fallback
         # exchange should that fail on this box, torch.distributed's
         D.combine_partials(cid, np.zeros(cv.projective_words(cid), dtype=np.uint64))
+        def all_ranks(ok):
+            f = torch.tensor([1.0 if ok else 0.0], device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return f.item() != 0.0
+        why = ""
         try:
             ok = D.comm_init()
-            exchange = "RCCL inside libark_hip.so (ark_hip_msm_sw_device_sharded)" if ok else \
-                "torch.distributed all_gather (%s backend)" % backend
         except Exception as e:  # noqa: BLE001 -- the headline must survive a communicator problem
-            exchange = "torch.distributed all_gather (library communicator failed: %s)" % repr(e)[:120]
-        flags = torch.tensor([1.0 if D.library_comm_active() else 0.0], device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(flags, op=dist.ReduceOp.MIN)   # all ranks or none
-        if flags.item() == 0.0 and D.library_comm_active():
-            D.comm_destroy()
+            ok, why = False, repr(e)[:120]
+        if backend == "nccl" and all_ranks(ok):
+            # pre-flight: one tiny sharded MSM (4 pairs per rank, k * G checked below by the real job's own check) so that
+            # a collective that cannot run on this box is found here, on every rank at once, not inside the timed region
+            try:
+                tb = S.grow_bases(cid, 4, (A0 + rank * 4 * B0) % R_MOD, B0, R_MOD)
+                ts = torch.from_numpy(gen_scalars(4, 0x7E57 + rank).view(np.int64)).cuda()
+                torch.cuda.synchronize()
+                D.msm_bigint_sharded(cid, tb, ts)
+                ok2 = True
+            except Exception as e:  # noqa: BLE001
+                ok2, why = False, repr(e)[:120]
+            if not all_ranks(ok2):
+                ok = False
+        else:
+            ok = False
+        if not ok and D.library_comm_active():
+            try:
+                D.comm_destroy()
+            except Exception:  # noqa: BLE001
+                D._LIB_COMM["world"] = 0
+        exchange = "RCCL inside libark_hip.so (ark_hip_msm_sw_device_sharded)" if ok else \
+            "torch.distributed all_gather (%s backend%s)" % (backend, "; library communicator unavailable: " + why if why else "")
 
     if world == 1:
         exchange = "none (one GPU)"

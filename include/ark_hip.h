@@ -316,7 +316,8 @@ int ark_hip_fft_last_timing(double out[10]);
 
 /* ---- device-arithmetic test hooks (used by tests/ to check the kernels' field and point
  * arithmetic against the oracle; host pointers) ----
- * op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 dbl, 7 into_bigint, 8 from_bigint */
+ * op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 dbl, 7 into_bigint, 8 from_bigint; 20 / 21 / 22: x y, x^2, 2 x y computed through
+ * the carry-free 28-bit-limb form of the accumulate kernels (device product, square, sum of two products) */
 int ark_hip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
 int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
 /* kind: 2 bucket += affine, 3 bucket -= affine, 4 bucket += bucket, 5 bucket double, 6 bucket -> jacobian,

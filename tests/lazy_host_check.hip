@@ -51,7 +51,7 @@ template <class P> int run(const char* name, const uint64_t* gen) {
     L la = to_lazy<P>(a), lb = to_lazy<P>(b), lc = to_lazy<P>(c), ld = to_lazy<P>(d);
     if (!F::eq(lazy_value<P>(la), a)) { bad++; if (bad < 5) printf("%s roundtrip fail\n", name); }
     if (!F::eq(lazy_value<P>(L::mul(la, lb)), F::mul(a, b))) { bad++; if (bad < 5) printf("%s mul fail\n", name); }
-    if (!F::eq(lazy_value<P>(L::mul_chain1(la, lb)), F::mul(a, b))) { bad++; if (bad < 5) printf("%s mul_chain1 fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul_c(la, lb)), F::mul(a, b))) { bad++; if (bad < 5) printf("%s mul_c fail\n", name); }
     if (!F::eq(lazy_value<P>(L::sqr(la)), F::mul(a, a))) { bad++; if (bad < 5) printf("%s sqr fail\n", name); }
     if (!F::eq(lazy_value<P>(L::sqr(L::template sub<6>(la, lb))), F::mul(F::sub(a, b), F::sub(a, b)))) { bad++; if (bad < 5) printf("%s sqr(sub<6>) fail\n", name); }
     if (!F::eq(lazy_value<P>(L::sop2(la, lb, lc, ld)), F::add(F::mul(a, b), F::mul(c, d)))) { bad++; if (bad < 5) printf("%s sop2 fail\n", name); }

@@ -40,6 +40,19 @@ def test_field_ops_match_oracle(fname):
         assert np.array_equal(got.reshape(-1), exp.reshape(-1)), (fname, op)
 
 
+@pytest.mark.parametrize("fname", O.FIELDS)
+def test_lazy_28bit_device_forms_match_oracle(fname):
+    """fp28.cuh's product / square / sum of two products as the DEVICE runs them (one asm multiply-add chain per column),
+    on every field: operands enter by the shifted repack, results leave through shr_mod + one conditional subtraction --
+    the path of a bucket through the accumulate kernels -- and must equal the reference's canonical product."""
+    fid = O.FID[fname]
+    a, b = _field_inputs(fid, 4096, 77 + fid)
+    mul = O.field_op(fid, "mul", a, b)
+    assert np.array_equal(H.field_op(fid, "lazy_mul", a, b).reshape(-1), mul.reshape(-1)), fname
+    assert np.array_equal(H.field_op(fid, "lazy_sqr", a, None).reshape(-1), O.field_op(fid, "sqr", a, None).reshape(-1)), fname
+    assert np.array_equal(H.field_op(fid, "lazy_sop2", a, b).reshape(-1), O.field_op(fid, "dbl", mul, None).reshape(-1)), fname
+
+
 @pytest.mark.parametrize("cname", ["BLS12_377_G2", "BLS12_381_G2"])
 def test_fp2_ops_match_oracle(cname):
     cid = O.CID[cname]
