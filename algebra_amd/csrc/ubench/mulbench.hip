@@ -34,12 +34,38 @@ __global__ void __launch_bounds__(256) k_sat(u32* out, int iters) {
   for (int i = 0; i < F::N; i++) r ^= a.l[i];
   out[tid] = r;
 }
+// issue peak of v_mad_u64_u32: four independent accumulator chains per lane, 32 instructions per asm statement
+__global__ void __launch_bounds__(256) k_mad_peak(u64* out, int iters, u32 mask) {
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  u64 a0 = tid, a1 = tid + 1, a2 = tid + 2, a3 = tid + 3;
+  const u32 x = (tid * 2654435761u | 0x80000001u) & mask, y = ((tid * 40503u + 7u) | 0x80000000u) & mask;   // operands of `bits` significant bits
+#define ARK_M4 "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\tv_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_mad_u64_u32 %3, vcc, %4, %5, %3\n\t"
+  for (int k = 0; k < iters; k++)
+    asm volatile(ARK_M4 ARK_M4 ARK_M4 ARK_M4 ARK_M4 ARK_M4 ARK_M4 ARK_M4 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y) : "vcc");
+  out[tid] = a0 ^ a1 ^ a2 ^ a3;
+}
 int main() {
   u32* out;
-  if (hipMalloc(&out, 256 * 8 * 256 * 4 * 4) != hipSuccess) return 1;
+  if (hipMalloc(&out, 256 * 8 * 256 * 4 * 4 * 2) != hipSuccess) return 1;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 2000;
+  for (int bits : {32, 28, 24, 16}) {
+    for (int w : {2, 8}) {
+      const int b = 256 * w, it = 4000;
+      const u32 mask = bits == 32 ? 0xffffffffu : ((1u << bits) - 1u);
+      hipLaunchKernelGGL(k_mad_peak, dim3(b), dim3(256), 0, 0, (u64*)out, 10, mask);
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(k_mad_peak, dim3(b), dim3(256), 0, 0, (u64*)out, it, mask);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("v_mad_u64_u32 alone, 4 chains per lane, %2d-bit operands  waves/SIMD=%d  %8.3f ms  %8.2f T lane-ops/s\n", bits, w, ms,
+             (double)b * 256 * it * 32 / (ms * 1e-3) * 1e-12);
+    }
+  }
   const char* names[6] = {"lazy28 mul, compiler-scheduled columns", "lazy28 mul  (asm: one chain per column)", "lazy28 sqr  (asm)                      ", "lazy28 sop2 (asm: a b + c d)           ", "lazy28 sqr, compiler-scheduled         ", "sat32  mul  (fp.cuh)                   "};
   for (int w : {1, 2, 4, 8}) {
     for (int v = 0; v < 6; v++) {

@@ -549,7 +549,10 @@ def main():
                                                         "saturated 32-bit limbs: 8 products + one two-product sum"),
                                  "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
                                  "frac": mads_per_s / MAD_U64_U32_PER_S,
-                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32)"},
+                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32); re-measured in "
+                                                "round 3 with four independent chains per lane: 28.1-30.6e12/s at eight "
+                                                "waves per SIMD across boxes, 23.7e12/s at the kernel's two waves "
+                                                "(profiles/r3_ubench_product_rate.txt)"},
                          "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
             "cpu_baseline": cpu,
             "trait_surface": trait,
