@@ -63,15 +63,11 @@ ARK_HD XYZZ<Fp<P>> lazy_to_bucket(const XYZZL<P>& a) {
   return r;
 }
 
-// affine doubling (mdbl-2008-s-1, a = 0), all in 28-bit limbs, of the base at `src` (reference layout, canonical limbs;
-// neg: the digit's sign).  Rare branch (equal points in one bucket): out of line, and it re-reads the base, so that
-// nothing of the hot loop has to stay alive for it.
+// affine doubling (mdbl-2008-s-1, a = 0), all in 28-bit limbs; x2, y2 the operands of lazy_from_affine (< 256 p).  Rare
+// branch (equal points in one bucket): out of line so that its registers do not burden the hot loops.
 template <class P>
-__host__ __device__ __attribute__((noinline)) void xyzz_mdbl_lazy(XYZZL<P>& acc, const char* src, bool neg) {
+__host__ __device__ __attribute__((noinline)) void xyzz_mdbl_lazy_xy(XYZZL<P>& acc, const FpL<P>& x2, const FpL<P>& y2) {
   typedef FpL<P> F;
-  const Affine<Fp<P>> b = Affine<Fp<P>>::load(src);
-  F x2, y2;
-  lazy_from_affine<P>(b.x, Fp<P>::cond_neg(b.y, neg), x2, y2);
   const F one = F::one();
   const F x1 = F::mul(x2, one);                                   // < 1.13 (n)
   const F y = F::mul(y2, one);                                    // < 1.13 (n)
@@ -87,6 +83,15 @@ __host__ __device__ __attribute__((noinline)) void xyzz_mdbl_lazy(XYZZL<P>& acc,
   acc.zz = v;
   acc.zzz = w;
   acc.inf = false;
+}
+// the same for the base at `src` (reference layout, canonical limbs; neg: the digit's sign): the accumulate kernels'
+// form -- it re-reads the base, so that nothing of their hot loop has to stay alive for a doubling that almost never comes
+template <class P>
+__host__ __device__ __attribute__((noinline)) void xyzz_mdbl_lazy(XYZZL<P>& acc, const char* src, bool neg) {
+  const Affine<Fp<P>> b = Affine<Fp<P>>::load(src);
+  FpL<P> x2, y2;
+  lazy_from_affine<P>(b.x, Fp<P>::cond_neg(b.y, neg), x2, y2);
+  xyzz_mdbl_lazy_xy<P>(acc, x2, y2);
 }
 
 // acc += (x2, y2): a non-identity base from lazy_from_affine (x2, y2 < 256, n; the digit's sign is in y2 already).
@@ -126,6 +131,71 @@ ARK_HD bool xyzz_madd_lazy(XYZZL<P>& acc, const FpL<P>& x2, const FpL<P>& y2) {
   acc.zzz = F::mul(acc.zzz, ppp);                                 // < 1.01
   acc.x = x3;
   return false;
+}
+
+// ---- full addition (the reduction and heavy-run kernels) ------------------------------------------------------------
+// acc += b, add-2008-s (bucket.rs:256-337) in 28-bit limbs.  b's coordinates may be a stored bucket's canonical limbs
+// repacked (below 256 p: lazy_operands_of) or another accumulator's (small): they enter through products with acc's
+// small coordinates only.  Bounds for the large case:
+//   U1 = X1 ZZ2 < 5.01 * 256 / 2048 + 1 < 1.63, U2 = X2 ZZ1 < 1.13, S1 = Y1 ZZZ2 < 1.15, S2 = Y2 ZZZ1 < 1.13  (n)
+//   P = U2 - U1 + 2p in (0.37, 3.13), R = S2 - S1 + 2p in (0.85, 3.13)  (s);  PP < 1.01, PPP, Q < 1.01  (n)
+//   X3 = R^2 - PPP - 2 Q + 4p in (0.99, 5.01) (n);  Y3 < (3.13 * 7.01 + 2 * 1.01) / 2048 + 1 < 1.02;  ZZ3, ZZZ3 < 1.01
+// equal points (P = R = 0 mod p): the doubling goes through the canonical form and the saturated formulas (rare).
+template <class P>
+struct XYZZOperands { FpL<P> x, y, zz, zzz; bool inf; };
+template <class P>
+ARK_HD XYZZOperands<P> lazy_operands_of(const XYZZ<Fp<P>>& b) {   // a stored bucket as multiplication operands
+  XYZZOperands<P> r;
+  r.inf = b.is_zero();
+  r.x = FpL<P>::unpack32_shl(b.x.l);
+  r.y = FpL<P>::unpack32_shl(b.y.l);
+  r.zz = FpL<P>::unpack32_shl(b.zz.l);
+  r.zzz = FpL<P>::unpack32_shl(b.zzz.l);
+  return r;
+}
+template <class P>
+__host__ __device__ __attribute__((noinline)) void xyzz_dbl_via_canonical(XYZZL<P>& acc) {
+  const XYZZ<Fp<P>> c = lazy_to_bucket<P>(acc);
+  acc = lazy_from_bucket<P>(xyzz_dbl<Fp<P>>(c));
+}
+template <class P>
+ARK_HD void xyzz_add_lazy(XYZZL<P>& acc, const FpL<P>& bx, const FpL<P>& by, const FpL<P>& bzz, const FpL<P>& bzzz, bool binf) {
+  typedef FpL<P> F;
+  if (binf) return;
+  if (acc.inf) {   // acc = b, brought below 1.13 p
+    const F one = F::one();
+    acc.x = F::mul(bx, one);
+    acc.y = F::mul(by, one);
+    acc.zz = F::mul(bzz, one);
+    acc.zzz = F::mul(bzzz, one);
+    acc.inf = false;
+    return;
+  }
+  const F u1 = F::mul(acc.x, bzz);
+  const F u2 = F::mul(bx, acc.zz);
+  const F s1 = F::mul(acc.y, bzzz);
+  const F s2 = F::mul(by, acc.zzz);
+  const F pd = F::template sub_semi<2>(u2, u1);
+  const F rd = F::template sub_semi<2>(s2, s1);
+  const F pp = F::sqr(pd);
+  if (pp.is_zero_or_p()) {
+    if (F::sqr(rd).is_zero_or_p()) {
+      XYZZL<P> d = acc;   // a copy goes out of line (an accumulator whose address escapes would live in scratch memory)
+      xyzz_dbl_via_canonical<P>(d);
+      acc = d;
+    } else {
+      acc.inf = true;
+    }
+    return;
+  }
+  const F ppp = F::mul(pd, pp);
+  const F q = F::mul(u1, pp);
+  const F x3 = F::template sub_b_2c_norm<4>(F::sqr(rd), ppp, q);
+  const F t = F::template sub_semi<6>(q, x3);
+  acc.y = F::sop2(rd, t, F::template neg_semi<2>(s1), ppp);
+  acc.zz = F::mul(F::mul(acc.zz, bzz), pp);
+  acc.zzz = F::mul(F::mul(acc.zzz, bzzz), ppp);
+  acc.x = x3;
 }
 
 }  // namespace arkhip

@@ -669,35 +669,120 @@ static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* _
   for (u32 q = 0; q < k; q++) items[first + q] = make_uint2(g, q);
 }
 
-// Point additions of the reduction / heavy-run kernels on the accumulate field C::FA: relaxed residues where the
-// curve's field allows it, one element per lane (Fp) or per lane PAIR (Fp2Half; index arithmetic below is in "slots"
-// = lanes / LANES, and every branch is uniform over a pair).
+// Point additions of the reduction / heavy-run kernels.  `Pt` is a point as it lives in memory (canonical XYZZ over the
+// accumulate field C::FA), `Acc` the form it is summed in:
+//   * saturated limbs (BN254, the Fp2 curves): Acc = Pt on relaxed residues where the field allows it, one element per
+//     lane (Fp) or per lane PAIR (Fp2Half; index arithmetic below is in "slots" = lanes / LANES, every branch uniform
+//     over a pair);
+//   * carry-free 28-bit limbs (the Fp384 G1 curves, C::LAZY_A): Acc = XYZZL, memory operands enter by the shifted
+//     repack (ec28.cuh: xyzz_add_lazy) -- the full addition's 10 products + 2 squares + one two-product sum at the
+//     28-bit product's rate instead of 12 + 2 + 1.5 at the saturated one's.
+#ifndef ARK_REDUCE_LAZY
+#define ARK_REDUCE_LAZY 1   // 0: the reduction / heavy-run kernels of the Fp384 G1 curves on saturated limbs too (A/B builds)
+#endif
+template <class C, bool LAZY = (C::LAZY_A && ARK_REDUCE_LAZY != 0)>
+struct AccOps;
+
 template <class C>
-struct AccOps {
+struct AccOps<C, false> {
   typedef typename C::FA F;
   typedef XYZZ<F> Pt;
+  typedef Pt Acc;
   static constexpr u32 LANES = F::LANES;
-  ARK_DEV static void madd(Pt& acc, const F& x, const F& y) {
+  static constexpr size_t ACC_BYTES = Pt::BYTES;   // one accumulator parked in LDS
+  ARK_DEV static Acc zero() { return Pt::zero(); }
+  ARK_DEV static Acc from_pt(const Pt& p) { return p; }
+  ARK_DEV static void madd(Acc& acc, const F& x, const F& y) {
     if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, x, y);
     else xyzz_madd<F>(acc, x, y);
   }
-  ARK_DEV static void add(Pt& acc, const Pt& b) {
+  ARK_DEV static void add(Acc& acc, const Pt& b) {
     if constexpr (C::RELAXED_A) xyzz_add_relaxed<F>(acc, b);
     else xyzz_add<F>(acc, b);
   }
-  ARK_DEV static Pt fin(const Pt& a) {  // canonical form for memory
+  ARK_DEV static void add_acc(Acc& acc, const Acc& b) { add(acc, b); }
+  ARK_DEV static Pt fin(const Acc& a) {  // canonical form for memory
     if constexpr (C::RELAXED_A) return xyzz_canonical<F>(a);
     else return a;
   }
+  ARK_DEV static void park(const Acc& a, char* slot) { a.store(slot); }
+  ARK_DEV static Acc unpark(const char* slot) { return Pt::load(slot); }
   // sum over the `width` slots of an LDS array of per-slot partials (width a power of two); result in slot 0's acc
-  ARK_DEV static void tree(Pt& acc, char* sh, u32 slot, u32 width) {
-    acc.store(sh + (size_t)slot * Pt::BYTES);
+  ARK_DEV static void tree(Acc& acc, char* sh, u32 slot, u32 width) {
+    park(acc, sh + (size_t)slot * ACC_BYTES);
     __syncthreads();
     for (u32 o = width / 2; o > 0; o >>= 1) {
       if (slot < o) {
-        Pt other = Pt::load(sh + (size_t)(slot + o) * Pt::BYTES);
-        add(acc, other);
-        acc.store(sh + (size_t)slot * Pt::BYTES);
+        add_acc(acc, unpark(sh + (size_t)(slot + o) * ACC_BYTES));
+        park(acc, sh + (size_t)slot * ACC_BYTES);
+      }
+      __syncthreads();
+    }
+  }
+};
+
+template <class C>
+struct AccOps<C, true> {
+  typedef typename C::F F;       // Fp<P>: the Fp384 G1 curves
+  typedef typename F::P P;
+  typedef FpL<P> FL;
+  typedef XYZZ<F> Pt;
+  typedef XYZZL<P> Acc;
+  static constexpr u32 LANES = 1;
+  static constexpr size_t ACC_BYTES = ((4 * FL::L + 1) * 4 + 15) / 16 * 16;   // 4 x 14 limbs + the infinity flag: 240 B
+  ARK_DEV static Acc zero() {
+    Acc a;
+    a.inf = true;
+    a.x = a.y = a.zz = a.zzz = FL::zero();
+    return a;
+  }
+  ARK_DEV static Acc from_pt(const Pt& p) { return lazy_from_bucket<P>(p); }
+  ARK_DEV static void madd(Acc& acc, const F& x, const F& y) {   // (x, y): a non-identity base, the digit's sign in y
+    FL lx, ly;
+    lazy_from_affine<P>(x, y, lx, ly);
+    if (xyzz_madd_lazy<P>(acc, lx, ly)) {   // equal points
+      Acc d;
+      xyzz_mdbl_lazy_xy<P>(d, lx, ly);
+      acc = d;
+    }
+  }
+  ARK_DEV static void add(Acc& acc, const Pt& b) {
+    const XYZZOperands<P> o = lazy_operands_of<P>(b);
+    xyzz_add_lazy<P>(acc, o.x, o.y, o.zz, o.zzz, o.inf);
+  }
+  ARK_DEV static void add_acc(Acc& acc, const Acc& b) { xyzz_add_lazy<P>(acc, b.x, b.y, b.zz, b.zzz, b.inf); }
+  ARK_DEV static Pt fin(const Acc& a) { return lazy_to_bucket<P>(a); }
+  ARK_DEV static void park(const Acc& a, char* slot) {
+    u32* w = (u32*)slot;
+#pragma unroll
+    for (int i = 0; i < FL::L; i++) {
+      w[i] = a.x.l[i];
+      w[FL::L + i] = a.y.l[i];
+      w[2 * FL::L + i] = a.zz.l[i];
+      w[3 * FL::L + i] = a.zzz.l[i];
+    }
+    w[4 * FL::L] = a.inf ? 1u : 0u;
+  }
+  ARK_DEV static Acc unpark(const char* slot) {
+    const u32* w = (const u32*)slot;
+    Acc a;
+#pragma unroll
+    for (int i = 0; i < FL::L; i++) {
+      a.x.l[i] = w[i];
+      a.y.l[i] = w[FL::L + i];
+      a.zz.l[i] = w[2 * FL::L + i];
+      a.zzz.l[i] = w[3 * FL::L + i];
+    }
+    a.inf = w[4 * FL::L] != 0u;
+    return a;
+  }
+  ARK_DEV static void tree(Acc& acc, char* sh, u32 slot, u32 width) {
+    park(acc, sh + (size_t)slot * ACC_BYTES);
+    __syncthreads();
+    for (u32 o = width / 2; o > 0; o >>= 1) {
+      if (slot < o) {
+        add_acc(acc, unpark(sh + (size_t)(slot + o) * ACC_BYTES));
+        park(acc, sh + (size_t)slot * ACC_BYTES);
       }
       __syncthreads();
     }
@@ -719,12 +804,12 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
   constexpr u32 NS = 64 / Ops::LANES;  // slots per wave
   extern __shared__ uint4 heavy_lds[];
   const u32 wave = threadIdx.x >> 6, slot = (threadIdx.x & 63) / Ops::LANES, wpb = blockDim.x >> 6;
-  char* sh = (char*)heavy_lds + (size_t)wave * NS * Pt::BYTES;
+  char* sh = (char*)heavy_lds + (size_t)wave * NS * Ops::ACC_BYTES;
   const u32 nitems = ctr[0];
   for (u32 first = blockIdx.x * wpb; first < nitems; first += gridDim.x * wpb) {
     const u32 item = first + wave;
     const bool live = item < nitems;
-    Pt acc = Pt::zero();
+    typename Ops::Acc acc = Ops::zero();
     if (live) {
       uint2 it = items[item];
       u32 lo = offsets[it.x] + it.y * HEAVY_CHUNK;
@@ -736,7 +821,7 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
         Affine<F> p = Affine<F>::load(wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
         if (!p.is_zero()) {
           F y = p.y;  // negative digit: -P.  On relaxed residues 2p - y serves (a multiplication operand; no zero test)
-          if constexpr (C::RELAXED_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
+          if constexpr (C::RELAXED_A && !C::LAZY_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
           else y = F::cond_neg(p.y, (e >> 31) != 0);
           Ops::madd(acc, p.x, y);
         }
@@ -766,7 +851,7 @@ __global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __rest
   const u32 nheavy = ctr[1];
   for (u32 hslot = blockIdx.x; hslot < nheavy; hslot += gridDim.x) {  // uniform for the whole workgroup
     HeavyEntry h = list[hslot];
-    Pt acc = Pt::zero();
+    typename Ops::Acc acc = Ops::zero();
     for (u32 q = slot; q < h.items; q += NS) {
       Pt x = Pt::load(partials + (size_t)(h.first_item + q) * Pt::BYTES);
       Ops::add(acc, x);
@@ -812,7 +897,7 @@ __global__ void __launch_bounds__(64) msm_apply_heavy_kernel(const u32* __restri
     }
     if (!owner) continue;
     char* cell = buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * Pt::BYTES;
-    Pt acc = Pt::load(cell);
+    typename Ops::Acc acc = Ops::from_pt(Pt::load(cell));
     for (u32 w = w0; w < (u32)W; w++) {
       const u32 gg = (w << B) | s;
       const u32 a2 = offsets[gg];
@@ -839,20 +924,19 @@ __global__ void __launch_bounds__(128, 2) msm_reduce_level_kernel(const char* __
   const size_t base = (size_t)t * L;
   // the weighted sum A lives in LDS between its updates (one 4-coordinate slot per lane, or per lane pair over Fp2): two
   // accumulators + the loaded bucket + an addition's temporaries do not fit 256 registers (they spilled 16 B to scratch)
-  __shared__ uint4 park_lds[128 * 192 / 16];
-  static_assert((128 / Ops::LANES) * Pt::BYTES <= sizeof(uint4) * (128 * 192 / 16), "LDS slot size");
-  char* slot = (char*)park_lds + (size_t)(threadIdx.x / Ops::LANES) * Pt::BYTES;
-  Pt running = Pt::zero();
-  running.store(slot);
+  __shared__ uint4 park_lds[(128 / Ops::LANES) * Ops::ACC_BYTES / 16];
+  char* slot = (char*)park_lds + (size_t)(threadIdx.x / Ops::LANES) * Ops::ACC_BYTES;
+  typename Ops::Acc running = Ops::zero();
+  Ops::park(running, slot);
   for (u32 r = L; r-- > 0;) {
     Pt x = Pt::load(in + (base + r) * Pt::BYTES);
     Ops::add(running, x);
-    Pt acc = Pt::load(slot);
-    Ops::add(acc, running);
-    acc.store(slot);
+    typename Ops::Acc acc = Ops::unpark(slot);
+    Ops::add_acc(acc, running);
+    Ops::park(acc, slot);
   }
   Ops::fin(running).store(outS + (size_t)t * Pt::BYTES);
-  Ops::fin(Pt::load(slot)).store(outA + (size_t)t * Pt::BYTES);
+  Ops::fin(Ops::unpark(slot)).store(outA + (size_t)t * Pt::BYTES);
 }
 
 // ---- K5b: the rest of the reduction, bit-sliced -------------------------------------------------------
@@ -873,7 +957,7 @@ __global__ void __launch_bounds__(256) msm_reduce_bits_kernel(const char* __rest
   const u32 slot = threadIdx.x / Ops::LANES, nslots = blockDim.x / Ops::LANES;
   const bool plain = (int)q == nbits;
   const char* src = plain ? A : S;
-  Pt acc = Pt::zero();
+  typename Ops::Acc acc = Ops::zero();
   for (u32 e = slot; e < chunk; e += nslots) {
     u32 j = ch * chunk + e;
     if (j < m && (plain || ((j >> q) & 1u))) {
@@ -897,7 +981,7 @@ __global__ void __launch_bounds__(64) msm_sum_chunks_kernel(const char* __restri
   char* sh = (char*)chunk_lds;
   const u32 t = blockIdx.x, slot = threadIdx.x / Ops::LANES;
   if (t >= npairs) return;
-  Pt acc = Pt::zero();
+  typename Ops::Acc acc = Ops::zero();
   for (u32 k = slot; k < nchunks; k += NS) {
     Pt x = Pt::load(partial + ((size_t)t * nchunks + k) * Pt::BYTES);
     Ops::add(acc, x);
@@ -1322,17 +1406,18 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
                        forced_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
     constexpr u32 LN = C::FA::LANES;                        // lanes per element of the accumulate field
-    const u32 hthreads = Pt::BYTES * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
-    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * Pt::BYTES, stream,
+    constexpr size_t ACCB = AccOps<C>::ACC_BYTES;           // one parked accumulator (the form the kernels sum in)
+    const u32 hthreads = ACCB * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
+    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * ACCB, stream,
                        (const char*)d_points, sorted, offsets, hctr, (const uint2*)ws.hitems.p, wstride, Bbits,
                        (char*)ws.hpart.p);
     const u32 combine_grid = max_heavy < 16384 ? (u32)max_heavy : 16384u;  // grid-stride over the heavy runs
     if (pl.shared)
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, stream, hctr,
                          (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted, 0,
                          (char*)ws.hfinal.p);
     else
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(64), (64 / LN) * Pt::BYTES, stream, hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, stream, hctr,
                          (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted, accum,
                          d_buckets);
   }
@@ -1391,13 +1476,14 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * Wr * LNr + 127) / 128)), dim3(128), 0, stream,
                      (const char*)d_buckets, L0, (u32)(m * Wr), (char*)ws.lvlS[0].p, (char*)ws.lvlA[0].p);
   {
-    const u32 rthreads = Pt::BYTES * (256 / LNr) > 49152 ? 128 : 256;  // LDS tree within 48 KiB
-    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, Wr), dim3(rthreads), (rthreads / LNr) * Pt::BYTES, stream,
+    constexpr size_t ACCBr = AccOps<C>::ACC_BYTES;
+    const u32 rthreads = ACCBr * (256 / LNr) > 49152 ? 128 : 256;  // LDS tree within 48 KiB
+    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, Wr), dim3(rthreads), (rthreads / LNr) * ACCBr, stream,
                        (const char*)ws.lvlS[0].p, (const char*)ws.lvlA[0].p, (u32)m, nbits, chunk, (char*)ws.lvlS[1].p);
   }
   const char* d_sums = (const char*)ws.lvlS[1].p;
   if (nchunks > 1) {
-    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)npairs), dim3(64), (64 / LNr) * Pt::BYTES, stream,
+    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)npairs), dim3(64), (64 / LNr) * AccOps<C>::ACC_BYTES, stream,
                        (const char*)ws.lvlS[1].p, (u32)npairs, nchunks, (char*)ws.lvlA[1].p);
     d_sums = (const char*)ws.lvlA[1].p;
   }

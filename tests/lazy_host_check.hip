@@ -140,6 +140,45 @@ template <class P> int run(const char* name, const uint64_t* gen) {
                 F::eq(F::mul(F::sqr(d.zz), d.zz), F::sqr(d.zzz));  // and a valid XYZZ: ZZ^3 = ZZZ^2
     if (!same || !canon) { bad++; if (bad < 8) printf("%s point seq mismatch trial %d (same=%d canon=%d)\n", name, trial, (int)same, (int)canon); }
   }
+  // full additions (the reduction / heavy-run kernels): accumulator += stored bucket (canonical operand, repacked) and
+  // accumulator += accumulator, incl. the identity on either side, equal points (doubling) and inverse points
+  for (int trial = 0; trial < 200; trial++) {
+    auto build = [&](int len, XYZZ<F>& c, XYZZL<P>& l) {
+      c = XYZZ<F>::zero();
+      l.inf = true;
+      l.x = l.y = l.zz = l.zzz = L::zero();
+      for (int s2 = 0; s2 < len; s2++) {
+        const int k = g() % NP;
+        const bool ng = g() & 1;
+        F yy = F::cond_neg(py[k], ng);
+        L lx, ly;
+        lazy_from_affine<P>(px[k], yy, lx, ly);
+        xyzz_madd<F>(c, px[k], yy);
+        if (xyzz_madd_lazy<P>(l, lx, ly)) { XYZZL<P> d; xyzz_mdbl_lazy_xy<P>(d, lx, ly); l = d; }
+      }
+    };
+    XYZZ<F> ca, cb;
+    XYZZL<P> la, lb;
+    build(trial % 5 == 0 ? 0 : 1 + g() % 6, ca, la);
+    build(trial % 7 == 0 ? 0 : 1 + g() % 6, cb, lb);
+    if (trial % 3 == 1) { cb = ca; lb = la; }                                   // equal points: doubling
+    if (trial % 11 == 2) { cb = ca; cb.y = F::neg(cb.y); lb = lazy_from_bucket<P>(cb); }   // inverse points: infinity
+    XYZZ<F> want = ca;
+    xyzz_add<F>(want, cb);
+    XYZZL<P> v1 = la, v2 = la;
+    xyzz_add_lazy<P>(v1, lb.x, lb.y, lb.zz, lb.zzz, lb.inf);                    // += accumulator
+    const XYZZ<F> stored = lazy_to_bucket<P>(lb);                               // += stored bucket (what sits in HBM)
+    const XYZZOperands<P> o = lazy_operands_of<P>(stored);
+    xyzz_add_lazy<P>(v2, o.x, o.y, o.zz, o.zzz, o.inf);
+    for (int v = 0; v < 2; v++) {
+      const XYZZ<F> d = lazy_to_bucket<P>(v ? v2 : v1);
+      bool same;
+      if (want.is_zero() || d.is_zero()) same = want.is_zero() && d.is_zero();
+      else same = F::eq(F::mul(want.x, d.zz), F::mul(d.x, want.zz)) && F::eq(F::mul(want.y, d.zzz), F::mul(d.y, want.zzz)) &&
+                  F::eq(F::mul(F::sqr(d.zz), d.zz), F::sqr(d.zzz));
+      if (!same) { bad++; if (bad < 8) printf("%s full-add mismatch trial %d variant %d\n", name, trial, v); }
+    }
+  }
   printf("%s: %s (%d bad)\n", name, bad ? "FAIL" : "ok", bad);
   return bad;
 }
