@@ -813,7 +813,7 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
   const bool shared = allow_shared && npieces >= 2 && npieces <= 8;
   MsmPlan plan{};
   if (shared) {
-    plan = msm_make_plan(n, msm_scalar_bits(curve), msm_mul_cost(curve), false);
+    plan = msm_make_plan(n, msm_scalar_bits(curve), msm_mul_cost(curve), false, msm_lazy28(curve));
     if ((size_t)step * (size_t)plan.W >= (1ull << 32)) return ARK_HIP_ERR_SIZE;
     const size_t need = plan.nbuckets() * (size_t)CURVES[curve].fe_words * 32;  // XYZZ: four field elements
     if (c->piece_buckets.cap < need) {
@@ -1404,7 +1404,7 @@ int ark_hip_msm_cache_stats(uint64_t out[6]) {
 // the window plan the library would use (host arithmetic only: no GPU needed)
 int ark_hip_msm_plan(int curve, size_t n, int prepared, int* window_bits, int* windows) {
   if (curve < 0 || curve > 4) return ARK_HIP_ERR_ARG;
-  const MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve), prepared != 0);
+  const MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve), prepared != 0, msm_lazy28(curve));
   if (window_bits) *window_bits = pl.c;
   if (windows) *windows = pl.W;
   return 0;

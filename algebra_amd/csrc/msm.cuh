@@ -1007,6 +1007,8 @@ struct MsmPlan {
 // relative cost of one mixed addition (Fp384 G1 = 1): Fp256 ~0.5; Fp2 over Fp384 2.7 (measured: 0.49 ns against
 // 0.18 ns per addition at full occupancy)
 static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 2.7 : 1.0); }
+// curves whose additions run on 28-bit limbs (C::LAZY_A: the Fp384 G1 curves)
+static inline bool msm_lazy28(int curve_id) { return curve_id == 1 || curve_id == 2; }
 static inline int msm_scalar_bits(int curve_id) {
   switch (curve_id) {
     case 0: return BN254_FR::BITS;
@@ -1041,7 +1043,8 @@ static inline int msm_window_offset(int w, int c, int W, int narrow) {
 // single bucket is a serial chain (~14 us per addition on a lightly loaded SIMD), the first reduction
 // level costs 2 full additions per bucket, the bit-sliced remainder ~0.5 ms.  With a prepared base set
 // (`shared`) only one bucket set is reduced, which moves the optimum to wider windows.
-static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool shared) {
+static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool shared, bool lazy28 = false) {
+  const double plain_k = lazy28 ? 0.79 : 1.0;   // plain path only: see the accumulate model below
   int best_c = 3;
   double best = 1e300;
   const char* env = getenv(shared ? "ARK_HIP_MSM_C_PREPARED" : "ARK_HIP_MSM_C");
@@ -1069,8 +1072,20 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
         const double per_add = fp2 ? 30e-6 : (nbk <= lanes / 2 ? 14e-6 : 24e-6) * mul_cost;
         const double walk = lmax * per_add + W * 5e-6;                          // + run switches of a shared bucket
         if (nbk <= lanes || walk > acc) acc = walk;
+      } else if (fp2) {
+        const double chain = (entries / nbk) * 14e-6 * mul_cost;  // one lane pair walks one (window, bucket) run
+        if (chain > acc) acc = chain;
       } else {
-        const double chain = (entries / nbk) * 14e-6 * mul_cost;  // one lane walks one (window, bucket) run
+        // Fp384 G1 on 28-bit limbs (round 3): 7.0e9 instead of 5.5e9 mixed additions/s (plain_k = 0.79; BN254, on
+        // saturated limbs, scales by its mul_cost alone).  (That the first point of a bucket is only a copy does not show
+        // in the aggregate rate: 6.5e9/s at 2^22 with c = 19 against 6.8e9/s with c = 17.)
+        // One lane walks one (window, bucket) run, and the kernel lasts at least as long as its most loaded lane: measured
+        // 19 us per dependent addition for BLS12-381 whatever the occupancy (2^15 / 2^16, mean loads 2 .. 128:
+        // profiles/r3_window_sweep.txt), 14-18 us for BN254.
+        const double load = entries / nbk;
+        acc *= plain_k;
+        const double lmax = load + 3.0 * sqrt(load) + 2.0;
+        const double chain = lmax * (lazy28 ? 19e-6 : 32e-6 * mul_cost);
         if (chain > acc) acc = chain;
       }
       // level 0 of the reduction: 2 full additions per bucket; over Fp2 with ONE bucket set (a lane PAIR per bucket: half
@@ -1079,7 +1094,13 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       double red0 = nbk * 2.0 * fadd * (fp2 && shared ? 2.5 : 1.0);
       const double red0_lat = (fp2 && shared) ? 0.6e-3 : 2.0 * 8.0 * 21e-6 * mul_cost;  // latency floor of the reduction (G2: measured 0.62-0.76 ms for 2^12..2^16 buckets)
       if (red0_lat > red0) red0 = red0_lat;
-      const double bits_stage = 0.5e-3 * mul_cost;              // bit-sliced stage + host tail
+      double bits_stage = 0.5e-3 * mul_cost;                    // bit-sliced stage + host tail
+      if (!shared && !fp2) {
+        // plain path, fitted on BLS12-381 2^16 .. 2^24 (profiles/r3_window_sweep.txt): 0.2 ms + 0.45 ns per bucket
+        // + 1.4 ns per bucket for the first 3e5 (few buckets leave the chip's lanes idle, the chains dominate)
+        red0 = nbk * 2.0 * fadd * plain_k;
+        bits_stage = (0.25e-3 + (nbk < 3e5 ? nbk : 3e5) * 1.75e-9) * mul_cost * plain_k;
+      }
       // partition sort: per entry, plus a per-(window, bucket) term.  On the shared path at n >= 2^23 the latter is
       // measured nearly flat up to c = 22 (9 super-bucket bits + 12 bits finished in LDS, msm_part_split); beyond that the
       // super-bucket histogram grows and so do both sort passes (2^25: c = 24 costs +2.8 ms of sort and +7 ms of
@@ -1237,7 +1258,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (sbytes && (prepared || (sbytes != 1 && sbytes != 2 && sbytes != 4 && sbytes != 8) || sbits < 1 || sbits > 8 * sbytes))
     return -1;
   const MsmPlan pl = prepared ? *prepared
-                     : (piece ? *piece->plan : msm_make_plan(n, sbytes ? sbits + 1 : C::S::BITS, msm_mul_cost(C::ID), false));
+                     : (piece ? *piece->plan : msm_make_plan(n, sbytes ? sbits + 1 : C::S::BITS, msm_mul_cost(C::ID), false, C::LAZY_A));
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;                      // sort slots
   const size_t nbk = pl.nbuckets();             // accumulated buckets
