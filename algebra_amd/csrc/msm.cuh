@@ -1186,12 +1186,17 @@ struct MsmWorkspace {
   MsmJob jobs[MSM_JOBS];
   std::mutex mu;
   bool attr_set = false;  // dynamic-LDS opt-in done for this device
+  // window groups (msm_enqueue): the second group's sort runs on this stream under the first group's accumulate kernel
+  hipStream_t side = nullptr;
+  hipEvent_t grp_ev[2] = {nullptr, nullptr};
   void release() {
     hctr.release(); hlist.release(); hitems.release(); hpart.release(); hfinal.release();
     keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
     offsets.release(); sums.release();
     order.release(); ohist.release(); ooff.release();
     buckets.release();
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; }
+    for (auto& e : grp_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     for (int i = 0; i < 2; i++) { lvlS[i].release(); lvlA[i].release(); }
     for (auto& j : jobs) {
       if (j.pinned) (void)hipHostFree(j.pinned);
@@ -1278,14 +1283,15 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (ws.keys.ensure((size_t)W * n * 4)) return -3;
   if (ws.sorted.ensure((size_t)W * n * 4)) return -3;
   if (ws.part.ensure((size_t)W * n * 8)) return -3;
-  if (ws.thist.ensure(nthist * 4) || ws.toff.ensure((nthist + 1) * 4)) return -3;
-  if (ws.offsets.ensure((nb + 1) * 4)) return -3;
+  if (ws.thist.ensure(nthist * 4) || ws.toff.ensure((nthist + 2) * 4)) return -3;   // (+1 per window group)
+  if (ws.offsets.ensure((nb + 2) * 4)) return -3;
   const u32 ntscan = (u32)((nthist + SCAN_TILE - 1) / SCAN_TILE);
   const u32 noblk = (u32)((nbk + ORDER_TILE - 1) / ORDER_TILE);
   const size_t nohist = (size_t)noblk * ORDER_BINS;
   const u32 noscan = (u32)((nohist + SCAN_TILE - 1) / SCAN_TILE);
-  if (ws.sums.ensure((size_t)(ntscan > noscan ? ntscan : noscan) * 4)) return -3;
-  if (ws.order.ensure(nbk * 4) || ws.ohist.ensure(nohist * 4) || ws.ooff.ensure((nohist + 1) * 4)) return -3;
+  const size_t nsums = (size_t)(ntscan > noscan ? ntscan : noscan) + 2;
+  if (ws.sums.ensure(2 * nsums * 4)) return -3;   // one scan scratch per window group
+  if (ws.order.ensure(nbk * 4) || ws.ohist.ensure((nohist + ORDER_BINS) * 4) || ws.ooff.ensure((nohist + ORDER_BINS + 2) * 4)) return -3;
   if (!piece && ws.buckets.ensure(nbk * Pt::BYTES)) return -3;
   char* const d_buckets = piece ? (char*)piece->buckets : (char*)ws.buckets.p;
   const int accum = (piece && !piece->first) ? 1 : 0;
@@ -1364,11 +1370,11 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   }
   const size_t max_heavy = total_entries / 64 + 1;  // the threshold is never below 64
   const size_t max_items = total_entries / HEAVY_CHUNK + max_heavy + 1;
-  if (ws.hctr.ensure(16) || ws.hlist.ensure(max_heavy * sizeof(HeavyEntry)) || ws.hitems.ensure(max_items * 8) ||
-      ws.hpart.ensure(max_items * Pt::BYTES))
+  if (ws.hctr.ensure(32) || ws.hlist.ensure((max_heavy + 1) * sizeof(HeavyEntry)) || ws.hitems.ensure((max_items + 1) * 8) ||
+      ws.hpart.ensure((max_items + 1) * Pt::BYTES))
     return -3;
   if (pl.shared && ws.hfinal.ensure(max_heavy * Pt::BYTES)) return -3;
-  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 16, stream));  // [chunk items, heavy runs, threshold, scalar-range error flag]
+  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 32, stream));  // per window group: [chunk items, heavy runs, threshold, -]; [3]: scalar-range error flag
   const u32 nblk = (u32)((n + 255) / 256);
   if (sbytes) {
     const u64 vmask = sbits >= 64 ? ~0ull : ((1ull << sbits) - 1ull);
@@ -1384,63 +1390,39 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                        (u32)n, scalars_mont, c, W, pl.narrow, keys, (u32*)ws.hctr.p + 3);
   }
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[1], stream));
-  // partition sort: (A) split by the high bucket bits with LDS counters, (B) finish each super-bucket in LDS
-  hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, W), dim3(256), (size_t)4 << HB, stream, keys, (u32)n, HB, LB,
-                     ntiles, ptile, thist);
-  scan_exclusive(thist, nthist, sums, toff, stream);
-  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[2], stream));
-  {
-    // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device; the workspace is per device)
-    const size_t lds_a = ((size_t)8 << HB) + (size_t)ptile * 8;
-    const u32 stage_cap = msm_part_stage_cap(LB);
-    const size_t lds_b = ((size_t)(1 << LB) + 1024 + stage_cap) * 4;
-    if (!ws.attr_set) {
-      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 4096 - 64));
-      ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 64));
-      ws.attr_set = true;
-    }
-    hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, W), dim3(1024), lds_a, stream, keys, (u32)n, HB, LB, ntiles,
-                       ptile, toff, part);
-    hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper), dim3(1024), lds_b, stream, part, toff, ntiles, LB, nsuper,
-                       stage_cap, offsets, sorted);
+
+  // ---- window groups -------------------------------------------------------------------------------------------
+  // The sort is memory / LDS bound and small (8-28 VGPRs per lane), the accumulate kernel is multiply bound, uses no LDS
+  // and leaves 70 of the 512 registers per SIMD lane free: the two overlap well.  A plain MSM is therefore cut into TWO
+  // groups of windows: group 0 is sorted and accumulated on `stream`; group 1's sort runs on a side stream UNDER group
+  // 0's accumulate kernel and its accumulate kernel follows on `stream`.  Every kernel below already works on a range
+  // of windows through its base pointers (keys, pairs, sorted indices, offsets, order and buckets are window-major), so
+  // a group is nothing but offsets into the same arrays.  One group: a prepared set (its windows share one bucket set),
+  // a piece of a streamed MSM, few windows, and n < 2^25 -- measured (profiles/r3_window_groups_ab.txt): the sort kernels
+  // slow the accumulate kernel they run under by about what they hide up to 2^24 (38.6 against 38.5 ms; 2^20 4.27 against
+  // 4.14), and win where the sort is a larger share: 2^26 136.4 against 139.7 ms.  ARK_HIP_MSM_GROUPS=1 / =2 force it.
+  int ngroups = 1;
+  if (!pl.shared && !piece && W >= 6 && n >= ((size_t)1 << 19)) {
+    static const int groups_env = [] {
+      const char* e = getenv("ARK_HIP_MSM_GROUPS");
+      return e ? atoi(e) : 0;
+    }();
+    if (groups_env == 2 || (groups_env != 1 && n >= ((size_t)1 << 25))) ngroups = 2;
   }
-  {
-    // processing order, heaviest load class first; class width 2^shift so that the mean falls around class 32..63
-    int shift = 0;
-    while ((mean_load >> shift) >= 64) shift++;
-    u32* ohist = (u32*)ws.ohist.p;
-    u32* ooff = (u32*)ws.ooff.p;
-    const int wsum = pl.shared ? W : 1;
-    const size_t wstr = mwin;
-    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nbk, shift, noblk, wsum, wstr, ohist);
-    scan_exclusive(ohist, nohist, sums, ooff, stream);
-    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk), dim3(256), 0, stream, offsets, nbk, shift, noblk, wsum, wstr,
-                       ooff, order);
+  if (ngroups == 2) {
+    if (!ws.side) ARK_HIP_TRY(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
+    for (auto& e : ws.grp_ev)
+      if (!e) ARK_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[3], stream));
-  if (piece && piece->after_prev) ARK_HIP_TRY(hipStreamWaitEvent(stream, piece->after_prev, 0));  // the buckets' previous writer
-  {
-    // runs too long for one lane: chunk partials by one wave each, combined per run (empty for uniform scalars)
-    u32* hctr = (u32*)ws.hctr.p;
-    hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream, offsets, (u32)nb,
-                       forced_thresh, hctr, (HeavyEntry*)ws.hlist.p, (uint2*)ws.hitems.p);
-    constexpr u32 LN = C::FA::LANES;                        // lanes per element of the accumulate field
-    constexpr size_t ACCB = AccOps<C>::ACC_BYTES;           // one parked accumulator (the form the kernels sum in)
-    const u32 hthreads = ACCB * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
-    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * ACCB, stream,
-                       (const char*)d_points, sorted, offsets, hctr, (const uint2*)ws.hitems.p, wstride, Bbits,
-                       (char*)ws.hpart.p);
-    const u32 combine_grid = max_heavy < 16384 ? (u32)max_heavy : 16384u;  // grid-stride over the heavy runs
-    if (pl.shared)
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, stream, hctr,
-                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted, 0,
-                         (char*)ws.hfinal.p);
-    else
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, stream, hctr,
-                         (const HeavyEntry*)ws.hlist.p, (const char*)ws.hpart.p, HB, LB, offsets, sorted, accum,
-                         d_buckets);
+  const size_t lds_a = ((size_t)8 << HB) + (size_t)ptile * 8;
+  const u32 stage_cap = msm_part_stage_cap(LB);
+  const size_t lds_b = ((size_t)(1 << LB) + 1024 + stage_cap) * 4;
+  if (!ws.attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device; the workspace is per device)
+    ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 4096 - 64));
+    ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 64));
+    ws.attr_set = true;
   }
   bool lazy = false;  // Fp384 G1: the accumulate kernels on carry-free 28-bit limbs (fp28.cuh); ARK_HIP_MSM_LAZY=0: saturated
   if constexpr (C::LAZY_A) {
@@ -1450,33 +1432,125 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     }();
     lazy = lazy_on;
   }
-  if (pl.shared)
-  {
-    if constexpr (C::LAZY_A) {
-      if (lazy)
-        hipLaunchKernelGGL((msm_accumulate_shared_lazy_kernel<C>), dim3((u32)((nbk + 255) / 256)), dim3(256), 0, stream,
-                           (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, (const u32*)ws.hctr.p + 2,
-                           HB, LB, d_buckets);
-    }
-    if (!lazy)
-    hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
-                       (const char*)d_points, wstride, sorted, offsets, order, (u32)nbk, W, Bbits, (const u32*)ws.hctr.p + 2, HB, LB,
-                       d_buckets);
-    hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3(1024), dim3(64), 0, stream,
-                       (const u32*)ws.hctr.p, (const HeavyEntry*)ws.hlist.p, offsets, sorted, (const char*)ws.hfinal.p, W,
-                       Bbits, HB, LB, d_buckets);
+  const int W0 = ngroups == 2 ? (W + 1) / 2 : W;   // windows of group 0
+  struct Group {
+    int w0, Wg;
+    size_t slot0, nslots, nbk_g;   // first sort slot, sort slots, accumulated buckets
+    u32 *keys, *sorted, *offsets, *thist, *toff, *order, *sums, *ohist, *ooff, *hctr;
+    uint2* part;
+    HeavyEntry* hlist;
+    uint2* hitems;
+    char *hpart, *buckets;
+    size_t max_heavy;
+  } grp[2];
+  for (int g = 0; g < ngroups; g++) {
+    Group& G = grp[g];
+    G.w0 = g == 0 ? 0 : W0;
+    G.Wg = g == 0 ? W0 : W - W0;
+    G.slot0 = (size_t)G.w0 << Bbits;
+    G.nslots = (size_t)G.Wg << Bbits;
+    G.nbk_g = pl.shared ? nbk : G.nslots;
+    G.keys = keys + (size_t)G.w0 * n;
+    G.sorted = sorted + (size_t)G.w0 * n;
+    G.part = part + (size_t)G.w0 * n;
+    G.offsets = offsets + G.slot0 + (size_t)g;                     // nslots + 1 entries each
+    G.thist = thist + ((size_t)G.w0 << HB) * ntiles;
+    G.toff = toff + ((size_t)G.w0 << HB) * ntiles + (size_t)g;     // (Wg << HB) * ntiles + 1 entries each
+    G.order = order + G.slot0;
+    G.sums = sums + (size_t)g * nsums;
+    const size_t noblk0 = ((size_t)(pl.shared ? nbk : ((size_t)W0 << Bbits)) + ORDER_TILE - 1) / ORDER_TILE;
+    G.ohist = (u32*)ws.ohist.p + (size_t)g * noblk0 * ORDER_BINS;
+    G.ooff = (u32*)ws.ooff.p + (size_t)g * (noblk0 * ORDER_BINS + 1);
+    G.hctr = (u32*)ws.hctr.p + 4 * g;
+    const size_t ent0 = (size_t)n * W0;
+    const size_t mh0 = ent0 / 64 + 1, mi0 = ent0 / HEAVY_CHUNK + mh0 + 1;   // group 0's share of the heavy-run arrays
+    G.max_heavy = g == 0 ? (ngroups == 2 ? mh0 : max_heavy) : max_heavy - mh0;
+    G.hlist = (HeavyEntry*)ws.hlist.p + (g == 0 ? 0 : mh0);
+    G.hitems = (uint2*)ws.hitems.p + (g == 0 ? 0 : mi0);
+    G.hpart = (char*)ws.hpart.p + (g == 0 ? 0 : mi0) * Pt::BYTES;
+    G.buckets = d_buckets + (pl.shared ? 0 : G.slot0 * Pt::BYTES);
   }
-  else {
-    if constexpr (C::LAZY_A) {
-      if (lazy)
-        hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((nb + 255) / 256)), dim3(256), 0, stream,
-                           (const char*)d_points, sorted, offsets, order, (u32)nb, (const u32*)ws.hctr.p + 2, HB, LB, accum,
-                           d_buckets);
+  // partition sort of one group: (A) split by the low bucket bits with LDS counters, (B) finish each super-bucket in LDS;
+  // then the processing order of its buckets, heaviest load class first
+  auto sort_group = [&](const Group& G, hipStream_t st, bool mark) -> int {
+    const u32 nsuper_g = (u32)G.Wg << HB;
+    const size_t nthist_g = (size_t)nsuper_g * ntiles;
+    hipLaunchKernelGGL(msm_part_hist_kernel, dim3(ntiles, G.Wg), dim3(256), (size_t)4 << HB, st, G.keys, (u32)n, HB, LB,
+                       ntiles, ptile, G.thist);
+    scan_exclusive(G.thist, nthist_g, G.sums, G.toff, st);
+    if (mark && timing) ARK_HIP_TRY(hipEventRecord(job.ev[2], st));
+    hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, G.Wg), dim3(1024), lds_a, st, G.keys, (u32)n, HB, LB, ntiles,
+                       ptile, G.toff, G.part);
+    hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper_g), dim3(1024), lds_b, st, G.part, G.toff, ntiles, LB, nsuper_g,
+                       stage_cap, G.offsets, G.sorted);
+    int shift = 0;  // class width 2^shift so that the mean load falls around class 32..63
+    while ((mean_load >> shift) >= 64) shift++;
+    const u32 noblk_g = (u32)((G.nbk_g + ORDER_TILE - 1) / ORDER_TILE);
+    const int wsum = pl.shared ? W : 1;
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(noblk_g), dim3(256), 0, st, G.offsets, G.nbk_g, shift, noblk_g, wsum, mwin,
+                       G.ohist);
+    scan_exclusive(G.ohist, (size_t)noblk_g * ORDER_BINS, G.sums, G.ooff, st);
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(noblk_g), dim3(256), 0, st, G.offsets, G.nbk_g, shift, noblk_g, wsum, mwin,
+                       G.ooff, G.order);
+    return 0;
+  };
+  // heavy runs + the lane-per-bucket kernel of one group
+  auto accumulate_group = [&](const Group& G, hipStream_t st) -> int {
+    // runs too long for one lane: chunk partials by one wave each, combined per run (empty for uniform scalars)
+    hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((G.nslots + 255) / 256)), dim3(256), 0, st, G.offsets, (u32)G.nslots,
+                       forced_thresh, G.hctr, G.hlist, G.hitems);
+    constexpr u32 LN = C::FA::LANES;                        // lanes per element of the accumulate field
+    constexpr size_t ACCB = AccOps<C>::ACC_BYTES;           // one parked accumulator (the form the kernels sum in)
+    const u32 hthreads = ACCB * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
+    hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * ACCB, st,
+                       (const char*)d_points, G.sorted, G.offsets, G.hctr, (const uint2*)G.hitems, wstride, Bbits, G.hpart);
+    const u32 combine_grid = G.max_heavy < 16384 ? (u32)G.max_heavy : 16384u;  // grid-stride over the heavy runs
+    if (pl.shared)
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, st, G.hctr,
+                         (const HeavyEntry*)G.hlist, (const char*)G.hpart, HB, LB, G.offsets, G.sorted, 0, (char*)ws.hfinal.p);
+    else
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, st, G.hctr,
+                         (const HeavyEntry*)G.hlist, (const char*)G.hpart, HB, LB, G.offsets, G.sorted, accum, G.buckets);
+    if (pl.shared) {
+      if constexpr (C::LAZY_A) {
+        if (lazy)
+          hipLaunchKernelGGL((msm_accumulate_shared_lazy_kernel<C>), dim3((u32)((nbk + 255) / 256)), dim3(256), 0, st,
+                             (const char*)d_points, wstride, G.sorted, G.offsets, G.order, (u32)nbk, W, Bbits,
+                             (const u32*)G.hctr + 2, HB, LB, G.buckets);
+      }
+      if (!lazy)
+        hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
+                           (const char*)d_points, wstride, G.sorted, G.offsets, G.order, (u32)nbk, W, Bbits,
+                           (const u32*)G.hctr + 2, HB, LB, G.buckets);
+      hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3(1024), dim3(64), 0, st, (const u32*)G.hctr,
+                         (const HeavyEntry*)G.hlist, G.offsets, G.sorted, (const char*)ws.hfinal.p, W, Bbits, HB, LB, G.buckets);
+    } else {
+      if constexpr (C::LAZY_A) {
+        if (lazy)
+          hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((G.nslots + 255) / 256)), dim3(256), 0, st,
+                             (const char*)d_points, G.sorted, G.offsets, G.order, (u32)G.nslots, (const u32*)G.hctr + 2, HB, LB,
+                             accum, G.buckets);
+      }
+      if (!lazy)
+        hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((G.nslots * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
+                           (const char*)d_points, G.sorted, G.offsets, G.order, (u32)G.nslots, (const u32*)G.hctr + 2, HB, LB,
+                           accum, G.buckets);
     }
-    if (!lazy)
-    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((nb * C::FA::LANES + 255) / 256)), dim3(256), 0, stream,
-                       (const char*)d_points, sorted, offsets, order, (u32)nb, (const u32*)ws.hctr.p + 2, HB, LB, accum,
-                       d_buckets);
+    return 0;
+  };
+  if (int rc = sort_group(grp[0], stream, true)) return rc;
+  if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[3], stream));
+  if (ngroups == 2) {   // group 1's sort starts when group 0's accumulate kernel does
+    ARK_HIP_TRY(hipEventRecord(ws.grp_ev[0], stream));
+    ARK_HIP_TRY(hipStreamWaitEvent(ws.side, ws.grp_ev[0], 0));
+    if (int rc = sort_group(grp[1], ws.side, false)) return rc;
+    ARK_HIP_TRY(hipEventRecord(ws.grp_ev[1], ws.side));
+  }
+  if (piece && piece->after_prev) ARK_HIP_TRY(hipStreamWaitEvent(stream, piece->after_prev, 0));  // the buckets' previous writer
+  if (int rc = accumulate_group(grp[0], stream)) return rc;
+  if (ngroups == 2) {
+    ARK_HIP_TRY(hipStreamWaitEvent(stream, ws.grp_ev[1], 0));
+    if (int rc = accumulate_group(grp[1], stream)) return rc;
   }
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
   if (piece) ARK_HIP_TRY(hipEventRecord(piece->after_this, stream));

@@ -28,6 +28,6 @@ for name, d in zip(dem, rows.values()):
     if flt and flt not in name:
         continue
     short = re.sub(r"\(.*", "", name).replace("arkhip::", "").replace("void ", "")
-    print("%-70s VGPR %4s  SGPR %3s  spill %3s  scratch %5s  LDS %6s  occ %s" % (
-        short[:70], d.get("VGPRs"), d.get("SGPRs"), d.get("VGPR Spill"), d.get("ScratchSize [bytes/lane]"),
+    print("%-70s VGPR %4s  AGPR %3s  SGPR %3s  spilled VGPRs %3s  scratch %5s  LDS %6s  occ %s" % (
+        short[:70], d.get("VGPRs"), d.get("AGPRs"), d.get("TotalSGPRs"), d.get("VGPRs Spill"), d.get("ScratchSize [bytes/lane]"),
         d.get("LDS Size [bytes/block]"), d.get("Occupancy [waves/SIMD]")))
