@@ -16,12 +16,12 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(12345)
 A4 = np.array([0xA11CE, 1, 2, 0], dtype=np.uint64)
 B4 = np.array([0xB0B, 3, 0, 0], dtype=np.uint64)
-CURVES = ("BLS12_381_G1", "BN254_G1", "BLS12_377_G2")
+CURVES = ("BLS12_381_G1", "BN254_G1", "BLS12_377_G2", "BLS12_377_G1")
 bases = {c: O.gen_bases(O.CID[c], A4, B4, (1 << 12) if c.endswith("G2") else (1 << 15)) for c in CURVES}
 prepared = {}  # (curve, off, n) windows re-prepared every few iterations
 bad = 0
 for it in range(iters):
-    cname = CURVES[it % 3]
+    cname = CURVES[it % len(CURVES)]
     cid = O.CID[cname]
     cap = bases[cname].shape[0]
     n = int(rng.integers(1, cap))
@@ -33,8 +33,18 @@ for it in range(iters):
         sc[:, 0] &= np.uint64(0xFF)
     if kind == 4:  # many equal
         sc[::2] = sc[0]
-    got = A.into_affine(cid, A.msm_bigint(cid, bases[cname][off:off + n], sc))
-    exp = O.to_affine(cid, O.msm(cid, bases[cname][off:off + n], sc, O.SIGNED, 8))
+    bs = bases[cname][off:off + n]
+    if it % 7 == 6 and n >= 8:  # duplicate bases with equal scalars (doubling in one bucket), and P / -P pairs (infinity)
+        bs = bs.copy()
+        bs[1::3] = bs[0]
+        sc[1::3] = sc[0]
+        fw = bs.shape[1] // 2
+        if n >= 16:
+            bs[5, :fw] = bs[2, :fw]
+            bs[5, fw:] = O.basefield_op(cid, "neg", bs[2, fw:].reshape(1, -1)).reshape(-1)
+            sc[5] = sc[2]
+    got = A.into_affine(cid, A.msm_bigint(cid, bs, sc))
+    exp = O.to_affine(cid, O.msm(cid, bs, sc, O.SIGNED, 8))
     if not np.array_equal(got, exp):
         bad += 1
         print("MSM MISMATCH", cname, n, it)
@@ -43,7 +53,7 @@ for it in range(iters):
         os.environ["ARK_HIP_MSM_C_PREPARED"] = str(int(rng.integers(3, 18)))
     else:
         os.environ.pop("ARK_HIP_MSM_C_PREPARED", None)
-    pb = A.PreparedBases(cid, bases[cname][off:off + n])
+    pb = A.PreparedBases(cid, bs)
     os.environ.pop("ARK_HIP_MSM_C_PREPARED", None)
     job = pb.msm_bigint_async(sc)
     got_p = A.into_affine(cid, pb.msm_bigint(sc))
