@@ -206,6 +206,35 @@ def test_msm_skewed_scalars_heavy_buckets(cname):
         assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp)), (cname, name)
 
 
+@pytest.mark.parametrize("cname", ["BLS12_381_G1", "BLS12_377_G1", "BN254_G1", "BLS12_377_G2"])
+def test_msm_identical_bases_in_heavy_buckets(cname):
+    """Thousands of copies of ONE base with ONE scalar (and a block of its inverse): every lane of the heavy-run kernels
+    sums the same multiple, so the LDS trees and the chunk combine add EQUAL points (the full addition's doubling branch,
+    in the 28-bit form for the Fp384 G1 curves) and P + (-P) (its infinity branch); the lane-per-bucket kernel sees
+    the same point twice in a row (the mixed addition's doubling branch).  Checked against the oracle."""
+    import torch
+    cid = O.CID[cname]
+    r = P.Curve(cname).r
+    seed = O.gen_bases(cid, A4, B4, 4)
+    fw = seed.shape[1] // 2
+    for n, nneg in ((6000, 0), (9000, 3000), (70, 35), (5000, 2500)):
+        bases = np.tile(seed[1], (n, 1))
+        if nneg:
+            bases[:nneg, fw:] = O.basefield_op(cid, "neg", seed[1, fw:].reshape(1, -1)).reshape(-1)
+        for sval in (1, 0xFFFF, (r - 1) // 3, 0x1234567 + (1 << 200)):
+            scalars = np.tile(np.array(P.to_limbs(sval % r, 4), dtype=np.uint64), (n, 1))
+            if n == 5000:   # a second base in between: two long runs per bucket
+                bases[1::2] = seed[2]
+            got = A.msm_bigint(cid, torch.from_numpy(bases.view(np.int64)).cuda(), torch.from_numpy(scalars.view(np.int64)).cuda())
+            exp = O.msm(cid, bases, scalars, O.SIGNED, 4)
+            assert np.array_equal(A.into_affine(cid, got), O.to_affine(cid, exp)), (cname, n, nneg, hex(sval))
+            if cname != "BLS12_377_G2":
+                pb = A.PreparedBases(cid, bases)
+                gp = pb.msm_bigint(scalars)
+                pb.free()
+                assert np.array_equal(A.into_affine(cid, gp), O.to_affine(cid, exp)), (cname, n, nneg, hex(sval), "prepared")
+
+
 def test_msm_known_answer_table_bls12_381_g2():
     # reference KAT for the Fp2 path: k*G2 for k = 0..999 (g2_uncompressed_valid_test_vectors.dat, tests/mod.rs:113-123)
     import os
