@@ -1415,11 +1415,12 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
       if (!e) ARK_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const size_t lds_a = ((size_t)8 << HB) + (size_t)ptile * 8;
+  if (lds_a > PART_SCATTER_LDS_MAX) return -2;   // 2^14 super-buckets and more: beyond the n W < 2^32 the sort serves anyway
   const u32 stage_cap = msm_part_stage_cap(LB);
   const size_t lds_b = ((size_t)(1 << LB) + 1024 + stage_cap) * 4;
   if (!ws.attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute (once per device; the workspace is per device)
     ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 4096 - 64));
+                                    (int)PART_SCATTER_LDS_MAX));
     ARK_HIP_TRY(hipFuncSetAttribute((const void*)msm_part_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 64));
     ws.attr_set = true;

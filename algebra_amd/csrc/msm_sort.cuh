@@ -62,12 +62,16 @@ static constexpr int PART_TILE = 8192;         // keys per workgroup in pass A (
 static constexpr int PART_TILE_BIG = 16384;    // ... 128 KiB where pass A has >= 2^11 super-buckets (n >= 2^26): the per-tile
                                                // histogram array halves and the runs a tile writes per super-bucket double
                                                // (2^26, c = 22: 4 entries = 32 B per run with 8192 keys)
+static constexpr size_t PART_SCATTER_LDS_MAX = 160 * 1024 - 4096 - 64;   // dynamic LDS the scatter kernel may ask for
 static inline u32 msm_part_tile(int HB) {
   if (const char* e = getenv("ARK_HIP_MSM_TILE")) {   // tuning knob
     const int v = atoi(e);
-    if (v == PART_TILE || v == PART_TILE_BIG) return (u32)v;
+    if (v == PART_TILE || (v == PART_TILE_BIG && ((size_t)8 << HB) + (size_t)PART_TILE_BIG * 8 <= PART_SCATTER_LDS_MAX)) return (u32)v;
   }
-  return HB >= 11 ? (u32)PART_TILE_BIG : (u32)PART_TILE;
+  // the big tile must fit the scatter kernel's LDS beside its 2 x 2^HB counters (HB = 11: 16 + 128 KiB; from HB = 12,
+  // i.e. n >= 2^27, it does not -- 32 + 128 KiB -- and the 8192-key tile stays)
+  const bool fits = ((size_t)8 << HB) + (size_t)PART_TILE_BIG * 8 <= PART_SCATTER_LDS_MAX;
+  return (HB >= 11 && fits) ? (u32)PART_TILE_BIG : (u32)PART_TILE;
 }
 static constexpr u32 PART_KEY_NONE = 0xffffffffu;
 

@@ -63,9 +63,11 @@ def test_msm_g2_at_size_dlog(cname, logn):
     dlog_case(cname, logn, 4000 + logn)
 
 
-@pytest.mark.parametrize("logn", [23, 26])
+@pytest.mark.parametrize("logn", [23, 25, 26, 27])
 def test_msm_bls12_381_g1_2_26_and_shard_plan_dlog(logn):
-    # BASELINE config 4: the 2^26 total and the 2^23-per-GPU shard plan of its 8-way split
+    # BASELINE config 4: the 2^26 total and the 2^23-per-GPU shard plan of its 8-way split; 2^25 and 2^27: the window
+    # groups (from 2^25) on either side of the sort's tile-size switch (16384-key tiles at 2^26 only: 2^11 super-buckets
+    # fit the scatter kernel's LDS beside them, 2^12 do not -- a 2^27 job once asked for 160 KiB and aborted the queue)
     dlog_case("BLS12_381_G1", logn, 5000 + logn)
 
 
