@@ -20,7 +20,7 @@
 //   K5a msm_reduce_level  sum_k k*B_k per window, level 0: chunked running sums over <= 32 buckets per lane
 //                         (parallel form of mod.rs:478-484).
 //   K5b msm_reduce_bits   the rest, bit-sliced: log2(m)+1 independent masked sums per window.
-//   host                  Horner over the bit sums and the <= 64 window sums: ~(W-1)*c serial doublings -- a
+//   host                  one Horner over the bit positions of all bit sums and window sums: <= 256 serial doublings -- a
 //                         chain with no parallelism, run on the host in the same templated formulas (~0.3 ms).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -1657,26 +1657,32 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     return 0;
   }
 
-  // host tail (serial chains):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(offset_w) T_w
-  // (window combine of mod.rs:489-502, high to low).  A prepared base set has a single T: no doublings between
-  // windows at all.
+  // host tail (one serial chain):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(offset_w) T_w
+  // (window combine of mod.rs:489-502, high to low) -- evaluated as ONE Horner over bit positions: A_w sits at
+  // offset_w, U_(w,b) at offset_w + log2 L0 + b, so the chain doubles once per scalar bit (<= 256 doublings) instead of
+  // once per bit inside every window and again between windows (~2 c W).  A prepared base set has a single T.
   auto part_at = [&](int w, u32 q) { return Pt::load((const char*)job.pinned + ((size_t)w * Q + q) * Pt::BYTES); };
+  std::vector<int> off((size_t)Wr + 1);
+  off[0] = 0;
+  for (int w = 0; w < Wr; w++) off[w + 1] = off[w] + msm_window_width(w, c, W, pl.narrow);
+  int top = 0;
+  for (int w = 0; w < Wr; w++) top = std::max(top, off[w] + job.log2L0 + nbits - 1);
   Pt total = Pt::zero();
-  for (int w = Wr - 1; w >= 0; w--) {
-    if (w != Wr - 1) {
-      const int cw = msm_window_width(w, c, W, pl.narrow);  // weight of window w+1 over window w
-      for (int k = 0; k < cw; k++) total = xyzz_dbl<F>(total);
+  for (int pos = top; pos >= 0; pos--) {
+    total = xyzz_dbl<F>(total);
+    for (int w = Wr - 1; w >= 0; w--) {
+      const int rel = pos - off[w];
+      if (rel < 0) continue;
+      if (rel == 0) {
+        Pt asum = part_at(w, (u32)nbits);
+        xyzz_add<F>(total, asum);
+      }
+      const int b2 = rel - job.log2L0;
+      if (b2 >= 0 && b2 < nbits) {
+        Pt ub = part_at(w, (u32)b2);
+        xyzz_add<F>(total, ub);
+      }
     }
-    Pt u = Pt::zero();
-    for (int b2 = nbits - 1; b2 >= 0; b2--) {
-      u = xyzz_dbl<F>(u);
-      Pt ub = part_at(w, (u32)b2);
-      xyzz_add<F>(u, ub);
-    }
-    for (int k = 0; k < job.log2L0; k++) u = xyzz_dbl<F>(u);
-    Pt asum = part_at(w, (u32)nbits);
-    xyzz_add<F>(u, asum);
-    xyzz_add<F>(total, u);
   }
   xyzz_to_jac<F>(total).store(out_xyz);
 
