@@ -89,11 +89,12 @@ def comm_init(group=None):
     L = lib()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     buf = (C.c_ubyte * 128)()
-    if rank == 0:
-        check(L.ark_hip_comm_unique_id(buf), "ark_hip_comm_unique_id")
-    box = [bytes(buf)]
+    rc = L.ark_hip_comm_unique_id(buf) if rank == 0 else 0
+    # rank 0's failure travels with the broadcast: every rank raises together instead of the others waiting for an id
+    box = [(rc, bytes(buf))]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    check(box[0][0], "ark_hip_comm_unique_id (on rank 0)")
+    ident = (C.c_ubyte * 128).from_buffer_copy(box[0][1])
     check(L.ark_hip_comm_init(ident, rank, world), "ark_hip_comm_init")
     _LIB_COMM["world"] = world
     return True
