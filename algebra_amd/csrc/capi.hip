@@ -340,13 +340,18 @@ int msm_prepare_dispatch(int curve, const void* d_bases, size_t n, const MsmPlan
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
-int batchmul_build_dispatch(int curve, const void* d_base, void* d_scratch, void* d_table, hipStream_t st) {
-#define X(NAME) batchmul_build_##NAME(d_base, d_scratch, d_table, st)
+int batchmul_build_dispatch(int curve, const void* h_base, int window, void* d_scratch, void* d_table, hipStream_t st) {
+#define X(NAME) batchmul_build_##NAME(h_base, window, d_scratch, d_table, st)
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
-int batchmul_run_dispatch(int curve, const void* d_table, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t st) {
-#define X(NAME) batchmul_run_##NAME(d_table, d_scalars, n, mont, d_tmp, d_out, st)
+long long batchmul_build_scratch_dispatch(int curve, int window) {   // bytes; < 0: unknown curve
+#define X(NAME) (long long)batchmul_build_scratch_##NAME(window)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int batchmul_run_dispatch(int curve, const void* d_table, int window, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t st) {
+#define X(NAME) batchmul_run_##NAME(d_table, window, d_scalars, n, mont, d_tmp, d_out, st)
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
@@ -586,6 +591,7 @@ struct PreparedBases {   // ark_hip_msm_bases: a fixed base set with its table o
 struct BatchMulTable {   // ark_hip_batch_mul_table: multiples of one base (batchmul.cuh)
   int curve = -1;
   int logical = -1;
+  int window = 0;        // bits per table row (batchmul_window(num_scalars))
   DevBuf table;
 };
 struct MsmJobHandle {    // ark_hip_msm_job
@@ -1648,7 +1654,8 @@ int ark_hip_msm_prepared_multi(int n_gpus, const ark_hip_msm_bases* const* shard
 
 // ---- fixed-base batch multiplication (ScalarMul::batch_mul / BatchMulPreprocessing, ec/src/scalar_mul/mod.rs:104-251) ----
 int ark_hip_batch_mul_table_new(int curve, const uint64_t* base_xyz, size_t num_scalars, ark_hip_batch_mul_table** out) {
-  (void)num_scalars;  // the reference sizes its window from it (:222-228); the device table has a fixed geometry
+  // the reference sizes its window from num_scalars (:222-228); so does the device table, by its own cost rule
+  // (batchmul.cuh batchmul_window)
   if (curve < 0 || curve > 4 || !base_xyz || !out) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
   Context* c = sc.c;
@@ -1659,15 +1666,16 @@ int ark_hip_batch_mul_table_new(int curve, const uint64_t* base_xyz, size_t num_
   BatchMulTable* t = new BatchMulTable();
   t->curve = curve;
   t->logical = c->logical;
-  const size_t entries = (size_t)BATCHMUL_OUTER << BATCHMUL_WINDOW;
-  if (t->table.ensure(entries * ab) || c->stage_c.ensure(ab + (size_t)BATCHMUL_OUTER * 2 * ab)) {
+  t->window = batchmul_window(num_scalars);
+  const size_t entries = (size_t)batchmul_outer(t->window) << t->window;
+  if (t->table.ensure(entries * ab) || c->stage_c.ensure((size_t)batchmul_build_scratch_dispatch(curve, t->window))) {
     delete t;
     return ARK_HIP_ERR_NOMEM;
   }
-  rc = hipMemcpyAsync(c->stage_c.p, aff, ab, hipMemcpyHostToDevice, c->stream) == hipSuccess ? 0 : -1000;
-  if (rc == 0) rc = batchmul_build_dispatch(curve, c->stage_c.p, (char*)c->stage_c.p + ab, t->table.p, c->stream);
+  rc = batchmul_build_dispatch(curve, aff, t->window, c->stage_c.p, t->table.p, c->stream);
   if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = -1000;
   if (rc) {
+    (void)hipStreamSynchronize(c->stream);
     t->table.release();
     delete t;
     return rc;
@@ -1692,7 +1700,7 @@ int ark_hip_batch_mul_device(const ark_hip_batch_mul_table* table, const void* d
   if (int rc = sc.enter(t->logical)) return rc;
   if (n == 0) return 0;
   if (sc.c->stage_c.ensure(n * 2 * (size_t)CURVES[t->curve].fe_words * 16)) return ARK_HIP_ERR_NOMEM;  // XYZZ scratch
-  int rc = batchmul_run_dispatch(t->curve, t->table.p, d_scalars, n, mont, sc.c->stage_c.p, d_out_xy, sc.c->stream);
+  int rc = batchmul_run_dispatch(t->curve, t->table.p, t->window, d_scalars, n, mont, sc.c->stage_c.p, d_out_xy, sc.c->stream);
   if (rc) return rc;
   ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
   return 0;
@@ -1707,7 +1715,7 @@ int ark_hip_batch_mul(const ark_hip_batch_mul_table* table, const uint64_t* scal
   if (n == 0) return 0;
   if (c->stage_a.ensure(n * 32) || c->stage_b.ensure(n * ab) || c->stage_c.ensure(n * 2 * ab)) return ARK_HIP_ERR_NOMEM;
   ARK_HIP_TRY(hipMemcpyAsync(c->stage_a.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  int rc = batchmul_run_dispatch(t->curve, t->table.p, c->stage_a.p, n, mont, c->stage_c.p, c->stage_b.p, c->stream);
+  int rc = batchmul_run_dispatch(t->curve, t->table.p, t->window, c->stage_a.p, n, mont, c->stage_c.p, c->stage_b.p, c->stream);
   if (rc) return rc;
   ARK_HIP_TRY(hipMemcpyAsync(out_xy, c->stage_b.p, n * ab, hipMemcpyDeviceToHost, c->stream));
   ARK_HIP_TRY(hipStreamSynchronize(c->stream));

@@ -19,8 +19,9 @@ struct FftTimings;
                          int sbits, const MsmPiece* piece);                                                       \
   int msm_finish_##NAME(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm);                          \
   int msm_prepare_##NAME(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream);   \
-  int batchmul_build_##NAME(const void* d_base_affine, void* d_scratch, void* d_table, hipStream_t stream);      \
-  int batchmul_run_##NAME(const void* d_table, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t s); \
+  int batchmul_build_##NAME(const void* h_base_affine, int window, void* d_scratch, void* d_table, hipStream_t stream); \
+  size_t batchmul_build_scratch_##NAME(int window);                                                               \
+  int batchmul_run_##NAME(const void* d_table, int window, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t s); \
   int test_basefield_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);    \
   int test_point_op_##NAME(int kind, const void* d_acc, const void* d_other, void* d_out, size_t n, hipStream_t s); \
   int sw_add_affine_##NAME(const void* d_in, void* d_out, size_t n, const void* d_delta, hipStream_t s);        \

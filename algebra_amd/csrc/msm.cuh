@@ -1009,6 +1009,14 @@ struct MsmPlan {
 static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 2.7 : 1.0); }
 // curves whose additions run on 28-bit limbs (C::LAZY_A: the Fp384 G1 curves)
 static inline bool msm_lazy28(int curve_id) { return curve_id == 1 || curve_id == 2; }
+// ARK_HIP_MSM_LAZY=0: the saturated kernels on those curves too (A/B measurements)
+static inline bool msm_lazy_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("ARK_HIP_MSM_LAZY");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 static inline int msm_scalar_bits(int curve_id) {
   switch (curve_id) {
     case 0: return BN254_FR::BITS;
@@ -1426,13 +1434,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     ws.attr_set = true;
   }
   bool lazy = false;  // Fp384 G1: the accumulate kernels on carry-free 28-bit limbs (fp28.cuh); ARK_HIP_MSM_LAZY=0: saturated
-  if constexpr (C::LAZY_A) {
-    static const bool lazy_on = [] {
-      const char* e = getenv("ARK_HIP_MSM_LAZY");
-      return !(e && e[0] == '0');
-    }();
-    lazy = lazy_on;
-  }
+  if constexpr (C::LAZY_A) lazy = msm_lazy_enabled();
   const int W0 = ngroups == 2 ? (W + 1) / 2 : W;   // windows of group 0
   struct Group {
     int w0, Wg;

@@ -15,11 +15,12 @@ int msm_finish_BLS12_377_G1(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTi
 int msm_prepare_BLS12_377_G1(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream) {
   return msm_prepare_table<BLS12_377_G1>(d_bases, n, pl, d_table, d_tmp, stream);
 }
-int batchmul_build_BLS12_377_G1(const void* d_base_affine, void* d_scratch, void* d_table, hipStream_t stream) {
-  return batchmul_build<BLS12_377_G1>(d_base_affine, d_scratch, d_table, stream);
+int batchmul_build_BLS12_377_G1(const void* h_base_affine, int window, void* d_scratch, void* d_table, hipStream_t stream) {
+  return batchmul_build<BLS12_377_G1>(h_base_affine, window, d_scratch, d_table, stream);
 }
-int batchmul_run_BLS12_377_G1(const void* d_table, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t s) {
-  return batchmul_run<BLS12_377_G1>(d_table, d_scalars, n, mont, d_tmp, d_out, s);
+size_t batchmul_build_scratch_BLS12_377_G1(int window) { return batchmul_build_scratch<BLS12_377_G1>(window); }
+int batchmul_run_BLS12_377_G1(const void* d_table, int window, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t s) {
+  return batchmul_run<BLS12_377_G1>(d_table, window, d_scalars, n, mont, d_tmp, d_out, s);
 }
 int test_basefield_op_BLS12_377_G1(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<BLS12_377_G1::F, false>(op, a, b, r, n, s);

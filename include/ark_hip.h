@@ -189,8 +189,9 @@ int ark_hip_msm_last_timing(double out[8]);
 /* ---- fixed-base batch multiplication ----
  * ScalarMul::batch_mul / BatchMulPreprocessing (ec/src/scalar_mul/mod.rs:104-251): out[i] = v[i] * g for ONE group element
  * g, results affine (the reference's Vec<MulBase>).  table_new = BatchMulPreprocessing::new(base, num_scalars): builds the
- * table of multiples on the device (base_xyz: Projective; num_scalars only sizes the reference's window and is accepted
- * for signature parity); batch_mul = BatchMulPreprocessing::batch_mul.  Scalars: n x 4 limbs, Fr (Montgomery) when
+ * table of multiples on the device (base_xyz: Projective; num_scalars sizes the table as in the reference, :222-228, by
+ * the device's own cost rule: 12-bit rows, 16-bit rows from 2^24 scalars -- the window never changes a result);
+ * batch_mul = BatchMulPreprocessing::batch_mul.  Scalars: n x 4 limbs, Fr (Montgomery) when
  * scalars_are_montgomery != 0 as in the reference, or canonical BigInt<4> (any 256-bit value is multiplied exactly). */
 typedef struct ark_hip_batch_mul_table ark_hip_batch_mul_table;
 int ark_hip_batch_mul_table_new(int curve, const uint64_t* base_xyz, size_t num_scalars, ark_hip_batch_mul_table** out);

@@ -326,6 +326,46 @@ def test_batch_mul_matches_oracle(cname):
     assert not A.batch_mul(cid, ident, mont[:7]).any()
 
 
+@pytest.mark.parametrize("window", [0, 4, 7, 16])
+@pytest.mark.parametrize("cname", ["BN254_G1", "BLS12_381_G1", "BLS12_377_G2"])
+def test_batch_mul_window_geometries(cname, window, monkeypatch):
+    # BatchMulPreprocessing::new sizes the table from num_scalars (ec/src/scalar_mul/mod.rs:222-228); the device table's
+    # rule: 12-bit rows below 2^24 scalars, 16-bit rows from there (window 0 here = that default, asked for through
+    # num_scalars); other row widths through the measurement knob.  The window never changes the result.
+    cid = O.CID[cname]
+    fid = sf(cid)
+    r = S.R[O.FIELDS[fid]]
+    n = 200 if cname.endswith("G2") else 700
+    if window:
+        monkeypatch.setenv("ARK_HIP_BATCHMUL_WINDOW", str(window))
+    base = O.scalar_mul(cid, O.generator(cid), np.array([0xBA5E, 3, 0, 0], dtype=np.uint64))
+    canon = O.gen_scalars(fid, 67 + window, n)
+    canon[0] = 0
+    canon[1] = P.to_limbs(r - 1, 4)
+    t = A.BatchMulPreprocessing(cid, base, (1 << 24) if window == 0 else n)
+    assert np.array_equal(t.batch_mul(canon, montgomery=False), O.batch_mul(cid, base, canon))
+    t.free()
+
+
+@pytest.mark.parametrize("cname", ["BN254_G1", "BLS12_381_G1", "BLS12_377_G1"])
+def test_batch_mul_unreduced_scalar_hits_the_doubling_branch(cname):
+    # "any BigInt<4> is multiplied exactly": s = d 2^252 + (d 2^252 - r) with 0 <= d 2^252 - r < 2^252 makes the sum of
+    # the lower 21 rows EQUAL to the top row's entry (d 2^252 g = (d 2^252 - r) g) -- the addition must double.
+    cid = O.CID[cname]
+    fid = sf(cid)
+    r = S.R[O.FIELDS[fid]]
+    d = next(d for d in range(1, 16) if 0 <= (d << 252) - r < (1 << 252))
+    s = (d << 252) + ((d << 252) - r)
+    assert s < (1 << 256)
+    base = O.scalar_mul(cid, O.generator(cid), np.array([0x5EED, 0, 0, 0], dtype=np.uint64))
+    sc = np.stack([P.to_limbs(s, 4), P.to_limbs(5, 4), P.to_limbs(s, 4)]).astype(np.uint64)
+    baff = O.to_affine(cid, base)
+    exp = np.stack([O.to_affine(cid, O.scalar_mul(cid, baff, P.to_limbs(v % r, 4))) for v in (s, 5, s)])
+    t = A.BatchMulPreprocessing(cid, base, 3)
+    assert np.array_equal(t.batch_mul(sc, montgomery=False).reshape(exp.shape), exp)
+    t.free()
+
+
 def test_two_msm_lanes_under_concurrent_threads_and_batched_fft():
     # Two MSM lanes per device (a job enqueued while another is in flight runs on the second stream / workspace) and
     # up to three FFTs in flight: three host threads mix device-pointer MSMs (synchronous = enqueue + wait, so calls
