@@ -1,0 +1,14 @@
+#!/bin/bash
+# session AL: partition sort with wave-shuffle block scans (2 barriers instead of 20) and the run starts in LDS
+mkdir -p gpurun_out/r3al
+O=$PWD/gpurun_out/r3al
+export TMPDIR=/tmp
+for rep in 1 2; do
+for v in a_before b_scan; do
+  for cfg in "BLS12_381_G1 24" "BLS12_381_G1 20" "BLS12_381_G1 16" "BLS12_381_G1 26"; do
+    (echo "== $v $cfg"; ARK_HIP_LIB=$PWD/algebra_amd/variants/$v.so timeout 300 python tools/msm_bench.py $cfg 5 plain | grep -v amdgpu.ids) >> $O/ab.txt 2>> $O/ab.err
+  done
+done
+done
+(ARK_HIP_LIB=$PWD/algebra_amd/variants/b_scan.so timeout 900 python -m pytest tests/test_gpu_msm.py tests/test_gpu_msm_prepared.py tests/test_gpu_configs.py -m gpu -q -x 2>&1 | tail -5) > $O/tests.log
+echo done > $O/done
