@@ -21,7 +21,7 @@
 //                         (parallel form of mod.rs:478-484).
 //   K5b msm_reduce_bits   the rest, bit-sliced: log2(m)+1 independent masked sums per window.
 //   host                  one Horner over the bit positions of all bit sums and window sums: <= 256 serial doublings -- a
-//                         chain with no parallelism, run on the host in the same templated formulas (~0.3 ms).
+//                         chain with no parallelism, run on the host in the same templated formulas (~0.2 ms).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
