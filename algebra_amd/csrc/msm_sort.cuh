@@ -74,6 +74,9 @@ static inline u32 msm_part_tile(int HB) {
   return (HB >= 11 && fits) ? (u32)PART_TILE_BIG : (u32)PART_TILE;
 }
 static constexpr u32 PART_KEY_NONE = 0xffffffffu;
+static constexpr int PART_MLP = 8;             // global loads a lane keeps in flight in the sweeps of the sort kernels
+static constexpr int PART_OUT_MLP = 4;         // ... in the scatter kernel's output loop (8-byte pairs; 64 VGPRs keep two workgroups per CU)
+static constexpr int PART_SCATTER_KEYS = PART_TILE_BIG / 1024;   // keys per lane of the scatter kernel (1024 lanes)
 
 // slot index (sort order) -> bucket index (window-major, weight order)
 __host__ __device__ __forceinline__ u32 msm_slot_to_bucket(u32 slot, int HB, int LB) {
@@ -97,9 +100,19 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
   const size_t base = (size_t)w * n;
   const u32 lo = blockIdx.x * tile;
   const u32 hi = lo + tile < n ? lo + tile : n;
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    u32 key = keys[base + i];
-    if (key != PART_KEY_NONE) atomicAdd(&part_lds[key & hmask], 1u);
+  // PART_MLP loads in flight per lane before the first LDS atomic waits on one: a load -> atomic loop leaves one 4-byte
+  // load per lane outstanding, ~8 KiB per CU where HBM's latency x bandwidth asks for ~40 KiB (SQ counters of the three
+  // sort kernels: 88-91 % of wave time parked in s_waitcnt, LDS bank conflicts 1 %: profiles/r3_pmc_sq_counters.txt)
+  for (u32 c0 = lo; c0 < hi; c0 += blockDim.x * PART_MLP) {
+    u32 k[PART_MLP];
+#pragma unroll
+    for (int b = 0; b < PART_MLP; b++) {
+      const u32 i = c0 + (u32)b * blockDim.x + threadIdx.x;
+      k[b] = i < hi ? keys[base + i] : PART_KEY_NONE;
+    }
+#pragma unroll
+    for (int b = 0; b < PART_MLP; b++)
+      if (k[b] != PART_KEY_NONE) atomicAdd(&part_lds[k[b] & hmask], 1u);
   }
   __syncthreads();
   // bin-major: [(w << HB | bin)][tile]
@@ -110,7 +123,7 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
 // A2: second sweep over the same tile.  Pairs are staged in LDS grouped by super-bucket and then written
 // out in order, so that each (super-bucket, tile) run leaves as contiguous 8-byte elements.
 // dynamic LDS: (2 << HB) counters + `tile` pairs.
-static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32* __restrict__ keys, u32 n, int HB,
+static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const u32* __restrict__ keys, u32 n, int HB,
                                                                        int LB, u32 ntiles, u32 tile,
                                                                        const u32* __restrict__ tile_off,
                                                                        uint2* __restrict__ part) {
@@ -126,11 +139,18 @@ static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32
   const u32 hi = lo + tile < n ? lo + tile : n;
   const u32 hmask = nbins - 1u;
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) cnt[b] = 0;
-  __syncthreads();
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    u32 key = keys[base + i];
-    if (key != PART_KEY_NONE) atomicAdd(&cnt[key & hmask], 1u);
+  // the lane's keys stay in registers for both sweeps (tile <= PART_SCATTER_KEYS * blockDim.x); all loads are issued
+  // before the first LDS atomic waits
+  u32 k[PART_SCATTER_KEYS];
+#pragma unroll
+  for (int b = 0; b < PART_SCATTER_KEYS; b++) {
+    const u32 i = lo + (u32)b * blockDim.x + threadIdx.x;
+    k[b] = i < hi ? keys[base + i] : PART_KEY_NONE;
   }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < PART_SCATTER_KEYS; b++)
+    if (k[b] != PART_KEY_NONE) atomicAdd(&cnt[k[b] & hmask], 1u);
   __syncthreads();
   // exclusive scan of cnt[0..nbins) -> lstart ; cnt becomes the cursor
   const u32 per = (nbins + blockDim.x - 1) / blockDim.x;
@@ -159,20 +179,35 @@ static __global__ void __launch_bounds__(1024) msm_part_scatter_kernel(const u32
   }
   __syncthreads();
   const u32 total = wsum[blockDim.x - 1];
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    u32 key = keys[base + i];
-    if (key != PART_KEY_NONE) {
-      u32 pos = atomicAdd(&cnt[key & hmask], 1u);
-      stage[pos] = make_uint2(key, i);   // full key kept: the bin is re-derived below
+#pragma unroll
+  for (int b = 0; b < PART_SCATTER_KEYS; b++) {
+    if (k[b] != PART_KEY_NONE) {
+      const u32 pos = atomicAdd(&cnt[k[b] & hmask], 1u);
+      stage[pos] = make_uint2(k[b], lo + (u32)b * blockDim.x + threadIdx.x);   // full key kept: the bin is re-derived below
     }
   }
   __syncthreads();
-  for (u32 j = threadIdx.x; j < total; j += blockDim.x) {
-    uint2 e = stage[j];
-    u32 bkt = e.x & 0x7fffffffu;
-    u32 bin = bkt & hmask;
-    u32 dst = tile_off[((size_t)((w << HB) | bin)) * ntiles + blockIdx.x] + (j - lstart[bin]);
-    part[dst] = make_uint2((bkt >> HB) | (e.x & 0x80000000u), e.y);   // remaining (high) bits, < 2^LB
+  // output: the run starts (tile_off) of a batch of entries are fetched together, then the pairs are stored
+  for (u32 j0 = 0; j0 < total; j0 += blockDim.x * PART_OUT_MLP) {
+    uint2 e[PART_OUT_MLP];
+    u32 dst[PART_OUT_MLP];
+#pragma unroll
+    for (int b = 0; b < PART_OUT_MLP; b++) {
+      const u32 j = j0 + (u32)b * blockDim.x + threadIdx.x;
+      if (j < total) {
+        e[b] = stage[j];
+        const u32 bin = e[b].x & hmask;
+        dst[b] = tile_off[((size_t)((w << HB) | bin)) * ntiles + blockIdx.x] + (j - lstart[bin]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < PART_OUT_MLP; b++) {
+      const u32 j = j0 + (u32)b * blockDim.x + threadIdx.x;
+      if (j < total) {
+        const u32 bkt = e[b].x & 0x7fffffffu;
+        part[dst[b]] = make_uint2((bkt >> HB) | (e[b].x & 0x80000000u), e[b].y);   // remaining (high) bits, < 2^LB
+      }
+    }
   }
 }
 
@@ -195,7 +230,17 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
   for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
   const u32 lmask = nlow - 1u;
-  for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&cnt[part[j].x & lmask], 1u);
+  for (u32 c0 = start; c0 < end; c0 += blockDim.x * PART_MLP) {
+    u32 kx[PART_MLP];
+#pragma unroll
+    for (int b = 0; b < PART_MLP; b++) {
+      const u32 j = c0 + (u32)b * blockDim.x + threadIdx.x;
+      kx[b] = j < end ? part[j].x : PART_KEY_NONE;   // (a stored .x is < 2^31 + 2^LB: never the marker)
+    }
+#pragma unroll
+    for (int b = 0; b < PART_MLP; b++)
+      if (kx[b] != PART_KEY_NONE) atomicAdd(&cnt[kx[b] & lmask], 1u);
+  }
   __syncthreads();
   // exclusive scan of cnt[0..nlow): lane t owns `per` consecutive bins (nlow <= 4096, blockDim = 1024)
   const u32 per = nlow > blockDim.x ? nlow / blockDim.x : 1u;
@@ -224,10 +269,20 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
   __syncthreads();
   const u32 total = end - start;
   if (total <= stage_cap) {
-    for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) {
-      uint2 e = part[j];
-      u32 pos = atomicAdd(&cnt[e.x & lmask], 1u);
-      stage[pos] = e.y | (e.x & 0x80000000u);
+    for (u32 c0 = start; c0 < end; c0 += blockDim.x * PART_MLP) {
+      uint2 e[PART_MLP];
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++) {
+        const u32 j = c0 + (u32)b * blockDim.x + threadIdx.x;
+        e[b] = j < end ? part[j] : make_uint2(PART_KEY_NONE, 0u);
+      }
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++) {
+        if (e[b].x != PART_KEY_NONE) {
+          const u32 pos = atomicAdd(&cnt[e[b].x & lmask], 1u);
+          stage[pos] = e[b].y | (e[b].x & 0x80000000u);
+        }
+      }
     }
     __syncthreads();
     for (u32 j = threadIdx.x; j < total; j += blockDim.x) sorted[start + j] = stage[j];
