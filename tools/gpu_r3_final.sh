@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 3, final session: the committed build (one-Horner host tail, batch_mul by num_scalars):
 # parity, smoke, bench line, kernel trace, FETCH / WRITE_SIZE (3 full-size launches), N = 2 over gloo
-mkdir -p gpurun_out/r3fin2
-O=$PWD/gpurun_out/r3fin2
+mkdir -p gpurun_out/r3fin3
+O=$PWD/gpurun_out/r3fin3
 R=$PWD
 export TMPDIR=/tmp
 (timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6) > $O/tests.log
