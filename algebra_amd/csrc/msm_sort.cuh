@@ -88,6 +88,16 @@ __host__ __device__ __forceinline__ u32 msm_slot_to_bucket(u32 slot, int HB, int
   return (w << B) | (high << HB) | low;
 }
 
+// Tile of workgroup blockIdx.x, XCD-aware.  Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2:
+// with tile = blockIdx.x the runs that neighbouring tiles write next to each other -- 128-byte runs of pass A at arbitrary
+// 8-byte alignment, 4-byte histogram cells -- meet in eight different L2s and leave each of them as partial lines
+// (WRITE_SIZE 2.7 GB for 1.7 GB of pairs, 546 MiB for a 54 MiB histogram: profiles/r3_pmc_fetch_write_size.txt).  Giving
+// XCD k the k-th eighth of the tiles, in order, lets one L2 merge them.
+static __device__ __forceinline__ u32 part_tile_of_block(u32 b, u32 ntiles) {
+  const u32 per = ntiles >> 3;
+  return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
+}
+
 // A1: per-workgroup histogram over the high bits.  grid = (tiles, W); dynamic LDS = 4 << HB bytes.
 static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __restrict__ keys, u32 n, int HB, int LB,
                                                                    u32 ntiles, u32 tile, u32* __restrict__ tile_hist) {
@@ -98,7 +108,8 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
   __syncthreads();
   const u32 w = blockIdx.y;
   const size_t base = (size_t)w * n;
-  const u32 lo = blockIdx.x * tile;
+  const u32 tile_id = part_tile_of_block(blockIdx.x, ntiles);
+  const u32 lo = tile_id * tile;
   const u32 hi = lo + tile < n ? lo + tile : n;
   // PART_MLP loads in flight per lane before the first LDS atomic waits on one: a load -> atomic loop leaves one 4-byte
   // load per lane outstanding, ~8 KiB per CU where HBM's latency x bandwidth asks for ~40 KiB (SQ counters of the three
@@ -117,7 +128,7 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
   __syncthreads();
   // bin-major: [(w << HB | bin)][tile]
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x)
-    tile_hist[((size_t)((w << HB) | b)) * ntiles + blockIdx.x] = part_lds[b];
+    tile_hist[((size_t)((w << HB) | b)) * ntiles + tile_id] = part_lds[b];
 }
 
 // A2: second sweep over the same tile.  Pairs are staged in LDS grouped by super-bucket and then written
@@ -135,7 +146,8 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
   __shared__ u32 wsum[1024];
   const u32 w = blockIdx.y;
   const size_t base = (size_t)w * n;
-  const u32 lo = blockIdx.x * tile;
+  const u32 tile_id = part_tile_of_block(blockIdx.x, ntiles);
+  const u32 lo = tile_id * tile;
   const u32 hi = lo + tile < n ? lo + tile : n;
   const u32 hmask = nbins - 1u;
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) cnt[b] = 0;
@@ -197,7 +209,7 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
       if (j < total) {
         e[b] = stage[j];
         const u32 bin = e[b].x & hmask;
-        dst[b] = tile_off[((size_t)((w << HB) | bin)) * ntiles + blockIdx.x] + (j - lstart[bin]);
+        dst[b] = tile_off[((size_t)((w << HB) | bin)) * ntiles + tile_id] + (j - lstart[bin]);
       }
     }
 #pragma unroll
