@@ -811,11 +811,31 @@ void cache_forget(Context* c, int curve, const void* host, size_t n) {
 //   otherwise (msm_chunks with its fixed 2^20 steps): independent MSMs whose results are added on the host (the
 //   reference's own chunk sum, variable_base/mod.rs:542-557).
 int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_bases, const uint64_t* scalars, size_t n,
-               int mont, size_t step, uint64_t* out_xyz, bool allow_shared = true) {
+               int mont, size_t step, uint64_t* out_xyz, bool allow_shared = true, bool growing = false) {
   const size_t ab = (size_t)CURVES[curve].fe_words * 16;
   const size_t pw = (size_t)CURVES[curve].fe_words * 3;
   if (step == 0 || step > n) step = n;
-  const size_t npieces = n ? (n + step - 1) / step : 0;
+  // piece sizes: equal steps, or -- `growing`, scalars-only uploads against resident bases -- each piece twice the one
+  // before it: a piece's upload hides under the previous piece's kernels as long as it is less than ~3x as large (the MSM
+  // spends 2.1 ns per pair, the PCIe copy 0.64 ns per 32-byte scalar), so the one upload nothing hides shrinks to
+  // n / (2^P - 1) pairs and the per-piece costs (launches, the read-modify-write of every bucket) are paid P <= 6 times
+  std::vector<size_t> sizes;
+  if (growing && n >= ((size_t)3 << 18)) {
+    int P = 1;
+    while (P < 6 && (n / (((size_t)1 << (P + 1)) - 1)) >= ((size_t)1 << 18)) P++;
+    size_t first = (n / (((size_t)1 << P) - 1)) & ~(size_t)255;
+    size_t left = n, cur = first;
+    for (int k = 0; k < P; k++) {
+      const size_t take = k + 1 == P ? left : cur;
+      sizes.push_back(take);
+      left -= take;
+      cur *= 2;
+    }
+    step = sizes.back();   // the largest piece sizes the ring buffers
+  } else {
+    for (size_t off = 0; off < n; off += step) sizes.push_back(n - off < step ? n - off : step);
+  }
+  const size_t npieces = sizes.size();
   const bool shared = allow_shared && npieces >= 2 && npieces <= 8;
   MsmPlan plan{};
   if (shared) {
@@ -858,9 +878,9 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
     if (slot < 0) return slot;
     return msm_finish_ctx(c, curve, slot, out_xyz);
   }
-  size_t piece_no = 0;
-  for (size_t off = 0; off < n; off += step, piece_no++) {
-    const size_t cnt = n - off < step ? n - off : step;
+  size_t off = 0;
+  for (size_t piece_no = 0; piece_no < npieces; off += sizes[piece_no], piece_no++) {
+    const size_t cnt = sizes[piece_no];
     if (npend == 2) {
       if (int rc = drain_one()) return fail(rc);
     }
@@ -901,6 +921,9 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
 // piece keeps ~2^18 pairs (its ~20 launches and the read-modify-write of every bucket are per piece).  Measured on
 // MI355X, BLS12-381 G1, repeat call with resident bases (profiles/r3_trait_surface.txt): 2^24: 1 / 2 / 4 / 8 pieces
 // 52.6 / 47.1 / 45.3 / 44.0 ms (resident inputs: 41.3); 2^22: 17.0 / 15.2 / 14.0 / 13.5 (13.3); 2^20: 5.9 / 5.4 / 5.3 (4.8).
+// Repeat calls against resident bases use GROWING pieces instead (msm_stream, `growing`): 2^24 43.95 -> 42.59 ms, 2^20
+// 4.50 -> 4.01 ms (resident 3.97), 2^26 155.1 -> 147.9 ms (profiles/r3_trait_growing_pieces.txt); equal pieces remain for
+// calls that upload their bases too (there the copy, not the kernels, sets the pace).
 size_t msm_stream_step(size_t n) {
   size_t pieces = n >> 18;
   if (pieces < 1) pieces = 1;
@@ -1310,7 +1333,9 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
     else ce->hits = 0;
   }
   if (ce->prepared) return ark_hip_msm_prepared((const ark_hip_msm_bases*)ce->prepared, scalars, n, mont, out_xyz);
-  return msm_stream(c, curve, ce->dev.p, nullptr, scalars, n, mont, msm_stream_step(n), out_xyz);
+  const char* eg = getenv("ARK_HIP_STREAM_GROWING");   // =0: equal pieces (msm_stream_step); a forced piece count also
+  const bool growing = !(eg && eg[0] == '0') && !getenv("ARK_HIP_STREAM_PIECES");
+  return msm_stream(c, curve, ce->dev.p, nullptr, scalars, n, mont, msm_stream_step(n), out_xyz, true, growing);
 }
 
 // ---- narrow scalars: VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64 (variable_base/mod.rs:87-117) ----

@@ -140,6 +140,15 @@ def test_streamed_pieces_at_size(monkeypatch):
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
     st = A.base_cache_stats()          # (mul_gen's one-point MSMs own the other entries)
     assert st["bytes"] >= bases.nbytes and st["hits"] >= 1
+    # a hit streams its scalars in GROWING pieces (each twice the one before: 3 pieces here); the equal-piece rule and a
+    # ragged length (two growing pieces + remainder) give the same point
+    monkeypatch.setenv("ARK_HIP_STREAM_GROWING", "0")
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
+    monkeypatch.delenv("ARK_HIP_STREAM_GROWING")
+    m = (3 << 18) + 1001
+    want_m = S.mul_gen(cid, S.dlog_of_msm(sc[:m], S.A0, S.B0, r), r)
+    for _ in range(2):
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[:m], sc[:m])), want_m)
 
 
 def test_auto_prepare_after_hits():
