@@ -153,22 +153,22 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) cnt[b] = 0;
   // the lane's keys stay in registers for both sweeps (tile <= PART_SCATTER_KEYS * blockDim.x); all loads are issued
   // before the first LDS atomic waits
-  u32 k[PART_SCATTER_KEYS];
+  u32 key[PART_SCATTER_KEYS];
 #pragma unroll
   for (int b = 0; b < PART_SCATTER_KEYS; b++) {
     const u32 i = lo + (u32)b * blockDim.x + threadIdx.x;
-    k[b] = i < hi ? keys[base + i] : PART_KEY_NONE;
+    key[b] = i < hi ? keys[base + i] : PART_KEY_NONE;
   }
   __syncthreads();
 #pragma unroll
   for (int b = 0; b < PART_SCATTER_KEYS; b++)
-    if (k[b] != PART_KEY_NONE) atomicAdd(&cnt[k[b] & hmask], 1u);
+    if (key[b] != PART_KEY_NONE) atomicAdd(&cnt[key[b] & hmask], 1u);
   __syncthreads();
   // exclusive scan of cnt[0..nbins) -> lstart ; cnt becomes the cursor
   const u32 per = (nbins + blockDim.x - 1) / blockDim.x;
   u32 s = 0;
-  for (u32 k = 0; k < per; k++) {
-    u32 b = threadIdx.x * per + k;
+  for (u32 q = 0; q < per; q++) {
+    u32 b = threadIdx.x * per + q;
     if (b < nbins) s += cnt[b];
   }
   wsum[threadIdx.x] = s;
@@ -180,8 +180,8 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
     __syncthreads();
   }
   u32 run = wsum[threadIdx.x] - s;
-  for (u32 k = 0; k < per; k++) {
-    u32 b = threadIdx.x * per + k;
+  for (u32 q = 0; q < per; q++) {
+    u32 b = threadIdx.x * per + q;
     if (b < nbins) {
       u32 v = cnt[b];
       lstart[b] = run;
@@ -193,9 +193,9 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
   const u32 total = wsum[blockDim.x - 1];
 #pragma unroll
   for (int b = 0; b < PART_SCATTER_KEYS; b++) {
-    if (k[b] != PART_KEY_NONE) {
-      const u32 pos = atomicAdd(&cnt[k[b] & hmask], 1u);
-      stage[pos] = make_uint2(k[b], lo + (u32)b * blockDim.x + threadIdx.x);   // full key kept: the bin is re-derived below
+    if (key[b] != PART_KEY_NONE) {
+      const u32 pos = atomicAdd(&cnt[key[b] & hmask], 1u);
+      stage[pos] = make_uint2(key[b], lo + (u32)b * blockDim.x + threadIdx.x);   // full key kept: the bin is re-derived below
     }
   }
   __syncthreads();
