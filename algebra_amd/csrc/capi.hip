@@ -453,6 +453,19 @@ XYZZ<F> jac_to_xyzz(const uint64_t* p) {
   F zz = F::sqr(z);
   return XYZZ<F>{x, y, zz, F::mul(zz, z)};
 }
+// the MSM's host tail on caller-supplied bit sums (ark_hip_test_msm_host_fold)
+template <class C>
+int host_fold(const uint64_t* parts, int windows, int nbits, int log2_l0, const int* widths, uint64_t* out_xyz) {
+  std::vector<int> off((size_t)windows + 1);
+  off[0] = 0;
+  for (int w = 0; w < windows; w++) {
+    if (widths[w] < 1 || widths[w] > 32) return ARK_HIP_ERR_ARG;
+    off[w + 1] = off[w] + widths[w];
+  }
+  const XYZZ<typename C::F> t = msm_host_fold<C>((const char*)parts, (u32)(nbits + 1), windows, nbits, log2_l0, off.data());
+  xyzz_to_jac<typename C::F>(t).store(out_xyz);
+  return 0;
+}
 // sum of n Jacobian points on the host (the multi-GPU combine: one partial per rank)
 template <class C>
 int host_sum(const uint64_t* pts, size_t n, uint64_t* out) {
@@ -2043,6 +2056,19 @@ int ark_hip_sw_sum(int curve, const uint64_t* jac_points, size_t n, uint64_t* ou
     case 2: return host_sum<BLS12_377_G1>(jac_points, n, out_xyz);
     case 3: return host_sum<BLS12_377_G2>(jac_points, n, out_xyz);
     case 4: return host_sum<BLS12_381_G2>(jac_points, n, out_xyz);
+  }
+  return ARK_HIP_ERR_ARG;
+}
+int ark_hip_test_msm_host_fold(int curve, const uint64_t* parts, int windows, int nbits, int log2_l0, const int* widths,
+                               uint64_t* out_xyz) {
+  if (!parts || !widths || !out_xyz || windows < 1 || windows > 256 || nbits < 0 || nbits > 31 || log2_l0 < 0 || log2_l0 > 16)
+    return ARK_HIP_ERR_ARG;
+  switch (curve) {
+    case 0: return host_fold<BN254_G1>(parts, windows, nbits, log2_l0, widths, out_xyz);
+    case 1: return host_fold<BLS12_381_G1>(parts, windows, nbits, log2_l0, widths, out_xyz);
+    case 2: return host_fold<BLS12_377_G1>(parts, windows, nbits, log2_l0, widths, out_xyz);
+    case 3: return host_fold<BLS12_377_G2>(parts, windows, nbits, log2_l0, widths, out_xyz);
+    case 4: return host_fold<BLS12_381_G2>(parts, windows, nbits, log2_l0, widths, out_xyz);
   }
   return ARK_HIP_ERR_ARG;
 }

@@ -1623,6 +1623,38 @@ static inline hipError_t msm_wait_event(hipEvent_t ev) {
   }
 }
 
+// The serial tail of an MSM, on the host:  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(off_w) T_w  (window
+// combine of mod.rs:489-502) -- evaluated as ONE Horner over bit positions: A_w sits at off_w, U_(w,b) at
+// off_w + log2 L0 + b, so the chain doubles once per scalar bit (<= 256 doublings) instead of once per bit inside every
+// window and again between windows (~2 c W).  parts: [w][q] XYZZ points, q < nbits: U_(w,q), q == nbits: A_w, row
+// stride Q; off: Wr + 1 bit offsets.  A prepared base set has a single T (Wr = 1).
+template <class C>
+XYZZ<typename C::F> msm_host_fold(const char* parts, u32 Q, int Wr, int nbits, int log2L0, const int* off) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  auto part_at = [&](int w, u32 q) { return Pt::load(parts + ((size_t)w * Q + q) * Pt::BYTES); };
+  int top = 0;
+  for (int w = 0; w < Wr; w++) top = std::max(top, off[w] + log2L0 + nbits - 1);
+  Pt total = Pt::zero();
+  for (int pos = top; pos >= 0; pos--) {
+    total = xyzz_dbl<F>(total);
+    for (int w = Wr - 1; w >= 0; w--) {
+      const int rel = pos - off[w];
+      if (rel < 0) continue;
+      if (rel == 0) {
+        Pt asum = part_at(w, (u32)nbits);
+        xyzz_add<F>(total, asum);
+      }
+      const int b2 = rel - log2L0;
+      if (b2 >= 0 && b2 < nbits) {
+        Pt ub = part_at(w, (u32)b2);
+        xyzz_add<F>(total, ub);
+      }
+    }
+  }
+  return total;
+}
+
 // Wait for job `slot` and finish it on the host: out_xyz = Jacobian x|y|z Montgomery limbs (group.rs:34-41);
 // identity = (R, R, 0) (group.rs:145-151).  Releases the slot.
 template <class C>
@@ -1659,33 +1691,10 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     return 0;
   }
 
-  // host tail (one serial chain):  T_w = sum A + L0 * sum_b 2^b U_b ;  total = sum_w 2^(offset_w) T_w
-  // (window combine of mod.rs:489-502, high to low) -- evaluated as ONE Horner over bit positions: A_w sits at
-  // offset_w, U_(w,b) at offset_w + log2 L0 + b, so the chain doubles once per scalar bit (<= 256 doublings) instead of
-  // once per bit inside every window and again between windows (~2 c W).  A prepared base set has a single T.
-  auto part_at = [&](int w, u32 q) { return Pt::load((const char*)job.pinned + ((size_t)w * Q + q) * Pt::BYTES); };
   std::vector<int> off((size_t)Wr + 1);
   off[0] = 0;
   for (int w = 0; w < Wr; w++) off[w + 1] = off[w] + msm_window_width(w, c, W, pl.narrow);
-  int top = 0;
-  for (int w = 0; w < Wr; w++) top = std::max(top, off[w] + job.log2L0 + nbits - 1);
-  Pt total = Pt::zero();
-  for (int pos = top; pos >= 0; pos--) {
-    total = xyzz_dbl<F>(total);
-    for (int w = Wr - 1; w >= 0; w--) {
-      const int rel = pos - off[w];
-      if (rel < 0) continue;
-      if (rel == 0) {
-        Pt asum = part_at(w, (u32)nbits);
-        xyzz_add<F>(total, asum);
-      }
-      const int b2 = rel - job.log2L0;
-      if (b2 >= 0 && b2 < nbits) {
-        Pt ub = part_at(w, (u32)b2);
-        xyzz_add<F>(total, ub);
-      }
-    }
-  }
+  const Pt total = msm_host_fold<C>((const char*)job.pinned, Q, Wr, nbits, job.log2L0, off.data());
   xyzz_to_jac<F>(total).store(out_xyz);
 
   if (tm && job.timing) {

@@ -324,6 +324,12 @@ int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64
 /* kind: 2 bucket += affine, 3 bucket -= affine, 4 bucket += bucket, 5 bucket double, 6 bucket -> jacobian,
  * 7 affine double_to_bucket.  acc/other/out are arrays of n elements. */
 int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64_t* other, uint64_t* out, size_t n);
+/* HOST-ONLY test hook (no device needed): the serial tail of an MSM (ec/src/scalar_mul/variable_base/mod.rs:489-502, the
+ * window combine) as msm_finish runs it.  parts: windows x (nbits + 1) bucket-form points (x | y | zz | zzz), row w =
+ * U_(w,0) .. U_(w,nbits-1), A_w; widths: the windows' bit widths.  out = sum_w 2^(off_w) (A_w + 2^log2_l0 sum_b 2^b U_(w,b))
+ * as a Projective (x | y | z). */
+int ark_hip_test_msm_host_fold(int curve, const uint64_t* parts, int windows, int nbits, int log2_l0, const int* widths,
+                               uint64_t* out_xyz);
 
 #ifdef __cplusplus
 }

@@ -196,3 +196,48 @@ def test_synth_discrete_log_identity_is_exact_for_large_indices():
     x = np.full(1003, (1 << 61) - 1, dtype=np.uint64)
     assert S._exact_sum(x, 4) == 1003 * ((1 << 61) - 1)
     assert S._exact_sum(np.full(77, (1 << 58) - 1, dtype=np.uint64)) == 77 * ((1 << 58) - 1)
+
+
+@pytest.mark.parametrize("cname", O.CURVES)
+def test_msm_host_tail_folds_bit_sums_like_the_window_combine(cname):
+    # The serial tail of every MSM (msm_finish -> msm_host_fold: the window combine of
+    # ec/src/scalar_mul/variable_base/mod.rs:489-502 over bit-sliced bucket sums), run on caller-supplied parts:
+    #   out = sum_w 2^(off_w) (A_w + 2^l0 sum_b 2^b U_(w,b))  ==  one naive MSM of the same points with those weights.
+    # Parts are bucket-form points (x t^2, y t^3, t^2, t^3) with a different t each; some are the identity (zz = 0).
+    import ctypes as C
+    cid = O.CID[cname]
+    fw = O.fe_words(cid)
+    for windows, nbits, l0, widths in ((3, 4, 2, [7, 7, 6]), (1, 5, 0, [20]), (4, 3, 3, [6, 6, 6, 5])):
+        npts = windows * (nbits + 1)
+        aff = O.gen_bases(cid, A4, B4, npts + 1)
+        t_src = O.gen_bases(cid, B4, A4, npts)                      # x coordinates of other points: the t values
+        parts = np.zeros((windows, nbits + 1, 4 * fw), dtype=np.uint64)
+        weights, pts = [], []
+        off = 0
+        for w in range(windows):
+            for q in range(nbits + 1):
+                k = w * (nbits + 1) + q
+                if k % 5 == 3:
+                    continue                                        # identity part: all-zero cell
+                x, y = aff[k][:fw], aff[k][fw:]
+                t = t_src[k][:fw]
+                t2 = O.basefield_op(cid, "mul", t, t)
+                t3 = O.basefield_op(cid, "mul", t2, t)
+                parts[w, q, :fw] = O.basefield_op(cid, "mul", x, t2)
+                parts[w, q, fw:2 * fw] = O.basefield_op(cid, "mul", y, t3)
+                parts[w, q, 2 * fw:3 * fw] = t2
+                parts[w, q, 3 * fw:] = t3
+                pos = off if q == nbits else off + l0 + q
+                weights.append(1 << pos)
+                pts.append(aff[k])
+            off += widths[w]
+        out = np.zeros(3 * fw, dtype=np.uint64)
+        wid = (C.c_int * windows)(*widths)
+        parts = np.ascontiguousarray(parts)
+        rc = _lib.lib().ark_hip_test_msm_host_fold(cid, parts.ctypes.data_as(C.c_void_p), windows, nbits, l0, wid,
+                                                   out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        sc = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in weights], dtype=np.uint64)
+        want = O.to_affine(cid, O.msm(cid, np.stack(pts), sc, O.NAIVE))
+        assert np.array_equal(A.into_affine(cid, out), want), (cname, windows, nbits, l0)
+    assert _lib.lib().ark_hip_test_msm_host_fold(cid, None, 1, 1, 0, None, None) != 0      # argument check
