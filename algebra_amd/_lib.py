@@ -79,6 +79,8 @@ SYMBOLS = {
     "ark_hip_msm_sw_small": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     "ark_hip_msm_sw_small_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     "ark_hip_msm_prepared_small_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
+    "ark_hip_msm_bases_pin": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t]),
+    "ark_hip_msm_bases_unpin": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t]),
     "ark_hip_msm_cache_config": (C.c_int, [C.c_longlong, C.c_int]),
     "ark_hip_msm_cache_clear": (C.c_int, []),
     "ark_hip_msm_cache_stats": (C.c_int, [C.POINTER(C.c_uint64)]),

@@ -49,8 +49,8 @@ class CopyPool {
       memcpy(dst, src, bytes);
       return;
     }
-    std::atomic<int> left(parts);
-    std::mutex dmu;
+    int left = parts;              // guarded by dmu: the last worker decrements AND notifies under the lock, so the
+    std::mutex dmu;                // waiter cannot see 0, return and destroy dmu / dcv while a worker still touches them
     std::condition_variable dcv;
     const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;
     {
@@ -60,16 +60,14 @@ class CopyPool {
         const size_t len = off >= bytes ? 0 : (bytes - off < per ? bytes - off : per);
         q_.push_back([=, &left, &dmu, &dcv]() {
           if (len) memcpy((char*)dst + off, (const char*)src + off, len);
-          if (left.fetch_sub(1) == 1) {
-            std::lock_guard<std::mutex> l2(dmu);
-            dcv.notify_one();
-          }
+          std::lock_guard<std::mutex> l2(dmu);
+          if (--left == 0) dcv.notify_one();
         });
       }
     }
     cv_.notify_all();
     std::unique_lock<std::mutex> l2(dmu);
-    dcv.wait(l2, [&]() { return left.load() == 0; });
+    dcv.wait(l2, [&]() { return left == 0; });
   }
 
  private:
@@ -164,20 +162,29 @@ struct HostStager {
 
 // ---- resident copies of base sets handed over by host pointer -------------------------------------------
 // SWCurveConfig::msm / VariableBaseMSM::msm_bigint take `&[Affine]` on every call; provers (and the reference's own
-// bench, bench-templates/src/macros/ec.rs:223-240) pass the SAME slice -- an SRS -- again and again.  The host-pointer
-// entry keeps device copies keyed by (curve, host address, length) and validated by a fingerprint of sampled content, so
-// a repeat call pays the scalar upload only.
+// bench, bench-templates/src/macros/ec.rs:223-240) pass the SAME slice -- an SRS -- again and again.  By DEFAULT the
+// host-pointer entry is a pure function of its two slices (bases and scalars stream over PCIe together, nothing is
+// retained: the reference's borrow semantics, variable_base/mod.rs:59-85).  Two ways to keep a device copy:
+//   pinned  (ark_hip_msm_bases_pin .. _unpin): the caller DECLARES the slice immutable for that span (on the Rust side a
+//           guard that holds the shared borrow, so the compiler enforces it); any call whose base slice lies inside a
+//           pinned range uses the resident copy with no check at all;
+//   transparent (opt-in: ark_hip_msm_cache_config / ARK_HIP_BASE_CACHE_MB): copies keyed by (curve, address, length) and
+//           validated on EVERY call by a hash of the slice's FULL content, computed on host threads while the device
+//           already works from the cached copy; the result is withheld until the hash agrees, otherwise the copy is
+//           refreshed and the MSM rerun.  Never stale, at the price of one pass over the host slice per call.
 struct BaseCacheEntry {
   int curve = -1;
   const void* host = nullptr;
   size_t n = 0;
-  uint64_t fingerprint = 0;
+  uint64_t hash = 0;                  // transparent entries: base_hash of the content the device copy holds
   DevBuf dev;
   uint64_t last_use = 0;
   unsigned hits = 0;
+  int pins = 0;                       // > 0: pinned (never evicted, never validated)
+  bool no_prepare = false;            // the per-window table did not fit: do not retry on every call
   PreparedBases* prepared = nullptr;  // built after `auto_prepare` hits (off by default)
 };
-struct BaseCacheStats { uint64_t hits = 0, misses = 0, refreshed = 0, evicted = 0; };
+struct BaseCacheStats { uint64_t hits = 0, misses = 0, refreshed = 0, evicted = 0, pinned_hits = 0; };
 
 // One context per (logical) device: stream, workspaces, staging.  Every entry point runs on the calling thread's
 // current device (ark_hip_set_device / ark_hip_init; default: the first device initialised) and holds that
@@ -701,33 +708,73 @@ void free_prepared(PreparedBases* pb) {  // the caller has made sure no job in f
   delete pb;
 }
 
-// Fingerprint of a base set: every byte of up to 4096 evenly spaced points plus the last one.  A replaced or
-// regenerated set differs everywhere and is always noticed; an in-place edit of a few points between two calls is only
-// noticed if it touches a sampled point -- the documented limit of a transparent cache (callers that
-// patch an SRS in place call ark_hip_msm_cache_clear, or disable the cache with ARK_HIP_BASE_CACHE_MB=0).
-uint64_t base_fingerprint(const uint64_t* bases, size_t n, size_t words_per_point) {
-  uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n;
-  auto mix = [&](const uint64_t* p) {
-    for (size_t k = 0; k < words_per_point; k++) {
-      h ^= p[k];
-      h *= 0xff51afd7ed558ccdull;
-      h ^= h >> 29;
+// Hash of a base slice's FULL content (transparent entries).  64 KiB blocks, each hashed with four independent
+// multiply-rotate lanes (every step is a bijection of the lane state for a fixed word and injective in the word, so ANY
+// single-word edit changes the block hash), block hashes chained in order; blocks are dealt to `threads` host threads.
+// Not cryptographic: it guards against a caller's in-place edits, not an adversary.
+constexpr size_t HASH_BLOCK_WORDS = 8192;
+inline uint64_t hash_block(const uint64_t* p, size_t words, uint64_t seed) {
+  const uint64_t K = 0xff51afd7ed558ccdull;
+  uint64_t h0 = seed ^ 0x9e3779b97f4a7c15ull, h1 = seed ^ 0xc2b2ae3d27d4eb4full, h2 = seed ^ 0x165667b19e3779f9ull,
+           h3 = seed ^ 0x27d4eb2f165667c5ull;
+  auto step = [K](uint64_t h, uint64_t v) {
+    h = (h ^ v) * K;
+    return (h << 31) | (h >> 33);
+  };
+  size_t i = 0;
+  for (; i + 4 <= words; i += 4) {
+    h0 = step(h0, p[i]);
+    h1 = step(h1, p[i + 1]);
+    h2 = step(h2, p[i + 2]);
+    h3 = step(h3, p[i + 3]);
+  }
+  for (; i < words; i++) h0 = step(h0, p[i]);
+  return step(step(step(h0, h1), h2), h3);
+}
+int hash_threads() {
+  static int nt = -1;
+  if (nt < 0) {
+    const char* e = getenv("ARK_HIP_HASH_THREADS");
+    int v = e ? atoi(e) : 8;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && v > hw) v = hw;
+    nt = v < 1 ? 1 : v;
+  }
+  return nt;
+}
+uint64_t base_hash(const uint64_t* p, size_t words) {
+  const size_t nblocks = (words + HASH_BLOCK_WORDS - 1) / HASH_BLOCK_WORDS;
+  std::vector<uint64_t> bh(nblocks);
+  auto range = [&](size_t b0, size_t b1) {
+    for (size_t b = b0; b < b1; b++) {
+      const size_t off = b * HASH_BLOCK_WORDS;
+      bh[b] = hash_block(p + off, words - off < HASH_BLOCK_WORDS ? words - off : HASH_BLOCK_WORDS, (uint64_t)b);
     }
   };
-  const size_t S = n < 4096 ? n : 4096;
-  for (size_t k = 0; k < S; k++) mix(bases + (k * n / S) * words_per_point);
-  if (n) mix(bases + (n - 1) * words_per_point);
-  return h;
+  int nt = hash_threads();
+  if (nblocks < 64) nt = 1;
+  if (nt <= 1) {
+    range(0, nblocks);
+  } else {
+    std::vector<std::thread> th;
+    const size_t per = (nblocks + (size_t)nt - 1) / (size_t)nt;
+    for (int t = 1; t < nt; t++) {
+      const size_t b0 = (size_t)t * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+      if (b0 < b1) th.emplace_back(range, b0, b1);
+    }
+    range(0, per < nblocks ? per : nblocks);
+    for (auto& t : th) t.join();
+  }
+  return hash_block(bh.data(), nblocks, (uint64_t)words);
 }
+
 void cache_configure(Context* c) {
   if (c->cache_budget < 0) {
-    long long budget = -1;
+    // default 0: the transparent cache is OPT-IN (ark_hip_msm_cache_config or ARK_HIP_BASE_CACHE_MB) -- by default the
+    // host-pointer entries retain nothing of their inputs
+    long long budget = 0;
     if (const char* e = getenv("ARK_HIP_BASE_CACHE_MB")) budget = atoll(e) * (1ll << 20);
-    if (budget < 0) {
-      size_t fr = 0, tot = 0;
-      budget = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 4) : (8ll << 30);  // a quarter of the HBM
-    }
-    c->cache_budget = budget;
+    c->cache_budget = budget < 0 ? 0 : budget;
   }
   if (c->auto_prepare < 0) {
     const char* e = getenv("ARK_HIP_AUTO_PREPARE");
@@ -735,86 +782,180 @@ void cache_configure(Context* c) {
     if (c->auto_prepare < 0) c->auto_prepare = 0;
   }
 }
+long long cache_entry_bytes(const BaseCacheEntry& e) {   // device bytes an entry holds: the copy + its prepared table
+  return (long long)e.dev.cap + (e.prepared ? (long long)e.prepared->table.cap : 0);
+}
 void cache_drop(Context* c, size_t idx) {
   BaseCacheEntry& e = c->base_cache[idx];
   if (e.prepared) free_prepared(e.prepared);
   e.dev.release();
   c->base_cache.erase(c->base_cache.begin() + (long)idx);
 }
+// drops the transparent entries (pinned sets stay until their unpin)
 int cache_clear(Context* c) {
-  if (c->base_cache.empty()) return 0;
+  bool any = false;
+  for (auto& e : c->base_cache) any |= e.pins == 0;
+  if (!any) return 0;
   if (int rc = sync_compute(c)) return rc;  // a job in flight may still read a cached copy
-  while (!c->base_cache.empty()) cache_drop(c, c->base_cache.size() - 1);
+  for (size_t i = c->base_cache.size(); i-- > 0;)
+    if (c->base_cache[i].pins == 0) cache_drop(c, i);
   return 0;
 }
-// Device copy of `bases`.  *out = nullptr when the set cannot be cached (cache disabled, larger than the budget, no room):
-// the caller then streams bases and scalars through the ring.  *need_fill: the entry's buffer is reserved but does NOT
-// hold the bases yet (a miss, or the content changed) -- the caller uploads them, piecewise under the MSM's own kernels
-// (msm_stream), and drops the entry with cache_forget if that fails.
-int cache_get(Context* c, int curve, const uint64_t* bases, size_t n, BaseCacheEntry** out, bool* need_fill) {
-  *out = nullptr;
-  *need_fill = false;
-  cache_configure(c);
-  const size_t wpp = (size_t)CURVES[curve].fe_words * 2, bytes = n * wpp * 8;
-  if (c->cache_budget <= 0 || (long long)bytes > c->cache_budget || n == 0) return 0;
-  const uint64_t fp = base_fingerprint(bases, n, wpp);
-  c->cache_clock++;
-  for (auto& e : c->base_cache) {
-    if (e.curve != curve || e.host != (const void*)bases || e.n != n) continue;
-    e.last_use = c->cache_clock;
-    if (e.fingerprint != fp) {  // same address and length, different content: refresh in place
-      if (int rc = sync_compute(c)) return rc;
-      if (e.prepared) free_prepared(e.prepared);
-      e.prepared = nullptr;
-      e.fingerprint = fp;
-      e.hits = 0;
-      c->cache_stats.refreshed++;
-      *need_fill = true;
-    } else {
-      e.hits++;
-      c->cache_stats.hits++;
-    }
-    *out = &e;
-    return 0;
+// a pinned set that CONTAINS [bases, bases + n points): index, and the offset in points; -1 if none
+long cache_find_pinned(Context* c, int curve, const uint64_t* bases, size_t n, size_t* off_points) {
+  const size_t ab = (size_t)CURVES[curve].fe_words * 16;
+  for (size_t i = 0; i < c->base_cache.size(); i++) {
+    const BaseCacheEntry& e = c->base_cache[i];
+    if (e.pins <= 0 || e.curve != curve) continue;
+    const char* lo = (const char*)e.host;
+    const char* q = (const char*)bases;
+    if (q < lo || q + n * ab > lo + e.n * ab || (size_t)(q - lo) % ab) continue;
+    *off_points = (size_t)(q - lo) / ab;
+    return (long)i;
   }
-  // miss: make room (least recently used first), then upload
+  return -1;
+}
+long cache_find_exact(Context* c, int curve, const void* bases, size_t n, bool pinned) {
+  for (size_t i = 0; i < c->base_cache.size(); i++) {
+    const BaseCacheEntry& e = c->base_cache[i];
+    if (e.curve == curve && e.host == bases && e.n == n && (e.pins > 0) == pinned) return (long)i;
+  }
+  return -1;
+}
+// room for `bytes` more under the transparent budget: least recently used transparent entries go first
+// returns false if the set cannot be cached
+bool cache_make_room(Context* c, long long bytes, long keep = -1) {
+  if (bytes > c->cache_budget) return false;
   long long used = 0;
-  for (auto& e : c->base_cache) used += (long long)e.dev.cap;
+  for (auto& e : c->base_cache)
+    if (e.pins == 0) used += cache_entry_bytes(e);
   bool synced = false;
-  while (!c->base_cache.empty() && used + (long long)bytes > c->cache_budget) {
-    size_t lru = 0;
-    for (size_t i = 1; i < c->base_cache.size(); i++)
-      if (c->base_cache[i].last_use < c->base_cache[lru].last_use) lru = i;
+  while (used + bytes > c->cache_budget) {
+    long lru = -1;
+    for (size_t i = 0; i < c->base_cache.size(); i++) {
+      const BaseCacheEntry& e = c->base_cache[i];
+      if (e.pins > 0 || (long)i == keep) continue;
+      if (lru < 0 || e.last_use < c->base_cache[(size_t)lru].last_use) lru = (long)i;
+    }
+    if (lru < 0) return false;
     if (!synced) {
-      if (int rc = sync_compute(c)) return rc;
+      if (sync_compute(c)) return false;
       synced = true;
     }
-    used -= (long long)c->base_cache[lru].dev.cap;
-    cache_drop(c, lru);
+    used -= cache_entry_bytes(c->base_cache[(size_t)lru]);
+    cache_drop(c, (size_t)lru);
+    if (keep > lru) keep--;
     c->cache_stats.evicted++;
   }
+  return true;
+}
+// an entry whose upload did not complete must not be found again
+void cache_forget(Context* c, int curve, const void* host, size_t n, bool pinned) {
+  const long i = cache_find_exact(c, curve, host, n, pinned);
+  if (i < 0) return;
+  (void)sync_compute(c);
+  (void)hipStreamSynchronize(c->copy_stream);
+  cache_drop(c, (size_t)i);
+}
+// after `auto_prepare` hits on the WHOLE set: build its per-window table (a failed build leaves the plain path in place)
+void cache_maybe_prepare(Context* c, BaseCacheEntry& e) {
+  if (c->auto_prepare <= 0 || e.prepared || e.no_prepare || e.hits < (unsigned)c->auto_prepare) return;
+  if (e.pins == 0) {   // transparent entries: the table counts against the budget
+    const MsmPlan pl = msm_make_plan(e.n, msm_scalar_bits(e.curve), msm_mul_cost(e.curve), true, msm_lazy28(e.curve));
+    const long long table = (long long)pl.W * (long long)e.n * CURVES[e.curve].fe_words * 16;
+    const void* host = e.host;
+    const size_t n = e.n;
+    const int curve = e.curve;
+    const long self = cache_find_exact(c, curve, host, n, false);
+    if (!cache_make_room(c, table + table / 8, self)) {
+      c->base_cache[(size_t)cache_find_exact(c, curve, host, n, false)].no_prepare = true;
+      return;
+    }
+    BaseCacheEntry& e2 = c->base_cache[(size_t)cache_find_exact(c, curve, host, n, false)];  // eviction moved entries
+    ark_hip_msm_bases* pb = nullptr;
+    if (ark_hip_msm_bases_prepare_device(curve, e2.dev.p, n, &pb) == 0) e2.prepared = (PreparedBases*)pb;
+    else e2.no_prepare = true;
+    return;
+  }
+  ark_hip_msm_bases* pb = nullptr;
+  if (ark_hip_msm_bases_prepare_device(e.curve, e.dev.p, e.n, &pb) == 0) e.prepared = (PreparedBases*)pb;
+  else e.no_prepare = true;
+}
+
+// Runs one host-pointer MSM against whatever device copy of `bases` the context may use:
+//   run(d_bases, fill, entry)   d_bases == nullptr: no resident copy -- stream the bases with the scalars;
+//                               fill: d_bases is reserved but EMPTY -- upload `bases` into it on the way;
+//                               entry: the cache entry when the WHOLE set is the operand (prepared table), else nullptr.
+// Pinned range: used as is.  Transparent entry (opt-in): the run is speculative -- the slice's full-content hash is
+// computed on host threads meanwhile and the result only stands if it matches the hash of what the device copy holds.
+template <class Run>
+int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run run) {
+  const size_t wpp = (size_t)CURVES[curve].fe_words * 2, bytes = n * wpp * 8;
+  size_t off = 0;
+  const long pi = cache_find_pinned(c, curve, bases, n, &off);
+  if (pi >= 0) {
+    BaseCacheEntry& e = c->base_cache[(size_t)pi];
+    const bool whole = off == 0 && n == e.n;
+    if (whole) {
+      e.hits++;
+      cache_maybe_prepare(c, e);
+    }
+    c->cache_stats.pinned_hits++;
+    return run((const void*)((const char*)e.dev.p + off * wpp * 8), false, whole ? &e : nullptr);
+  }
+  cache_configure(c);
+  if (c->cache_budget <= 0 || (long long)bytes > c->cache_budget || n == 0) return run(nullptr, false, nullptr);
+  c->cache_clock++;
+  long idx = cache_find_exact(c, curve, bases, n, false);
+  uint64_t h = 0;
+  std::thread hasher([&h, bases, n, wpp]() { h = base_hash(bases, n * wpp); });
+  if (idx >= 0) {
+    {
+      BaseCacheEntry& e = c->base_cache[(size_t)idx];
+      e.last_use = c->cache_clock;
+      cache_maybe_prepare(c, e);
+    }
+    idx = cache_find_exact(c, curve, bases, n, false);
+    int rc = run(c->base_cache[(size_t)idx].dev.p, false, &c->base_cache[(size_t)idx]);   // speculative
+    hasher.join();
+    BaseCacheEntry& e = c->base_cache[(size_t)idx];
+    if (h == e.hash) {
+      e.hits++;
+      c->cache_stats.hits++;
+      return rc;
+    }
+    // the slice changed under the same address and length: refresh the copy and run again
+    if (int rc2 = sync_compute(c)) return rc2;
+    if (e.prepared) free_prepared(e.prepared);
+    e.prepared = nullptr;
+    e.no_prepare = false;
+    e.hash = h;
+    e.hits = 0;
+    c->cache_stats.refreshed++;
+    rc = run(e.dev.p, true, nullptr);
+    if (rc) cache_forget(c, curve, bases, n, false);
+    return rc;
+  }
+  // miss: make room (least recently used first), then fill under the call's own kernels
   BaseCacheEntry ne;
   ne.curve = curve;
   ne.host = bases;
   ne.n = n;
-  ne.fingerprint = fp;
   ne.last_use = c->cache_clock;
-  if (ne.dev.ensure(bytes)) return 0;  // no room on the device right now: not an error, the caller streams instead
+  if (!cache_make_room(c, (long long)(bytes + bytes / 8 + 256)) || ne.dev.ensure(bytes)) {
+    hasher.join();   // no room on the device right now: not an error, the bases stream instead
+    return run(nullptr, false, nullptr);
+  }
   c->cache_stats.misses++;
   c->base_cache.push_back(ne);
-  *out = &c->base_cache.back();
-  *need_fill = true;
+  const int rc = run(ne.dev.p, true, nullptr);
+  hasher.join();
+  if (rc) {
+    cache_forget(c, curve, bases, n, false);
+    return rc;
+  }
+  c->base_cache[(size_t)cache_find_exact(c, curve, bases, n, false)].hash = h;
   return 0;
-}
-// an entry whose upload did not complete must not be found again
-void cache_forget(Context* c, int curve, const void* host, size_t n) {
-  for (size_t i = 0; i < c->base_cache.size(); i++)
-    if (c->base_cache[i].curve == curve && c->base_cache[i].host == host && c->base_cache[i].n == n) {
-      (void)sync_compute(c);
-      (void)hipStreamSynchronize(c->copy_stream);
-      cache_drop(c, i);
-      return;
-    }
 }
 
 // One MSM whose scalars (and, with `host_bases`, bases) come from host memory, against `d_bases` (resident; with
@@ -824,7 +965,8 @@ void cache_forget(Context* c, int curve, const void* host, size_t n) {
 //   otherwise (msm_chunks with its fixed 2^20 steps): independent MSMs whose results are added on the host (the
 //   reference's own chunk sum, variable_base/mod.rs:542-557).
 int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_bases, const uint64_t* scalars, size_t n,
-               int mont, size_t step, uint64_t* out_xyz, bool allow_shared = true, bool growing = false) {
+               int mont, size_t step, uint64_t* out_xyz, bool allow_shared = true, bool growing = false,
+               bool taper = false) {
   const size_t ab = (size_t)CURVES[curve].fe_words * 16;
   const size_t pw = (size_t)CURVES[curve].fe_words * 3;
   if (step == 0 || step > n) step = n;
@@ -845,6 +987,24 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
       cur *= 2;
     }
     step = sizes.back();   // the largest piece sizes the ring buffers
+  } else if (taper && host_bases && n >= ((size_t)1 << 21) && !getenv("ARK_HIP_STREAM_PIECES") &&
+             !(getenv("ARK_HIP_STREAM_TAPER") && getenv("ARK_HIP_STREAM_TAPER")[0] == '0')) {
+    // bases AND scalars cross PCIe (2^24 BLS12-381 G1: 2 GiB, ~37-47 ms of copy against 36 ms of kernels).  Whichever
+    // of the two sets the pace, the call pays for one un-hidden end: the FIRST piece's copy when the kernels are the
+    // slower side, the LAST piece's kernels + the reduction when the copy is.  So both ends are small (>= 2^18 pairs:
+    // a piece's ~20 launches and its pass over the touched buckets are per piece) and the middle pieces large.
+    static const int F32[] = {2, 4, 10, 8, 4, 2, 1, 1}, F16[] = {1, 2, 6, 4, 2, 1}, F8[] = {1, 2, 3, 1, 1};
+    const int* fr = n >= ((size_t)1 << 23) ? F32 : (n >= ((size_t)1 << 22) ? F16 : F8);
+    const int cnt = n >= ((size_t)1 << 23) ? 8 : (n >= ((size_t)1 << 22) ? 6 : 5);
+    const size_t unit = (n / (n >= ((size_t)1 << 23) ? 32 : (n >= ((size_t)1 << 22) ? 16 : 8))) & ~(size_t)255;
+    size_t left = n;
+    step = 0;
+    for (int k = 0; k < cnt; k++) {
+      const size_t take = k + 1 == cnt ? left : unit * (size_t)fr[k];
+      sizes.push_back(take);
+      left -= take;
+      step = take > step ? take : step;
+    }
   } else {
     for (size_t off = 0; off < n; off += step) sizes.push_back(n - off < step ? n - off : step);
   }
@@ -1323,32 +1483,67 @@ int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars,
 }
 
 // The entry SWCurveConfig::msm / the msm_bigint hook land in (rust/ark-hip/src/msm.rs, patches/0001): host slices in,
-// Projective out.  The base set is looked up in (or entered into) the context's resident-base cache, so that a prover
-// calling with the same SRS slice again pays only for its scalars; those are streamed in pieces (msm_stream).
+// Projective out -- a function of the two slices.  Default: bases and scalars stream over PCIe in pieces under the
+// previous piece's kernels (msm_stream), nothing is retained.  A base slice inside a PINNED range (ark_hip_msm_bases_pin)
+// or found in the opt-in transparent cache uses the resident copy and uploads only its scalars (msm_with_bases).
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xyz) {
   if (curve < 0 || curve > 4 || !out_xyz || (n && (!bases || !scalars))) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
   Context* c = sc.c;
   if (n == 0) return msm_stream(c, curve, nullptr, nullptr, nullptr, 0, mont, 0, out_xyz);
-  BaseCacheEntry* ce = nullptr;
-  bool need_fill = false;
-  if (int rc = cache_get(c, curve, bases, n, &ce, &need_fill)) return rc;
-  if (!ce)  // not cacheable (disabled / over budget / no room): bases and scalars both stream through the ring
-    return msm_stream(c, curve, nullptr, bases, scalars, n, mont, msm_stream_step(n), out_xyz);
-  if (need_fill) {  // first call with this set: its bases cross PCIe with the scalars, piece k+1 under piece k's kernels
-    const int rc = msm_stream(c, curve, ce->dev.p, bases, scalars, n, mont, msm_stream_step(n), out_xyz);
-    if (rc) cache_forget(c, curve, bases, n);
+  return msm_with_bases(c, curve, bases, n, [&](const void* d_bases, bool fill, BaseCacheEntry* ce) -> int {
+    if (!d_bases)   // no resident copy: bases and scalars both stream through the ring, the tail in shrinking pieces
+      return msm_stream(c, curve, nullptr, bases, scalars, n, mont, msm_stream_step(n), out_xyz, true, false, true);
+    if (fill)       // first call with this set: its bases cross PCIe with the scalars, piece k+1 under piece k's kernels
+      return msm_stream(c, curve, d_bases, bases, scalars, n, mont, msm_stream_step(n), out_xyz, true, false, true);
+    if (ce && ce->prepared) return ark_hip_msm_prepared((const ark_hip_msm_bases*)ce->prepared, scalars, n, mont, out_xyz);
+    const char* eg = getenv("ARK_HIP_STREAM_GROWING");   // =0: equal pieces (msm_stream_step); a forced piece count also
+    const bool growing = !(eg && eg[0] == '0') && !getenv("ARK_HIP_STREAM_PIECES");
+    return msm_stream(c, curve, d_bases, nullptr, scalars, n, mont, msm_stream_step(n), out_xyz, true, growing);
+  });
+}
+
+// ---- pinned base sets ----
+// ark_hip_msm_bases_pin: the caller declares bases[0 .. n) immutable until the matching unpin; the set is uploaded now
+// and every host-pointer MSM whose base slice lies inside it (sub-slices at point boundaries included: msm_unchecked's
+// truncation, msm_chunks / ChunkedPippenger steps) runs against the resident copy.  Pins nest (a count per
+// (curve, address, n)).  Pinned sets are outside the transparent cache's budget and are never evicted.
+int ark_hip_msm_bases_pin(int curve, const uint64_t* bases, size_t n) {
+  if (curve < 0 || curve > 4 || !bases || n == 0) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  long i = cache_find_exact(c, curve, bases, n, true);
+  if (i >= 0) {
+    c->base_cache[(size_t)i].pins++;
+    return 0;
+  }
+  const size_t bytes = n * (size_t)CURVES[curve].fe_words * 16;
+  BaseCacheEntry ne;
+  ne.curve = curve;
+  ne.host = bases;
+  ne.n = n;
+  ne.pins = 1;
+  ne.last_use = ++c->cache_clock;
+  if (ne.dev.ensure(bytes)) return ARK_HIP_ERR_NOMEM;
+  int rc = c->stager.upload(ne.dev.p, bases, bytes, c->copy_stream);
+  if (rc == 0 && hipStreamSynchronize(c->copy_stream) != hipSuccess) rc = -1000;
+  if (rc) {
+    ne.dev.release();
     return rc;
   }
-  if (c->auto_prepare > 0 && !ce->prepared && ce->hits >= (unsigned)c->auto_prepare) {
-    ark_hip_msm_bases* pb = nullptr;  // a failed build (no room for the table) just leaves the plain path in place
-    if (ark_hip_msm_bases_prepare_device(curve, ce->dev.p, n, &pb) == 0) ce->prepared = (PreparedBases*)pb;
-    else ce->hits = 0;
-  }
-  if (ce->prepared) return ark_hip_msm_prepared((const ark_hip_msm_bases*)ce->prepared, scalars, n, mont, out_xyz);
-  const char* eg = getenv("ARK_HIP_STREAM_GROWING");   // =0: equal pieces (msm_stream_step); a forced piece count also
-  const bool growing = !(eg && eg[0] == '0') && !getenv("ARK_HIP_STREAM_PIECES");
-  return msm_stream(c, curve, ce->dev.p, nullptr, scalars, n, mont, msm_stream_step(n), out_xyz, true, growing);
+  c->base_cache.push_back(ne);
+  return 0;
+}
+int ark_hip_msm_bases_unpin(int curve, const uint64_t* bases, size_t n) {
+  if (curve < 0 || curve > 4 || !bases) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  const long i = cache_find_exact(c, curve, bases, n, true);
+  if (i < 0) return ARK_HIP_ERR_ARG;
+  if (--c->base_cache[(size_t)i].pins > 0) return 0;
+  if (int rc = sync_compute(c)) return rc;   // a job in flight may still read the copy
+  cache_drop(c, (size_t)i);
+  return 0;
 }
 
 // ---- narrow scalars: VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64 (variable_base/mod.rs:87-117) ----
@@ -1375,30 +1570,28 @@ int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, 
   ARK_SCOPE(sc);
   Context* c = sc.c;
   if (n == 0) return ark_hip_msm_sw_small_device(curve, nullptr, nullptr, 0, scalar_bytes, max_bits, out_xyz);
-  // the base set goes through the same resident-base cache as ark_hip_msm_sw; the scalars are small: one upload
-  BaseCacheEntry* ce = nullptr;
-  bool need_fill = false;
-  if (int rc = cache_get(c, curve, bases, n, &ce, &need_fill)) return rc;
+  // the base set is looked up like ark_hip_msm_sw's (pinned range / opt-in transparent cache); the scalars are small:
+  // one upload.  Uploads ride the copy stream and are complete before the MSM is enqueued on either lane.
   const size_t bb = n * (size_t)CURVES[curve].fe_words * 16, sb = n * (size_t)scalar_bytes;
-  const void* d_bases = nullptr;
-  if (ce) {
-    if (need_fill) {
-      int rc = c->stager.upload(ce->dev.p, bases, bb, c->copy_stream);
-      if (rc == 0 && hipStreamSynchronize(c->copy_stream) != hipSuccess) rc = -1000;
-      if (rc) {
-        cache_forget(c, curve, bases, n);
-        return rc;
+  return msm_with_bases(c, curve, bases, n, [&](const void* d_res, bool fill, BaseCacheEntry*) -> int {
+    const void* d_bases = d_res;
+    if (!d_bases) {
+      if (c->stage_a.cap < bb) {
+        if (int rc = sync_compute(c)) return rc;
+        if (c->stage_a.ensure(bb)) return ARK_HIP_ERR_NOMEM;
       }
+      d_bases = c->stage_a.p;
     }
-    d_bases = ce->dev.p;
-  } else {
-    if (c->stage_a.ensure(bb)) return ARK_HIP_ERR_NOMEM;
-    if (int rc = c->stager.upload(c->stage_a.p, bases, bb, c->stream)) return rc;
-    d_bases = c->stage_a.p;
-  }
-  if (c->stage_b.ensure(sb)) return ARK_HIP_ERR_NOMEM;
-  if (int rc = c->stager.upload(c->stage_b.p, scalars, sb, c->stream)) return rc;
-  return ark_hip_msm_sw_small_device(curve, d_bases, c->stage_b.p, n, scalar_bytes, max_bits, out_xyz);
+    if (!d_res || fill)
+      if (int rc = c->stager.upload((void*)d_bases, bases, bb, c->copy_stream)) return rc;
+    if (c->stage_b.cap < sb) {
+      if (int rc = sync_compute(c)) return rc;
+      if (c->stage_b.ensure(sb)) return ARK_HIP_ERR_NOMEM;
+    }
+    if (int rc = c->stager.upload(c->stage_b.p, scalars, sb, c->copy_stream)) return rc;
+    ARK_HIP_TRY(hipStreamSynchronize(c->copy_stream));   // staged uploads leave their last slices in flight
+    return ark_hip_msm_sw_small_device(curve, d_bases, c->stage_b.p, n, scalar_bytes, max_bits, out_xyz);
+  });
 }
 
 // The narrow entries against a PREPARED base set: the per-window table was laid out for 255-bit scalars (its wide windows
@@ -1431,17 +1624,26 @@ int ark_hip_msm_cache_clear(void) {
   ARK_SCOPE(sc);
   return cache_clear(sc.c);
 }
-int ark_hip_msm_cache_stats(uint64_t out[6]) {
+int ark_hip_msm_cache_stats(uint64_t out[8]) {
   if (!out) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
-  uint64_t bytes = 0;
-  for (auto& e : sc.c->base_cache) bytes += e.dev.cap;
-  out[0] = sc.c->base_cache.size();
+  uint64_t bytes = 0, entries = 0, pinned = 0;
+  for (auto& e : sc.c->base_cache) {
+    if (e.pins > 0) {
+      pinned++;
+    } else {
+      entries++;
+      bytes += (uint64_t)cache_entry_bytes(e);
+    }
+  }
+  out[0] = entries;
   out[1] = bytes;
   out[2] = sc.c->cache_stats.hits;
   out[3] = sc.c->cache_stats.misses;
   out[4] = sc.c->cache_stats.refreshed;
   out[5] = sc.c->cache_stats.evicted;
+  out[6] = pinned;
+  out[7] = sc.c->cache_stats.pinned_hits;
   return 0;
 }
 

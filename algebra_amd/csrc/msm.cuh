@@ -1152,6 +1152,7 @@ struct DevBuf {
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
       fprintf(stderr, "ark_hip: hipMalloc(%zu) failed: %s\n", want, hipGetErrorString(e));
+      (void)hipGetLastError();  // callers may fall back to a smaller plan / the streaming path: no sticky error left behind
       return -1;
     }
     cap = want;

@@ -45,9 +45,16 @@ def _sharded_in_library(curve, bases_shard, scalars_shard, mont):
     """local MSM + all-gather + sum, all inside libark_hip.so (ark_hip_msm_sw_device_sharded: RCCL)"""
     import ctypes as C
     from ._lib import check, lib
+    import torch
+    from .msm import _rows
     cid = cv.curve_id(curve)
     out = np.zeros(cv.projective_words(cid), dtype=np.uint64)
-    n = min(bases_shard.numel() * 8 // cv.affine_bytes(cid), scalars_shard.numel() // 4)
+    # the library reads raw device memory on its own non-blocking stream: the shards must be dense, and whatever produced
+    # them on torch's stream (a slice + .contiguous(), a scalar computation) must have finished (ADVICE r3)
+    if not (bases_shard.is_contiguous() and scalars_shard.is_contiguous()):
+        raise ValueError("sharded MSM needs contiguous shards (a strided view would be read as dense memory)")
+    n = min(_rows(bases_shard, cv.affine_words(cid)), _rows(scalars_shard, cv.SCALAR_WORDS))
+    torch.cuda.current_stream().synchronize()
     check(lib().ark_hip_msm_sw_device_sharded(cid, bases_shard.data_ptr(), scalars_shard.data_ptr(), n, mont,
                                               out.ctypes.data_as(C.c_void_p)), "ark_hip_msm_sw_device_sharded")
     return out

@@ -79,9 +79,68 @@ def msm_bigint(curve, bases, bigints):
     return _run(curve, bases, bigints, n, False)
 
 
+def msm_plan(curve, n, prepared=False):
+    """(window bits, windows) the library would use for n pairs (ark_hip_msm_plan: host arithmetic only)."""
+    c, w = C.c_int(), C.c_int()
+    check(lib().ark_hip_msm_plan(cv.curve_id(curve), int(n), int(bool(prepared)), C.byref(c), C.byref(w)), "ark_hip_msm_plan")
+    return c.value, w.value
+
+
+class ResidentBases:
+    """A base array pinned on the GPU (ark_hip_msm_bases_pin): while the pin lives the caller does NOT modify the
+    array, and every host-array msm / msm_bigint / msm_u* whose bases are this array -- or a row range of it -- runs
+    against the resident copy and uploads only its scalars.  The Rust twin (ark_hip::msm::ResidentBases) holds the
+    shared borrow of the slice, which makes the promise a compile-time fact; here the array is made read-only for the
+    pin's lifetime when numpy allows it.  Use as a context manager or call unpin()."""
+
+    def __init__(self, curve, bases):
+        self.curve = cv.curve_id(curve)
+        a = np.asarray(bases)
+        if a.dtype != np.uint64 or not a.flags.c_contiguous:
+            raise TypeError("pin needs a C-contiguous uint64 array (a copy would be pinned at another address)")
+        self.bases = a
+        self.n = a.size // cv.affine_words(self.curve)
+        self._was_writeable = bool(a.flags.writeable)
+        check(lib().ark_hip_msm_bases_pin(self.curve, a.ctypes.data_as(C.c_void_p), self.n), "ark_hip_msm_bases_pin")
+        self._pinned = True
+        try:
+            a.flags.writeable = False
+        except ValueError:
+            pass
+
+    def unpin(self):
+        if self._pinned:
+            self._pinned = False
+            check(lib().ark_hip_msm_bases_unpin(self.curve, self.bases.ctypes.data_as(C.c_void_p), self.n),
+                  "ark_hip_msm_bases_unpin")
+            if self._was_writeable:
+                try:
+                    self.bases.flags.writeable = True
+                except ValueError:
+                    pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.unpin()
+
+    def __del__(self):
+        try:
+            self.unpin()
+        except Exception:
+            pass
+
+
+def pin_bases(curve, bases):
+    """ResidentBases(curve, bases): `with A.pin_bases(cid, srs): ...` keeps the SRS on the GPU for the block."""
+    return ResidentBases(curve, bases)
+
+
 def base_cache_config(budget_bytes=-1, auto_prepare_after=-1):
-    """Resident-base cache of the host-array entry (ark_hip_msm_cache_config): numpy base sets passed to msm /
-    msm_bigint are kept on the GPU per (array address, length, sampled fingerprint).  0 bytes disables it."""
+    """Transparent resident-base cache of the host-array entry (ark_hip_msm_cache_config; OFF by default): numpy base
+    sets passed to msm / msm_bigint are kept on the GPU per (array address, length) and validated on every call by a
+    hash of their full content.  0 bytes disables it."""
     check(lib().ark_hip_msm_cache_config(int(budget_bytes), int(auto_prepare_after)), "ark_hip_msm_cache_config")
 
 
@@ -90,9 +149,10 @@ def base_cache_clear():
 
 
 def base_cache_stats():
-    out = (C.c_uint64 * 6)()
+    out = (C.c_uint64 * 8)()
     check(lib().ark_hip_msm_cache_stats(out), "ark_hip_msm_cache_stats")
-    return dict(zip(("entries", "bytes", "hits", "misses", "refreshed", "evicted"), [int(v) for v in out]))
+    return dict(zip(("entries", "bytes", "hits", "misses", "refreshed", "evicted", "pinned", "pinned_hits"),
+                    [int(v) for v in out]))
 
 
 def sum_projective(curve, points):

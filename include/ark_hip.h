@@ -91,27 +91,44 @@ int ark_hip_curve_generator(int curve, uint64_t* out_xy);
  * silently drops bits above ceil(bits/c)*c there, i.e. its result depends on the window size it happened to pick. */
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int scalars_are_montgomery,
                    uint64_t* out_xyz);
-/* Resident-base cache of ark_hip_msm_sw (and of ark_hip_msm_sw_multi, per device).  The reference's callers hand the SAME
- * `&[Affine]` -- an SRS -- to msm / msm_bigint on every call (bench-templates/src/macros/ec.rs:223-240 does exactly that),
- * so the host-pointer entry keeps a device copy per (curve, host address, length), validated on every call by a
- * fingerprint of sampled content (4096 evenly spaced points + the last): a repeat call uploads only its scalars, which
- * stream in pieces behind the previous piece's kernels.  A set that was replaced or regenerated at the same address is
- * noticed and re-uploaded; an in-place edit confined to unsampled points is NOT -- call ark_hip_msm_cache_clear after
- * patching a base set in place, or disable the cache.  Least-recently-used sets are dropped beyond the budget.
- *   ark_hip_msm_cache_config(budget_bytes, auto_prepare_after): budget < 0 keeps the current value (default: a quarter
- *     of the device memory, or ARK_HIP_BASE_CACHE_MB), 0 disables and empties the cache; auto_prepare_after = K > 0
- *     builds the per-window table of a cached set (ark_hip_msm_bases_prepare) once it has been hit K times
- *     (default 0 = never, or ARK_HIP_AUTO_PREPARE), < 0 keeps the current value.
- *   ark_hip_msm_cache_stats: [entries, device bytes, hits, misses, refreshed (content changed), evicted]. */
+/* ark_hip_msm_sw is a FUNCTION OF ITS TWO SLICES, like the reference (`bases: &[Affine]` is borrowed for the call,
+ * variable_base/mod.rs:59-85): by default bases and scalars stream over PCIe together, piece k+1 under piece k's kernels,
+ * and the library retains nothing of them.  Provers hand the SAME base slice -- an SRS -- to call after call
+ * (bench-templates/src/macros/ec.rs:223-240 does exactly that); two ways to keep it resident:
+ *
+ * Pinned base sets.  ark_hip_msm_bases_pin(curve, bases, n) uploads the set now and declares bases[0 .. n) IMMUTABLE until
+ * the matching ark_hip_msm_bases_unpin(curve, bases, n).  Every ark_hip_msm_sw / ark_hip_msm_sw_small call on this device
+ * whose base slice lies inside a pinned range (at a point boundary: the whole set, msm_unchecked's truncation, the steps
+ * of msm_chunks / ChunkedPippenger) runs against the resident copy and uploads only its scalars -- no validation, the
+ * declaration is the contract (the Rust guard ark_hip::msm::ResidentBases holds the shared borrow for the pin's lifetime,
+ * so the compiler enforces it).  Pins of the same (curve, address, n) nest.  ARK_HIP_ERR_NOMEM if the copy does not fit,
+ * ARK_HIP_ERR_ARG for an unpin without a pin.
+ *
+ * Transparent cache (OPT-IN: off unless ark_hip_msm_cache_config / ARK_HIP_BASE_CACHE_MB give it a budget).  Device copies
+ * keyed by (curve, host address, length) and validated on EVERY call by a hash of the slice's FULL content: the hash is
+ * computed on host threads (ARK_HIP_HASH_THREADS, default 8) while the device already works from the cached copy, and
+ * the result is returned only if it matches the hash of what the copy holds -- otherwise the copy is refreshed and the MSM
+ * rerun.  Any in-place edit of the slice, of a single limb, is therefore honoured; a hit costs one pass over the host
+ * slice instead of its PCIe transfer.  Least-recently-used sets (with their tables) are dropped beyond the budget.
+ *   ark_hip_msm_cache_config(budget_bytes, auto_prepare_after): budget < 0 keeps the current value (default 0 = off, or
+ *     ARK_HIP_BASE_CACHE_MB), 0 disables and empties the cache; auto_prepare_after = K > 0 builds the per-window table of
+ *     a resident set -- pinned or cached -- once the WHOLE set has been the operand K times (default 0 = never, or
+ *     ARK_HIP_AUTO_PREPARE; a cached set's table counts against the budget), < 0 keeps the current value.
+ *   ark_hip_msm_cache_clear: drops the transparent entries (pinned sets stay).
+ *   ark_hip_msm_cache_stats: [cached sets, their device bytes, hits, misses, refreshed (content changed), evicted,
+ *     pinned sets, pinned hits]. */
+int ark_hip_msm_bases_pin(int curve, const uint64_t* bases, size_t n);
+int ark_hip_msm_bases_unpin(int curve, const uint64_t* bases, size_t n);
 int ark_hip_msm_cache_config(long long budget_bytes, int auto_prepare_after);
 int ark_hip_msm_cache_clear(void);
-int ark_hip_msm_cache_stats(uint64_t out[6]);
+int ark_hip_msm_cache_stats(uint64_t out[8]);
 /* VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64 (variable_base/mod.rs:87-117; CPU bodies msm_binary /
  * msm_u8.. :373-434): scalars are n unsigned integers of scalar_bytes (1, 2, 4 or 8) bytes -- exactly the reference's
  * &[bool] (one byte each, max_bits = 1), &[u8], &[u16], &[u32], &[u64] -- whose low max_bits bits may be set (0 = all
  * 8 * scalar_bytes).  Only the ceil((max_bits + 1) / c) windows such scalars reach are built: nothing is widened to 32
  * bytes (a u8 vector uploads 1/32 of what msm_bigint would) and no empty window is sorted.  The host-pointer form shares
- * ark_hip_msm_sw's resident-base cache. */
+ * ark_hip_msm_sw's
+ * pinned sets / opt-in cache. */
 int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, size_t n, int scalar_bytes, int max_bits,
                          uint64_t* out_xyz);
 int ark_hip_msm_sw_small_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalar_bytes,

@@ -80,17 +80,35 @@ using Bls12_377G1 = CurveTag<ARK_HIP_BLS12_377_G1, 6, ARK_HIP_BLS12_377_FR>;
 using Bls12_377G2 = CurveTag<ARK_HIP_BLS12_377_G2, 12, ARK_HIP_BLS12_377_FR>;
 using Bls12_381G2 = CurveTag<ARK_HIP_BLS12_381_G2, 12, ARK_HIP_BLS12_381_FR>;
 
-// Resident-base cache behind VariableBaseMSM<..>::msm / msm_bigint (ark_hip_msm_cache_* in ark_hip.h): base vectors
-// passed again at the same address stay on the GPU; a repeat call uploads only its scalars.
-struct BaseCacheStats { uint64_t entries, bytes, hits, misses, refreshed, evicted; };
+// VariableBaseMSM<..>::msm / msm_bigint are functions of their two spans (bases and scalars stream over PCIe together).
+// ResidentBases pins a base vector on the GPU for its lifetime: while it lives the caller does not modify the vector, and
+// every msm / msm_bigint / msm_u* whose bases lie inside it runs against the resident copy (ark_hip_msm_bases_pin).
+template <class Curve>
+class ResidentBases {
+ public:
+  ResidentBases(const typename Curve::AffineT* bases, size_t n) : p_(bases), n_(n) {
+    check(ark_hip_msm_bases_pin(Curve::ID, reinterpret_cast<const uint64_t*>(bases), n), "ark_hip_msm_bases_pin");
+  }
+  explicit ResidentBases(const std::vector<typename Curve::AffineT>& bases) : ResidentBases(bases.data(), bases.size()) {}
+  ResidentBases(const ResidentBases&) = delete;
+  ResidentBases& operator=(const ResidentBases&) = delete;
+  ~ResidentBases() { (void)ark_hip_msm_bases_unpin(Curve::ID, reinterpret_cast<const uint64_t*>(p_), n_); }
+
+ private:
+  const typename Curve::AffineT* p_;
+  size_t n_;
+};
+// The opt-in transparent cache (ark_hip_msm_cache_* in ark_hip.h; off by default): base vectors passed again at the same
+// address stay on the GPU, validated on every call by a hash of their full content.
+struct BaseCacheStats { uint64_t entries, bytes, hits, misses, refreshed, evicted, pinned, pinned_hits; };
 inline void base_cache_config(long long budget_bytes = -1, int auto_prepare_after = -1) {
   check(ark_hip_msm_cache_config(budget_bytes, auto_prepare_after), "ark_hip_msm_cache_config");
 }
 inline void base_cache_clear() { check(ark_hip_msm_cache_clear(), "ark_hip_msm_cache_clear"); }
 inline BaseCacheStats base_cache_stats() {
-  uint64_t o[6];
+  uint64_t o[8];
   check(ark_hip_msm_cache_stats(o), "ark_hip_msm_cache_stats");
-  return BaseCacheStats{o[0], o[1], o[2], o[3], o[4], o[5]};
+  return BaseCacheStats{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
 }
 
 // Result<Projective, usize> of VariableBaseMSM::msm

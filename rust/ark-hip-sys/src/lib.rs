@@ -71,6 +71,10 @@ extern "C" {
                                 max_bits: c_int, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_msm_sw_small_device(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,
                                        scalar_bytes: c_int, max_bits: c_int, out_xyz: *mut u64) -> c_int;
+    /// Declares `bases[0..n)` immutable until the matching unpin and uploads it: host-pointer MSMs whose base slice lies
+    /// inside a pinned range run against the resident copy.
+    pub fn ark_hip_msm_bases_pin(curve: c_int, bases: *const u64, n: usize) -> c_int;
+    pub fn ark_hip_msm_bases_unpin(curve: c_int, bases: *const u64, n: usize) -> c_int;
     pub fn ark_hip_msm_cache_config(budget_bytes: c_longlong, auto_prepare_after: c_int) -> c_int;
     pub fn ark_hip_msm_cache_clear() -> c_int;
     pub fn ark_hip_msm_cache_stats(out: *mut u64) -> c_int;

@@ -140,12 +140,49 @@ pub fn sw_msm_chunks<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalar
     (rc == 0).then(|| unsafe { out.assume_init() })
 }
 
-/// Resident-base cache behind `sw_msm` / `sw_msm_bigint` (include/ark_hip.h, `ark_hip_msm_cache_*`): the library keeps a
-/// device copy of every base slice it is handed, keyed by (curve, address, length) and validated by a fingerprint of
-/// sampled content, so that `G::msm_bigint(&srs, ..)` called again with the same SRS uploads only its scalars.
-/// Rust's borrow rules make the common case safe by construction (the slice cannot change during a call); between calls a
-/// `Vec` that is overwritten wholesale or reallocated is noticed, one that is patched in a few places may not be --
-/// call [`base_cache_clear`] after such an edit.  `budget_bytes = Some(0)` turns the cache off.
+/// A base slice pinned on the GPU for the guard's lifetime (`ark_hip_msm_bases_pin` / `_unpin`).
+///
+/// `sw_msm` / `sw_msm_bigint` / `sw_msm_small` are functions of their two slices: by default bases and scalars cross
+/// PCIe together on every call and the library keeps nothing.  A prover that calls `G::msm(&srs, ..)` again and again
+/// pins the SRS once:
+///
+/// ```ignore
+/// let _resident = ResidentBases::pin(ark_hip::BLS12_381_G1, &srs)?;   // uploads srs; borrows it until dropped
+/// for w in witnesses { let c = G1Projective::msm(&srs, &w)?; }       // scalars only over PCIe
+/// ```
+///
+/// The guard holds the SHARED BORROW of the slice, so the compiler rejects any `&mut` access to the bases while a device
+/// copy of them exists -- the resident copy cannot go stale, which is exactly the guarantee the reference's
+/// `bases: &[Affine]` gives for the duration of one call (variable_base/mod.rs:59-85), stretched over the guard's life.
+/// Sub-slices (`&srs[..n]`, the steps of `msm_chunks`) hit the resident copy too.
+pub struct ResidentBases<'a, P: SWCurveConfig> {
+    curve: c_int,
+    bases: &'a [Affine<P>],
+}
+impl<'a, P: SWCurveConfig> ResidentBases<'a, P> {
+    /// `None` if the layout check fails, no device is present or the copy does not fit (callers then simply run unpinned).
+    pub fn pin(curve: c_int, bases: &'a [Affine<P>]) -> Option<Self> {
+        if bases.is_empty() || !layout_ok::<P, P::ScalarField>(curve) {
+            return None;
+        }
+        let rc = unsafe { sys::ark_hip_msm_bases_pin(curve, bases.as_ptr() as *const u64, bases.len()) };
+        (rc == 0).then_some(Self { curve, bases })
+    }
+    pub fn bases(&self) -> &'a [Affine<P>] {
+        self.bases
+    }
+}
+impl<'a, P: SWCurveConfig> Drop for ResidentBases<'a, P> {
+    fn drop(&mut self) {
+        unsafe { sys::ark_hip_msm_bases_unpin(self.curve, self.bases.as_ptr() as *const u64, self.bases.len()) };
+    }
+}
+
+/// The OPT-IN transparent cache behind `sw_msm` / `sw_msm_bigint` (include/ark_hip.h, `ark_hip_msm_cache_*`; off unless
+/// given a budget here or through `ARK_HIP_BASE_CACHE_MB`): device copies keyed by (curve, address, length), validated on
+/// every call by a hash of the slice's FULL content computed on host threads while the device works from the copy; a
+/// changed slice is refreshed and the MSM rerun, so a result never reflects stale bases.  For code that cannot hold a
+/// [`ResidentBases`] guard.  `budget_bytes = Some(0)` turns it off again.
 pub fn base_cache_config(budget_bytes: Option<u64>, auto_prepare_after: Option<u32>) -> bool {
     let b = budget_bytes.map(|v| v as core::ffi::c_longlong).unwrap_or(-1);
     let a = auto_prepare_after.map(|v| v as c_int).unwrap_or(-1);
@@ -154,9 +191,9 @@ pub fn base_cache_config(budget_bytes: Option<u64>, auto_prepare_after: Option<u
 pub fn base_cache_clear() -> bool {
     unsafe { sys::ark_hip_msm_cache_clear() == 0 }
 }
-/// `[entries, device bytes, hits, misses, refreshed, evicted]`
-pub fn base_cache_stats() -> Option<[u64; 6]> {
-    let mut out = [0u64; 6];
+/// `[cached sets, device bytes, hits, misses, refreshed, evicted, pinned sets, pinned hits]`
+pub fn base_cache_stats() -> Option<[u64; 8]> {
+    let mut out = [0u64; 8];
     (unsafe { sys::ark_hip_msm_cache_stats(out.as_mut_ptr()) } == 0).then_some(out)
 }
 

@@ -1,7 +1,9 @@
 """The entry the trait surface lands in: ark_hip_msm_sw from HOST pointers -- what SWCurveConfig::msm and the msm_bigint
-hook (patches/0001, rust/ark-hip/src/msm.rs) call with Rust slices -- with its resident-base cache (hit / miss / content
-replaced in place / eviction / disabled / auto-prepare), the streamed scalar pieces, and the ordering of the second MSM
-lane behind producers on the context stream.  Parity against the oracle through the C ABI."""
+hook (patches/0001, rust/ark-hip/src/msm.rs) call with Rust slices.  By default it is a function of its two slices
+(nothing retained: an in-place edit of ONE base between two calls is honoured); pinned base sets (ark_hip_msm_bases_pin:
+whole set and sub-slices, nesting, unpin) and the OPT-IN transparent cache validated by a full-content hash (hit / miss /
+one limb edited in place / eviction / disabled / auto-prepare); the streamed pieces; the ordering of the second MSM lane
+behind producers on the context stream.  Parity against the oracle through the C ABI."""
 import ctypes as C
 
 import numpy as np
@@ -31,20 +33,94 @@ def oracle_aff(cid, bases, scalars, **kw):
 
 
 @pytest.fixture(autouse=True)
-def fresh_cache():
+def default_state():
+    """Every test starts from the library's default: transparent cache off, nothing pinned."""
+    A.base_cache_config(0, 0)
+    yield
+    A.base_cache_config(0, 0)
+    assert A.base_cache_stats()["pinned"] == 0, "a test leaked a pin"
+
+
+@pytest.fixture
+def transparent_cache():
     A.base_cache_config(8 << 30, 0)
     A.base_cache_clear()
     yield
-    A.base_cache_clear()
-    A.base_cache_config(8 << 30, 0)
+    A.base_cache_config(0, 0)
 
 
 def delta(before, after):
     return {k: after[k] - before[k] for k in ("hits", "misses", "refreshed", "evicted")}
 
 
+# ---- default: a function of the two slices -------------------------------------------------------------------------
+def test_default_retains_nothing_and_honours_a_single_edited_base():
+    """n >= 2^16, ONE base edited in place between two calls (index 12345: not one of the 4097 points the
+    round-3 fingerprint sampled), default settings -> the oracle's result for the edited slice."""
+    cid = O.CID["BLS12_381_G1"]
+    n = 1 << 16
+    bases = O.gen_bases(cid, A4, B4, n).copy()
+    scalars = O.gen_scalars(sf(cid), 1, n)
+    s0 = A.base_cache_stats()
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+    bases[12345] = O.gen_bases(cid, C4, A4, 1)[0]               # same array, one point replaced
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+    bases[n - 1] = O.gen_bases(cid, B4, A4, 1)[0]               # and the last one
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+    s1 = A.base_cache_stats()
+    assert s1 == s0 and s1["entries"] == 0 and s1["pinned"] == 0
+
+
+# ---- pinned base sets ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cname", O.CURVES)
-def test_cache_miss_then_hits(cname):
+def test_pinned_bases_whole_set_and_sub_slices(cname):
+    cid = O.CID[cname]
+    n = 1 << 11 if cname.endswith("G2") else 1 << 13
+    bases = O.gen_bases(cid, A4, B4, n)
+    s0 = A.base_cache_stats()
+    with A.pin_bases(cid, bases) as rb:
+        assert not bases.flags.writeable                        # the Python stand-in for the Rust guard's borrow
+        assert A.base_cache_stats()["pinned"] == 1
+        for k in range(2):
+            scalars = O.gen_scalars(sf(cid), 100 + k, n)       # new scalars every call, the same base array
+            assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), k
+        mont = O.gen_scalars(sf(cid), 9, n, montgomery=True)   # SWCurveConfig::msm: Fr elements
+        assert np.array_equal(aff(cid, A.msm(cid, bases, mont)), oracle_aff(cid, bases, mont, montgomery_scalars=True))
+        # msm_unchecked's truncation and an interior range (a ChunkedPippenger step): sub-slices of the pinned set
+        k = n // 3
+        sc = O.gen_scalars(sf(cid), 5, k)
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[:k], sc)), oracle_aff(cid, bases[:k], sc))
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[7:7 + k], sc)), oracle_aff(cid, bases[7:7 + k], sc))
+        small = np.arange(1, k + 1, dtype=np.uint64).astype(np.uint16)
+        wide = np.zeros((k, 4), dtype=np.uint64)
+        wide[:, 0] = small
+        assert np.array_equal(aff(cid, A.msm_u16(cid, bases[7:7 + k], small)), oracle_aff(cid, bases[7:7 + k], wide))
+        assert A.base_cache_stats()["pinned_hits"] - s0["pinned_hits"] == 6
+        with A.pin_bases(cid, bases):                           # pins nest
+            assert A.base_cache_stats()["pinned"] == 1
+        assert A.base_cache_stats()["pinned"] == 1
+        assert rb.n == n
+    assert bases.flags.writeable
+    s1 = A.base_cache_stats()
+    assert s1["pinned"] == 0 and s1["entries"] == 0
+    # after the unpin the array is the caller's again: an edit is honoured
+    other = O.gen_bases(cid, C4, B4, n)
+    bases = bases.copy()
+    scalars = O.gen_scalars(sf(cid), 3, n)
+    bases[n // 2] = other[n // 2]
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+
+
+def test_unpin_without_pin_is_an_error():
+    cid = O.CID["BN254_G1"]
+    bases = O.gen_bases(cid, A4, B4, 64)
+    assert lib().ark_hip_msm_bases_unpin(cid, bases.ctypes.data_as(C.c_void_p), 64) != 0
+    assert lib().ark_hip_msm_bases_pin(cid, None, 64) != 0
+
+
+# ---- the opt-in transparent cache: validated by a hash of the FULL content ---------------------------------------------
+@pytest.mark.parametrize("cname", O.CURVES)
+def test_cache_miss_then_hits(cname, transparent_cache):
     cid = O.CID[cname]
     n = 1 << 11 if cname.endswith("G2") else 1 << 13
     bases = O.gen_bases(cid, A4, B4, n)
@@ -52,7 +128,7 @@ def test_cache_miss_then_hits(cname):
     for k in range(3):
         scalars = O.gen_scalars(sf(cid), 100 + k, n)           # new scalars every call, the same base array
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), k
-    mont = O.gen_scalars(sf(cid), 9, n, montgomery=True)       # SWCurveConfig::msm: Fr elements
+    mont = O.gen_scalars(sf(cid), 9, n, montgomery=True)
     assert np.array_equal(aff(cid, A.msm(cid, bases, mont)), oracle_aff(cid, bases, mont, montgomery_scalars=True))
     s1 = A.base_cache_stats()
     assert delta(s0, s1) == {"hits": 3, "misses": 1, "refreshed": 0, "evicted": 0}
@@ -64,29 +140,39 @@ def test_cache_miss_then_hits(cname):
     assert A.base_cache_stats()["entries"] == 2
 
 
-def test_cache_notices_replaced_content():
+def test_cache_notices_any_edit(transparent_cache):
     cid = O.CID["BLS12_381_G1"]
-    n = 1 << 12
+    n = 1 << 16                                                 # 8 host threads hash 6 MiB in 64 KiB blocks
     bases = O.gen_bases(cid, A4, B4, n).copy()
     other = O.gen_bases(cid, C4, B4, n)
     scalars = O.gen_scalars(sf(cid), 1, n)
-    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+    want = oracle_aff(cid, bases, scalars)
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), want)
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), want)
     s0 = A.base_cache_stats()
-    bases[:] = other                                           # same address, same length, new SRS
-    got = aff(cid, A.msm_bigint(cid, bases, scalars))
-    assert np.array_equal(got, oracle_aff(cid, other, scalars))
+    bases[12345] = other[12345]                                 # ONE point the round-3 fingerprint never sampled
+    want1 = oracle_aff(cid, bases, scalars)
+    assert not np.array_equal(want1, want)
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), want1)
     assert delta(s0, A.base_cache_stats()) == {"hits": 0, "misses": 0, "refreshed": 1, "evicted": 0}
-    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), got)   # and it is a plain hit afterwards
-    # an edit of ONE sampled point (n <= 4096: every point is sampled) is noticed as well
-    bases[7] = O.gen_bases(cid, B4, A4, 1)[0]
-    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
-    # the documented escape hatch for edits the sample could miss
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), want1)   # and it is a plain hit afterwards
+    assert delta(s0, A.base_cache_stats()) == {"hits": 1, "misses": 0, "refreshed": 1, "evicted": 0}
+    bases[:] = other                                            # same address, same length, new SRS
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, other, scalars))
+    assert delta(s0, A.base_cache_stats())["refreshed"] == 2
+    # the last point, the first limb, the narrow-scalar entry
+    bases[n - 1] = O.gen_bases(cid, B4, A4, 1)[0]
+    small = (np.arange(n, dtype=np.uint64) % 251).astype(np.uint8)
+    wide = np.zeros((n, 4), dtype=np.uint64)
+    wide[:, 0] = small
+    assert np.array_equal(aff(cid, A.msm_u8(cid, bases, small)), oracle_aff(cid, bases, wide))
+    assert delta(s0, A.base_cache_stats())["refreshed"] == 3
     A.base_cache_clear()
     assert A.base_cache_stats()["entries"] == 0
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
 
 
-def test_cache_eviction_lru_and_disabled():
+def test_cache_eviction_lru_and_disabled(transparent_cache):
     cid = O.CID["BN254_G1"]
     n = 1 << 12
     sets = [O.gen_bases(cid, np.array([11 + i, i, 0, 0], dtype=np.uint64), B4, n) for i in range(3)]
@@ -99,6 +185,11 @@ def test_cache_eviction_lru_and_disabled():
     d = delta(s0, A.base_cache_stats())
     assert d["misses"] == 4 and d["hits"] == 1 and d["evicted"] == 2, d
     assert A.base_cache_stats()["entries"] == 2
+    with A.pin_bases(cid, sets[2]):                             # pinned sets live outside the budget and survive a clear
+        A.base_cache_clear()
+        st = A.base_cache_stats()
+        assert st["entries"] == 0 and st["pinned"] == 1
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, sets[2], scalars)), want[2])
     A.base_cache_config(0, -1)                                  # off: bases stream with the scalars on every call
     assert A.base_cache_stats()["entries"] == 0
     s0 = A.base_cache_stats()
@@ -108,15 +199,17 @@ def test_cache_eviction_lru_and_disabled():
 
 
 @pytest.mark.parametrize("pieces", [1, 2, 3, 5])
-def test_streamed_pieces_match_oracle(pieces, monkeypatch):
+def test_streamed_pieces_match_oracle(pieces, monkeypatch, transparent_cache):
     monkeypatch.setenv("ARK_HIP_STREAM_PIECES", str(pieces))
     for cname, n in (("BLS12_381_G1", 12345), ("BLS12_377_G2", 1500), ("BN254_G1", 1)):
         cid = O.CID[cname]
         bases = O.gen_bases(cid, A4, B4, n)
         scalars = O.gen_scalars(sf(cid), 77 + pieces, n)
-        for _ in range(2):                                      # miss (bases uploaded) and hit (scalars only)
+        for _ in range(2):                                      # miss (bases fill the copy piecewise) and hit (scalars only)
             assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), (cname, pieces)
-    # cache off: bases AND scalars stream piecewise (the msm_chunks machinery)
+        with A.pin_bases(cid, bases):                           # pinned: scalars only, from the first call on
+            assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), (cname, pieces)
+    # the default: bases AND scalars stream piecewise (the msm_chunks machinery)
     A.base_cache_config(0, -1)
     cid = O.CID["BLS12_381_G1"]
     bases = O.gen_bases(cid, A4, B4, 5000)
@@ -125,7 +218,8 @@ def test_streamed_pieces_match_oracle(pieces, monkeypatch):
 
 
 def test_streamed_pieces_at_size(monkeypatch):
-    # 2^21 pairs through the default piece rule (two pieces on the two lanes), miss then hit, against k*G
+    # 2^21 pairs through the default piece rules against k*G: bases + scalars streamed in the tapered pieces
+    # (1, 2, 3, 1, 1 eighths), then pinned -- scalars only, in GROWING pieces (each twice the one before: 3 pieces here)
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -136,47 +230,100 @@ def test_streamed_pieces_at_size(monkeypatch):
     bases = S.grow_bases(cid, n, S.A0, S.B0, r).cpu().numpy().view(np.uint64).reshape(n, -1)
     sc = S.gen_scalars(n, 0x51, r)
     want = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
-    for _ in range(2):
-        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
-    st = A.base_cache_stats()          # (mul_gen's one-point MSMs own the other entries)
-    assert st["bytes"] >= bases.nbytes and st["hits"] >= 1
-    # a hit streams its scalars in GROWING pieces (each twice the one before: 3 pieces here); the equal-piece rule and a
-    # ragged length (two growing pieces + remainder) give the same point
-    monkeypatch.setenv("ARK_HIP_STREAM_GROWING", "0")
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
-    monkeypatch.delenv("ARK_HIP_STREAM_GROWING")
+    monkeypatch.setenv("ARK_HIP_STREAM_TAPER", "0")            # equal pieces: the same point
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
+    monkeypatch.delenv("ARK_HIP_STREAM_TAPER")
     m = (3 << 18) + 1001
     want_m = S.mul_gen(cid, S.dlog_of_msm(sc[:m], S.A0, S.B0, r), r)
-    for _ in range(2):
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[:m], sc[:m])), want_m)   # ragged, unpinned
+    with A.pin_bases(cid, bases):
+        s0 = A.base_cache_stats()
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
+        # the equal-piece rule and a ragged sub-slice (two growing pieces + remainder) give the same points
+        monkeypatch.setenv("ARK_HIP_STREAM_GROWING", "0")
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
+        monkeypatch.delenv("ARK_HIP_STREAM_GROWING")
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[:m], sc[:m])), want_m)
+        assert A.base_cache_stats()["pinned_hits"] - s0["pinned_hits"] == 3
+    # the transparent cache at this size: miss, hit, one base edited (hash of 192 MiB on the host threads), hit
+    A.base_cache_config(4 << 30, 0)
+    bases = bases.copy()
+    s0 = A.base_cache_stats()
+    for _ in range(2):
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
+    j = 1234567
+    bases[j], keep = bases[j - 1], bases[j].copy()              # P_j := P_(j-1): the sum moves by s_j (P_(j-1) - P_j) = -s_j b G
+    want_e = S.mul_gen(cid, (S.dlog_of_msm(sc, S.A0, S.B0, r) - S.scalar_int(sc[j]) * S.B0) % r, r)
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want_e)
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want_e)
+    bases[j] = keep
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
+    assert delta(s0, A.base_cache_stats()) == {"hits": 2, "misses": 1, "refreshed": 2, "evicted": 0}
 
 
-def test_auto_prepare_after_hits():
+@pytest.mark.parametrize("mode", ["pinned", "transparent"])
+def test_auto_prepare_after_hits(mode):
     cid = O.CID["BLS12_381_G1"]
     n = 3000
     bases = O.gen_bases(cid, A4, B4, n)
-    A.base_cache_config(-1, 2)                                  # the third call builds the per-window table
+    if mode == "pinned":
+        A.base_cache_config(0, 2)                               # the third call on the whole set builds the table
+        with A.pin_bases(cid, bases):
+            for k in range(5):
+                scalars = O.gen_scalars(sf(cid), 40 + k, n)
+                assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), k
+            sc = O.gen_scalars(sf(cid), 2, n // 2)              # a sub-slice keeps the plain path
+            assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[:n // 2], sc)), oracle_aff(cid, bases[:n // 2], sc))
+        return
+    A.base_cache_config(8 << 30, 2)
     for k in range(5):
         scalars = O.gen_scalars(sf(cid), 40 + k, n)
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), k
+    st = A.base_cache_stats()
+    assert st["bytes"] > 4 * bases.nbytes                       # the table counts against the budget
     # content replaced under a prepared entry: table dropped, plain path again, still exact
     bases2 = bases.copy()
     scalars = O.gen_scalars(sf(cid), 1, n)
     for k in range(4):
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases2, scalars)), oracle_aff(cid, bases2, scalars))
-    bases2[:] = O.gen_bases(cid, C4, A4, n)
+    bases2[n // 2] = O.gen_bases(cid, C4, A4, 1)[0]             # ONE base under a prepared entry
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases2, scalars)), oracle_aff(cid, bases2, scalars))
+    # a budget too small for the table: the set stays cached without one
+    A.base_cache_config(0, -1)
+    A.base_cache_config(int(1.5 * bases.nbytes), 1)
+    for k in range(3):
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+    st = A.base_cache_stats()
+    assert st["entries"] == 1 and st["bytes"] < 2 * bases.nbytes
 
 
-def test_multi_device_entry_caches_per_shard(monkeypatch):
+def test_multi_device_entry_pins_per_shard(monkeypatch):
     monkeypatch.setenv("ARK_HIP_OVERSUBSCRIBE", "1")
     cid = O.CID["BLS12_381_G1"]
     n = 5001
     bases = O.gen_bases(cid, A4, B4, n)
     scalars = O.gen_scalars(sf(cid), 8, n)
     want = oracle_aff(cid, bases, scalars)
+    assert np.array_equal(aff(cid, A.msm_bigint_multi(cid, 3, bases, scalars)), want)   # unpinned: every shard streams
+    # a pin lives on ONE device: pin each device's shard there (the split ark_hip_msm_sw_multi uses)
+    L = lib()
+    cur = L.ark_hip_get_device()
+    q, rem = divmod(n, 3)
+    pins = []
+    for g in range(3):
+        lo = g * q + min(g, rem)
+        cnt = q + (1 if g < rem else 0)
+        check(L.ark_hip_set_device(g), "set_device")
+        pins.append(A.pin_bases(cid, bases[lo:lo + cnt]))
+    check(L.ark_hip_set_device(cur), "set_device")
     for _ in range(2):
         assert np.array_equal(aff(cid, A.msm_bigint_multi(cid, 3, bases, scalars)), want)
+    for g in range(3):
+        check(L.ark_hip_set_device(g), "set_device")
+        assert A.base_cache_stats()["pinned_hits"] >= 2
+        pins[g].unpin()
+    check(L.ark_hip_set_device(cur), "set_device")
 
 
 def test_second_lane_waits_for_context_stream_producers():

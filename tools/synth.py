@@ -19,6 +19,11 @@ def limbs4(v):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
+def scalar_int(row):
+    """one BigInt<4> row as a Python integer."""
+    return sum(int(row[i]) << (64 * i) for i in range(4))
+
+
 def gen_scalars(n, seed, r):
     """uniform in [0, r) as canonical BigInt<4> limbs [n, 4]."""
     bits = r.bit_length()
