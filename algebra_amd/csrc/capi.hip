@@ -162,13 +162,13 @@ struct HostStager {
 
 // ---- resident copies of base sets handed over by host pointer -------------------------------------------
 // SWCurveConfig::msm / VariableBaseMSM::msm_bigint take `&[Affine]` on every call; provers (and the reference's own
-// bench, bench-templates/src/macros/ec.rs:223-240) pass the SAME slice -- an SRS -- again and again.  By DEFAULT the
-// host-pointer entry is a pure function of its two slices (bases and scalars stream over PCIe together, nothing is
-// retained: the reference's borrow semantics, variable_base/mod.rs:59-85).  Two ways to keep a device copy:
+// bench, bench-templates/src/macros/ec.rs:223-240) pass the SAME slice -- an SRS -- again and again.  The host-pointer
+// entry is a function of its two slices (the reference's borrow semantics, variable_base/mod.rs:59-85): whatever is
+// kept between calls never changes a result.  Two ways a device copy is kept:
 //   pinned  (ark_hip_msm_bases_pin .. _unpin): the caller DECLARES the slice immutable for that span (on the Rust side a
 //           guard that holds the shared borrow, so the compiler enforces it); any call whose base slice lies inside a
 //           pinned range uses the resident copy with no check at all;
-//   transparent (opt-in: ark_hip_msm_cache_config / ARK_HIP_BASE_CACHE_MB): copies keyed by (curve, address, length) and
+//   cached (default; ark_hip_msm_cache_config / ARK_HIP_BASE_CACHE_MB): copies keyed by (curve, address, length) and
 //           validated on EVERY call by a hash of the slice's FULL content, computed on host threads while the device
 //           already works from the cached copy; the result is withheld until the hash agrees, otherwise the copy is
 //           refreshed and the MSM rerun.  Never stale, at the price of one pass over the host slice per call.
@@ -770,11 +770,17 @@ uint64_t base_hash(const uint64_t* p, size_t words) {
 
 void cache_configure(Context* c) {
   if (c->cache_budget < 0) {
-    // default 0: the transparent cache is OPT-IN (ark_hip_msm_cache_config or ARK_HIP_BASE_CACHE_MB) -- by default the
-    // host-pointer entries retain nothing of their inputs
-    long long budget = 0;
+    // default: a quarter of the device memory (ARK_HIP_BASE_CACHE_MB=0 or ark_hip_msm_cache_config(0, ..) turn it off).
+    // The cache never changes a result: every hit is validated against a hash of the slice's full content, which host
+    // threads compute while the device works (2^24 BLS12-381 G1: 40.2 ms per call cached, 40.2 pinned, 47.8 streamed,
+    // 36.4 resident -- profiles/r4_trait_modes_sessionA.txt)
+    long long budget = -1;
     if (const char* e = getenv("ARK_HIP_BASE_CACHE_MB")) budget = atoll(e) * (1ll << 20);
-    c->cache_budget = budget < 0 ? 0 : budget;
+    if (budget < 0) {
+      size_t fr = 0, tot = 0;
+      budget = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 4) : (8ll << 30);
+    }
+    c->cache_budget = budget;
   }
   if (c->auto_prepare < 0) {
     const char* e = getenv("ARK_HIP_AUTO_PREPARE");
@@ -904,7 +910,8 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
     return run((const void*)((const char*)e.dev.p + off * wpp * 8), false, whole ? &e : nullptr);
   }
   cache_configure(c);
-  if (c->cache_budget <= 0 || (long long)bytes > c->cache_budget || n == 0) return run(nullptr, false, nullptr);
+  // sets below 64 KiB are not worth a device copy and a hashing pass: they stream with their scalars
+  if (c->cache_budget <= 0 || (long long)bytes > c->cache_budget || bytes < ((size_t)64 << 10)) return run(nullptr, false, nullptr);
   c->cache_clock++;
   long idx = cache_find_exact(c, curve, bases, n, false);
   uint64_t h = 0;
@@ -989,27 +996,47 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
     step = sizes.back();   // the largest piece sizes the ring buffers
   } else if (taper && host_bases && n >= ((size_t)1 << 21) && !getenv("ARK_HIP_STREAM_PIECES") &&
              !(getenv("ARK_HIP_STREAM_TAPER") && getenv("ARK_HIP_STREAM_TAPER")[0] == '0')) {
-    // bases AND scalars cross PCIe (2^24 BLS12-381 G1: 2 GiB, ~37-47 ms of copy against 36 ms of kernels).  Whichever
-    // of the two sets the pace, the call pays for one un-hidden end: the FIRST piece's copy when the kernels are the
-    // slower side, the LAST piece's kernels + the reduction when the copy is.  So both ends are small (>= 2^18 pairs:
-    // a piece's ~20 launches and its pass over the touched buckets are per piece) and the middle pieces large.
-    static const int F32[] = {2, 4, 10, 8, 4, 2, 1, 1}, F16[] = {1, 2, 6, 4, 2, 1}, F8[] = {1, 2, 3, 1, 1};
-    const int* fr = n >= ((size_t)1 << 23) ? F32 : (n >= ((size_t)1 << 22) ? F16 : F8);
-    const int cnt = n >= ((size_t)1 << 23) ? 8 : (n >= ((size_t)1 << 22) ? 6 : 5);
-    const size_t unit = (n / (n >= ((size_t)1 << 23) ? 32 : (n >= ((size_t)1 << 22) ? 16 : 8))) & ~(size_t)255;
+    // bases AND scalars cross PCIe (2^24 BLS12-381 G1: 2 GiB, ~40 ms of copy against 36 ms of kernels): the copy sets the
+    // pace and what the call adds to it is the LAST piece's kernels + the reduction.  Equal eighths -- every upload waits
+    // for the kernels two pieces back (two ring slots), so large middle pieces stall the copy: measured 54.4 ms with a
+    // 2,4,10,8,4,2,1,1 / 32 schedule against 47.8 ms for eighths -- with the last eighth halved down to >= 2^18 pairs.
+    // ARK_HIP_STREAM_SCHEDULE="a,b,c,.." (weights) overrides for experiments.
+    std::vector<size_t> wts;
+    if (const char* e = getenv("ARK_HIP_STREAM_SCHEDULE")) {
+      for (const char* q = e; *q;) {
+        wts.push_back((size_t)strtoul(q, (char**)&q, 10));
+        if (*q == ',') q++;
+      }
+    }
+    if (wts.empty()) {
+      wts.assign(7, 8);
+      size_t tail = 8;
+      while (tail > 1 && (n / 64) * (tail / 2) >= ((size_t)1 << 18) && wts.size() < 10) {
+        tail /= 2;
+        wts.push_back(tail);
+      }
+      wts.push_back(tail);
+    }
+    size_t wsum = 0;
+    for (size_t w : wts) wsum += w;
     size_t left = n;
     step = 0;
-    for (int k = 0; k < cnt; k++) {
-      const size_t take = k + 1 == cnt ? left : unit * (size_t)fr[k];
+    for (size_t k = 0; k < wts.size() && left; k++) {
+      size_t take = k + 1 == wts.size() ? left : ((n / wsum) * wts[k]) & ~(size_t)255;
+      if (take == 0 || take > left) take = left;
       sizes.push_back(take);
       left -= take;
       step = take > step ? take : step;
+    }
+    if (left) {
+      sizes.back() += left;
+      step = sizes.back() > step ? sizes.back() : step;
     }
   } else {
     for (size_t off = 0; off < n; off += step) sizes.push_back(n - off < step ? n - off : step);
   }
   const size_t npieces = sizes.size();
-  const bool shared = allow_shared && npieces >= 2 && npieces <= 8;
+  const bool shared = allow_shared && npieces >= 2 && npieces <= 16;
   MsmPlan plan{};
   if (shared) {
     plan = msm_make_plan(n, msm_scalar_bits(curve), msm_mul_cost(curve), false, msm_lazy28(curve));
@@ -1610,6 +1637,7 @@ int ark_hip_msm_prepared_small_device(const ark_hip_msm_bases* bases, const void
 // ---- resident-base cache control ----
 int ark_hip_msm_cache_config(long long budget_bytes, int auto_prepare_after) {
   ARK_SCOPE(sc);
+  if (budget_bytes == -2) sc.c->cache_budget = -1;   // back to the default (environment / a quarter of the device memory)
   cache_configure(sc.c);
   if (budget_bytes >= 0) {
     sc.c->cache_budget = budget_bytes;

@@ -14,7 +14,7 @@ struct BN254_G1 {
   static constexpr int ACC_MIN_WAVES = ARK_ACC_MIN_WAVES_G1;   // min waves per SIMD requested for the accumulate kernel
   static constexpr bool RELAXED = true;   // bucket accumulation on residues in [0, 2p) (fp.cuh, ec.cuh)
   static constexpr int ID = 0;
-  static constexpr bool LAZY_A = false;   // Fp256: the saturated product is as fast (100 multiply-adds for 64 + 64)
+  static constexpr bool LAZY_A = true;    // accumulate kernels on carry-free limbs: 9 x 29 bits (fp28.cuh / ec28.cuh)
   typedef Fp<BN254_FQ> F;
   typedef F FA;                           // field type of the bucket-accumulation kernels
   static constexpr bool RELAXED_A = RELAXED;

@@ -15,6 +15,18 @@
 // Formulas and branches: ec/src/models/short_weierstrass/bucket.rs:168-238 (madd-2008-s), affine.rs:169-201
 // (mdbl-2008-s-1, a = 0).  Bounds in the comments are in units of p; "n" = normalised limbs (< 2^28), "s" =
 // semi-normalised (< 3 2^28).
+//
+// Two limb geometries share these formulas (FpL::W / L from params.hpp).  The bounds in the comments are for 14 x 28
+// bits (Fp384: R' / p > 2048, bases enter below 2^8 p).  For 9 x 29 bits (BN254 Fq: R' / p >= 169, bases enter below
+// 2^5 p) the same chain gives
+//   x2, y2 < 32;  first point / U2 / S2 < 32 * 1.06 / 169 + 1 < 1.21;  P in (0.9, 7.21), R in (0.8, 3.21) -- both SWEPT to
+//   normalised limbs (FpL::sub_op: a 29-bit column has no room for two semi-normalised operands, 90 2^58 > 2^64);
+//   PP < 7.21^2 / 169 + 1 < 1.31 (the zero test needs < 2);  PPP < 7.21 * 1.31 / 169 + 1 < 1.06;  Q < 5.07 * 1.31 / 169 + 1
+//   < 1.04;  R^2 < 1.07;  X3 = R^2 - PPP - 2 Q + 4p in (0.8, 5.07);  t = Q - X3 + 6p < 7.04 (s);
+//   Y3 < (3.21 * 7.04 + 2 * 1.06) / 169 + 1 < 1.15;  ZZ3 < 1.06 * 1.31 / 169 + 1 < 1.01;  ZZZ3 < 1.01
+//   columns: (n x s) 9 x 3 2^58 + (limbs < 2^30) x n 9 x 2 2^58 + reduction 9 x 2^58 = 54 2^58 < 2^64
+//   full addition: U1 = X1 ZZ2 < 5.07 * 32 / 169 + 1 < 1.97 (hence P = U2 - U1 + 3p), S1 < 1.21 * 32 / 169 + 1 < 1.23,
+//   P in (1.03, 4.21), PP < 1.11; leaving: shr_mod<5> output < 5.07 / 32 + 1 < 2.
 #pragma once
 #include "ec.cuh"
 #include "fp28.cuh"
@@ -112,8 +124,8 @@ ARK_HD bool xyzz_madd_lazy(XYZZL<P>& acc, const FpL<P>& x2, const FpL<P>& y2) {
   }
   const F u2 = F::mul(x2, acc.zz);                                // < 256 * 1.01 / 2048 + 1 < 1.13 (n)
   const F s2 = F::mul(y2, acc.zzz);                               // < 1.13 (n)
-  const F pd = F::template sub_semi<6>(u2, acc.x);                // U2 - X1 + 6p: (0.99, 7.13), s
-  const F rd = F::template sub_semi<2>(s2, acc.y);                // S2 - Y1 + 2p: (0.87, 3.13), s
+  const F pd = F::template sub_op<6>(u2, acc.x);                  // U2 - X1 + 6p: (0.99, 7.13), s (n on 29-bit limbs)
+  const F rd = F::template sub_op<2>(s2, acc.y);                  // S2 - Y1 + 2p: (0.87, 3.13), s (n on 29-bit limbs)
   const F pp = F::sqr(pd);                                        // < 7.13^2 / 2048 + 1 < 1.03 (n)
   if (pp.is_zero_or_p()) {                                        // P = 0 mod p: same x -- doubling or infinity (bucket.rs:176-200)
     if (F::sqr(rd).is_zero_or_p()) return true;                   // R = 0 mod p as well: the same point
@@ -175,8 +187,8 @@ ARK_HD void xyzz_add_lazy(XYZZL<P>& acc, const FpL<P>& bx, const FpL<P>& by, con
   const F u2 = F::mul(bx, acc.zz);
   const F s1 = F::mul(acc.y, bzzz);
   const F s2 = F::mul(by, acc.zzz);
-  const F pd = F::template sub_semi<2>(u2, u1);
-  const F rd = F::template sub_semi<2>(s2, s1);
+  const F pd = F::template sub_op<3>(u2, u1);                     // U1 < 1.97 on 29-bit limbs (stored bucket: 32 p)
+  const F rd = F::template sub_op<2>(s2, s1);
   const F pp = F::sqr(pd);
   if (pp.is_zero_or_p()) {
     if (F::sqr(rd).is_zero_or_p()) {

@@ -92,10 +92,14 @@ ARK_DEV void lcol_vp(u64& c, const u32* x) {
 template <class P_>
 struct FpL {
   typedef P_ P;
-  static constexpr int L = P::LZ_L;   // 28-bit limbs
+  static constexpr int L = P::LZ_L;   // limbs of W bits
+  static constexpr int W = P::LZ_W;   // 28 (Fp384: 14 limbs) or 29 (Fp256: 9 limbs)
   static constexpr int N = P::N;      // 32-bit limbs of the canonical form
-  static constexpr u32 MASK = (1u << 28) - 1u;
-  static_assert(28 * L >= 32 * N, "the 28-bit form must hold every N x 32-bit value");
+  static constexpr u32 MASK = (1u << W) - 1u;
+  static_assert(W * L >= 32 * N, "the W-bit form must hold every N x 32-bit value");
+  // may BOTH operands of a product be semi-normalised (limbs < 3 2^W)?  L x 9 2^(2W) + L x 2^(2W) < 2^64
+  static constexpr bool SEMI2 = 10 * L < (1 << (64 - 2 * W));
+  static_assert(4 * L < (1 << (64 - 2 * W)), "a normalised x semi-normalised column must fit 64 bits");
   u32 l[L];  // value = sum l[i] 2^(28 i); "normalised": every l[i] < 2^28
 
   ARK_HD static FpL zero() {
@@ -131,7 +135,7 @@ struct FpL {
       u64 t = A + B;
       m[k] = ((u32)t * P::LZ_INV) & MASK;
       t += (u64)m[k] * P::LZ_KP[1][0];
-      carry = t >> 28;
+      carry = t >> W;
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -142,7 +146,7 @@ struct FpL {
       for (int i = k - L + 1; i < L; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
       const u64 t = A + B;
       r.l[k - L] = (u32)t & MASK;
-      carry = t >> 28;
+      carry = t >> W;
     }
     r.l[L - 1] = (u32)carry;
     return r;
@@ -153,23 +157,31 @@ struct FpL {
   // 69.3 for the compiler's scheduling of mul_c (which splits each column in two chains and joins them with a 64-bit
   // addition) and 58.7 for the saturated product.
   template <int K, int NP>
-  ARK_DEV static void asm_cols_lo(u64& c, const u32* a, const u32* b, const u32* a2, const u32* b2, u32* m) {
+  ARK_DEV static void asm_cols_lo(u64& c, const u32* a, const u32* b, const u32* a2, const u32* b2, u32* m,
+                                  const u32* a3 = nullptr, const u32* b3 = nullptr, const u32* a4 = nullptr,
+                                  const u32* b4 = nullptr) {
     lcol_vv<0, K, K>(c, a, b);
-    if constexpr (NP == 2) lcol_vv<0, K, K>(c, a2, b2);
+    if constexpr (NP >= 2) lcol_vv<0, K, K>(c, a2, b2);
+    if constexpr (NP >= 3) lcol_vv<0, K, K>(c, a3, b3);
+    if constexpr (NP >= 4) lcol_vv<0, K, K>(c, a4, b4);
     lcol_vp<P, 0, K - 1, K>(c, m);
     m[K] = ((u32)c * P::LZ_INV) & MASK;
     lcol_vp<P, K, K, K>(c, m);
-    c >>= 28;
-    if constexpr (K + 1 < L) asm_cols_lo<K + 1, NP>(c, a, b, a2, b2, m);
+    c >>= W;
+    if constexpr (K + 1 < L) asm_cols_lo<K + 1, NP>(c, a, b, a2, b2, m, a3, b3, a4, b4);
   }
   template <int K, int NP>
-  ARK_DEV static void asm_cols_hi(u64& c, const u32* a, const u32* b, const u32* a2, const u32* b2, const u32* m, u32* r) {
+  ARK_DEV static void asm_cols_hi(u64& c, const u32* a, const u32* b, const u32* a2, const u32* b2, const u32* m, u32* r,
+                                  const u32* a3 = nullptr, const u32* b3 = nullptr, const u32* a4 = nullptr,
+                                  const u32* b4 = nullptr) {
     lcol_vv<K - L + 1, L - 1, K>(c, a, b);
-    if constexpr (NP == 2) lcol_vv<K - L + 1, L - 1, K>(c, a2, b2);
+    if constexpr (NP >= 2) lcol_vv<K - L + 1, L - 1, K>(c, a2, b2);
+    if constexpr (NP >= 3) lcol_vv<K - L + 1, L - 1, K>(c, a3, b3);
+    if constexpr (NP >= 4) lcol_vv<K - L + 1, L - 1, K>(c, a4, b4);
     lcol_vp<P, K - L + 1, L - 1, K>(c, m);
     r[K - L] = (u32)c & MASK;
-    c >>= 28;
-    if constexpr (K + 1 < 2 * L - 1) asm_cols_hi<K + 1, NP>(c, a, b, a2, b2, m, r);
+    c >>= W;
+    if constexpr (K + 1 < 2 * L - 1) asm_cols_hi<K + 1, NP>(c, a, b, a2, b2, m, r, a3, b3, a4, b4);
   }
   // squaring columns: cross products a_i * (2 a_(K-i)) for i < K - i, then the diagonal
   template <int K>
@@ -179,7 +191,7 @@ struct FpL {
     lcol_vp<P, 0, K - 1, K>(c, m);
     m[K] = ((u32)c * P::LZ_INV) & MASK;
     lcol_vp<P, K, K, K>(c, m);
-    c >>= 28;
+    c >>= W;
     if constexpr (K + 1 < L) asm_sq_lo<K + 1>(c, a, d, m);
   }
   template <int K>
@@ -188,7 +200,7 @@ struct FpL {
     if constexpr (K % 2 == 0) lcol_vv<K / 2, K / 2, K>(c, a, a);
     lcol_vp<P, K - L + 1, L - 1, K>(c, m);
     r[K - L] = (u32)c & MASK;
-    c >>= 28;
+    c >>= W;
     if constexpr (K + 1 < 2 * L - 1) asm_sq_hi<K + 1>(c, a, d, m, r);
   }
   ARK_DEV static FpL mul(const FpL& a, const FpL& b) {
@@ -209,6 +221,18 @@ struct FpL {
     r.l[L - 1] = (u32)c;
     return r;
   }
+  // a b + c d + e f + g h under ONE reduction (the Y3 of a bucket addition over Fp2: fp28x2.cuh).  The caller keeps the
+  // column sum -- 4 L limb products + L reduction terms -- below 2^64 (operand classes stated at the call site).
+  ARK_DEV static FpL sop4(const FpL& a, const FpL& b, const FpL& x, const FpL& y, const FpL& e, const FpL& f, const FpL& g,
+                          const FpL& h) {
+    u32 m[L];
+    FpL r;
+    u64 c = 0;
+    asm_cols_lo<0, 4>(c, a.l, b.l, x.l, y.l, m, e.l, f.l, g.l, h.l);
+    asm_cols_hi<L, 4>(c, a.l, b.l, x.l, y.l, m, r.l, e.l, f.l, g.l, h.l);
+    r.l[L - 1] = (u32)c;
+    return r;
+  }
   ARK_DEV static FpL sqr(const FpL& a) {
     u32 m[L], d[L];
     FpL r;
@@ -225,7 +249,34 @@ struct FpL {
   static FpL mul(const FpL& a, const FpL& b) { return mul_c(a, b); }
   static FpL sqr(const FpL& a) { return sqr_c(a); }
   static FpL sop2(const FpL& a, const FpL& b, const FpL& x, const FpL& y) { return sop2_c(a, b, x, y); }
+  static FpL sop4(const FpL& a, const FpL& b, const FpL& x, const FpL& y, const FpL& e, const FpL& f, const FpL& g,
+                  const FpL& h) { return sop4_c(a, b, x, y, e, f, g, h); }
 #endif
+  ARK_HD static FpL sop4_c(const FpL& a, const FpL& b, const FpL& x, const FpL& y, const FpL& e, const FpL& f, const FpL& g,
+                           const FpL& h) {
+    u32 m[L];
+    FpL r;
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; k++) {
+      u64 t = carry;
+      const int lo = k < L ? 0 : k - L + 1, hi = k < L ? k : L - 1;
+#pragma unroll
+      for (int i = lo; i <= hi; i++)
+        t += (u64)a.l[i] * b.l[k - i] + (u64)x.l[i] * y.l[k - i] + (u64)e.l[i] * f.l[k - i] + (u64)g.l[i] * h.l[k - i];
+#pragma unroll
+      for (int i = lo; i <= (k < L ? k - 1 : L - 1); i++) t += (u64)m[i] * P::LZ_KP[1][k - i];
+      if (k < L) {
+        m[k] = ((u32)t * P::LZ_INV) & MASK;
+        t += (u64)m[k] * P::LZ_KP[1][0];
+      } else {
+        r.l[k - L] = (u32)t & MASK;
+      }
+      carry = t >> W;
+    }
+    r.l[L - 1] = (u32)carry;
+    return r;
+  }
   // a^2 of a normalised or semi-normalised a (limbs < 3 2^28): every cross product once, against the doubled limb (< 6 2^28;
   // per column at most 7 x 18 2^56 + 9 2^56 + 14 x 2^56 + carry < 2^63.3).  105 + 196 multiply-adds instead of 392.
   // (The saturated form's dedicated square lost to mul(a, a) on its doubling carries -- DESIGN 4; here doubling is a shift.)
@@ -246,7 +297,7 @@ struct FpL {
       u64 t = A + B;
       m[k] = ((u32)t * P::LZ_INV) & MASK;
       t += (u64)m[k] * P::LZ_KP[1][0];
-      carry = t >> 28;
+      carry = t >> W;
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -258,7 +309,7 @@ struct FpL {
       for (int i = k - L + 1; i < L; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
       const u64 t = A + B;
       r.l[k - L] = (u32)t & MASK;
-      carry = t >> 28;
+      carry = t >> W;
     }
     r.l[L - 1] = (u32)carry;
     return r;
@@ -282,7 +333,7 @@ struct FpL {
       u64 t = A + C + B;
       m[k] = ((u32)t * P::LZ_INV) & MASK;
       t += (u64)m[k] * P::LZ_KP[1][0];
-      carry = t >> 28;
+      carry = t >> W;
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; k++) {
@@ -295,7 +346,7 @@ struct FpL {
       for (int i = k - L + 1; i < L; i++) B += (u64)m[i] * P::LZ_KP[1][k - i];
       const u64 t = A + C + B;
       r.l[k - L] = (u32)t & MASK;
-      carry = t >> 28;
+      carry = t >> W;
     }
     r.l[L - 1] = (u32)carry;
     return r;
@@ -316,7 +367,7 @@ struct FpL {
     for (int i = 0; i < L - 1; i++) {
       const int v = d[i] + carry;
       r.l[i] = (u32)v & MASK;
-      carry = v >> 28;  // arithmetic shift: floor division
+      carry = v >> W;  // arithmetic shift: floor division
     }
     r.l[L - 1] = (u32)(d[L - 1] + carry);
     return r;
@@ -361,7 +412,7 @@ struct FpL {
   // subtrahend's: floor(K p / 2^364) - H >= floor(b / 2^364), true whenever K exceeds the subtrahend's bound by >= 1/2.
   template <int K, int H>
   static constexpr u32 kp_spread(int i) {
-    return P::LZ_KP[K][i] + (i < L - 1 ? ((u32)H << 28) : 0u) - (i > 0 ? (u32)H : 0u);
+    return P::LZ_KP[K][i] + (i < L - 1 ? ((u32)H << W) : 0u) - (i > 0 ? (u32)H : 0u);
   }
   // a - b + K p, semi-normalised (a, b normalised)
   template <int K>
@@ -370,6 +421,42 @@ struct FpL {
 #pragma unroll
     for (int i = 0; i < L; i++) r.l[i] = a.l[i] - b.l[i] + kp_spread<K, 1>(i);
     return r;
+  }
+  // a - b + K p as an operand that may meet ANOTHER semi-normalised operand in a product (a square of it, R t in Y3):
+  // semi-normalised where the limb width leaves room for that (SEMI2: 14 x 28 bits), otherwise swept to normalised
+  // limbs (9 x 29 bits) -- an unsigned sweep, the spread limbs cannot go negative
+  template <int K>
+  ARK_HD static FpL sub_op(const FpL& a, const FpL& b) {
+    if constexpr (SEMI2) {
+      return sub_semi<K>(a, b);
+    } else {
+      FpL r;
+      u32 carry = 0;
+#pragma unroll
+      for (int i = 0; i < L - 1; i++) {
+        const u32 v = a.l[i] - b.l[i] + kp_spread<K, 1>(i) + carry;
+        r.l[i] = v & MASK;
+        carry = v >> W;
+      }
+      r.l[L - 1] = a.l[L - 1] - b.l[L - 1] + kp_spread<K, 1>(L - 1) + carry;
+      return r;
+    }
+  }
+  // limb i of k p for ANY k with k p < 2^(W L) (the LZ_KP table stops at 8): compile-time arithmetic on LZ_KP[1]
+  static constexpr u32 kp_limb(int k, int i) {
+    u64 carry = 0;
+    u32 out = 0;
+    for (int j = 0; j <= i; j++) {
+      const u64 t = (u64)P::LZ_KP[1][j] * (u64)k + carry;
+      out = j < L - 1 ? (u32)(t & MASK) : (u32)t;
+      carry = t >> W;
+    }
+    return out;
+  }
+  // k p with limbs that each lend H 2^W to the one below (kp_spread for arbitrary k)
+  template <int K, int H>
+  static constexpr u32 kp_spread_any(int i) {
+    return kp_limb(K, i) + (i < L - 1 ? ((u32)H << W) : 0u) - (i > 0 ? (u32)H : 0u);
   }
   // K p - a, limbs below 2^29 (a normalised)
   template <int K>
@@ -397,7 +484,7 @@ struct FpL {
     for (int i = 0; i < L - 1; i++) {
       const u32 v = a.l[i] - b.l[i] - 2u * c.l[i] + kp_spread<K, 3>(i) + carry;
       r.l[i] = v & MASK;
-      carry = v >> 28;
+      carry = v >> W;
     }
     r.l[L - 1] = a.l[L - 1] - b.l[L - 1] - 2u * c.l[L - 1] + kp_spread<K, 3>(L - 1) + carry;
     return r;
@@ -437,7 +524,7 @@ struct FpL {
     FpL r;
 #pragma unroll
     for (int i = 0; i < L; i++) {
-      const int bit = 28 * i;
+      const int bit = W * i;
       const int j = bit / 32, sh = bit % 32;
       u64 v = 0;
       if (j < N) v = (u64)in[j] >> sh;
@@ -448,13 +535,13 @@ struct FpL {
   }
   // the canonical limbs shifted left by SH = 28 L - 32 N bits: x R 2^SH = x R', i.e. the residue x itself in this form's
   // radix, unreduced (below 2^SH p; normalised limbs) -- good as ONE operand of a product: x y / R' < 2^SH y p / R'
-  static constexpr int SH = 28 * L - 32 * N;
+  static constexpr int SH = W * L - 32 * N;
   ARK_HD static FpL unpack32_shl(const u32* in) {
-    static_assert(SH >= 0 && SH < 28, "shift within the lowest limb");
+    static_assert(SH >= 0 && SH < W, "shift within the lowest limb");
     FpL r;
 #pragma unroll
     for (int i = 0; i < L; i++) {
-      const int bit = 28 * i - SH;   // input bit that lands at this limb's bit 0
+      const int bit = W * i - SH;   // input bit that lands at this limb's bit 0
       if (bit < 0) {
         r.l[i] = (in[0] << SH) & MASK;
       } else {
@@ -472,10 +559,10 @@ struct FpL {
 #pragma unroll
     for (int j = 0; j < N; j++) {
       const int bit = 32 * j;
-      const int i = bit / 28, sh = bit % 28;
+      const int i = bit / W, sh = bit % W;
       u64 v = (u64)l[i] >> sh;
-      if (i + 1 < L) v |= (u64)l[i + 1] << (28 - sh);
-      if (i + 2 < L) v |= (u64)l[i + 2] << (56 - sh);
+      if (i + 1 < L) v |= (u64)l[i + 1] << (W - sh);
+      if (i + 2 < L) v |= (u64)l[i + 2] << (2 * W - sh);
       out[j] = (u32)v;
     }
   }
@@ -497,13 +584,13 @@ struct FpL {
     for (int i = 0; i < L; i++) {
       acc += (u64)l[i] + (u64)m * P::LZ_KP[1][i];
       t[i] = (u32)acc & MASK;
-      acc >>= 28;
+      acc >>= W;
     }
     t[L] = (u32)acc;
     FpL r;
 #pragma unroll
-    for (int i = 0; i < L; i++) r.l[i] = ((t[i] >> K) | (t[i + 1] << (28 - K))) & MASK;
-    r.l[L - 1] = (t[L - 1] >> K) | (t[L] << (28 - K));  // top limb keeps whatever is left (value < 2^(28 L))
+    for (int i = 0; i < L; i++) r.l[i] = ((t[i] >> K) | (t[i + 1] << (W - K))) & MASK;
+    r.l[L - 1] = (t[L - 1] >> K) | (t[L] << (W - K));  // top limb keeps whatever is left (value < 2^(28 L))
     return r;
   }
   // normalised value below 2 p (and below 2^(32 N)) -> canonical limbs in [0, p)

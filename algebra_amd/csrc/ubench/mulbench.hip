@@ -1,17 +1,21 @@
-// Product-rate microbenchmark of the two Fp384 multiplications the accumulate kernels can run on (BLS12-381 Fq):
-// fp.cuh's saturated 32-bit Comba product against fp28.cuh's carry-free 28-bit forms (compiler-scheduled and asm
-// columns, dedicated square, sum of two products), back to back in a loop at 1 / 2 / 4 / 8 waves per SIMD.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I.. mulbench.hip -o mulbench.bin
+// Product-rate microbenchmark of the two multiplications the kernels can run on: fp.cuh's saturated 32-bit Comba
+// product against fp28.cuh's carry-free forms (14 x 28 bits for Fp384, 9 x 29 bits for Fp254/255: compiler-scheduled
+// and asm columns, dedicated square, sum of two products), back to back in a loop at 1 / 2 / 4 / 8 waves per SIMD.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I.. mulbench.hip -o mulbench.bin            (BLS12-381 Fq)
+//   hipcc ... -DMULBENCH_FIELD=BLS12_381_FR mulbench.hip -o mulbench_fr.bin                  (9 x 29 bits)
 #include "../fp28.cuh"
 #include <stdio.h>
 using namespace arkhip;
-typedef BLS12_381_FQ P;
+#ifndef MULBENCH_FIELD
+#define MULBENCH_FIELD BLS12_381_FQ
+#endif
+typedef MULBENCH_FIELD P;
 template <int V> __global__ void __launch_bounds__(256) k_lazy(u32* out, int iters) {
   typedef FpL<P> L;
   L a, b;
   u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   for (int i = 0; i < L::L; i++) { a.l[i] = (tid * 2654435761u * (i + 1)) & L::MASK; b.l[i] = ((tid ^ 77) * 40503u * (i + 3)) & L::MASK; }
-  a.l[L::L - 1] &= 0xffff; b.l[L::L - 1] &= 0xffff;
+  a.l[L::L - 1] &= 0xfff; b.l[L::L - 1] &= 0xfff;
   for (int k = 0; k < iters; k++) {
     if constexpr (V == 0) a = L::mul_c(a, b);
     else if constexpr (V == 1) a = L::mul(a, b);
@@ -28,7 +32,7 @@ __global__ void __launch_bounds__(256) k_sat(u32* out, int iters) {
   F a, b;
   u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   for (int i = 0; i < F::N; i++) { a.l[i] = (tid * 2654435761u * (i + 1)); b.l[i] = ((tid ^ 77) * 40503u * (i + 3)); }
-  a.l[F::N - 1] &= 0xfffffff; b.l[F::N - 1] &= 0xfffffff;
+  a.l[F::N - 1] &= 0x7ffffff; b.l[F::N - 1] &= 0x7ffffff;
   for (int k = 0; k < iters; k++) a = F::mul(a, b);
   u32 r = 0;
   for (int i = 0; i < F::N; i++) r ^= a.l[i];
@@ -66,7 +70,8 @@ int main() {
              (double)b * 256 * it * 32 / (ms * 1e-3) * 1e-12);
     }
   }
-  const char* names[6] = {"lazy28 mul, compiler-scheduled columns", "lazy28 mul  (asm: one chain per column)", "lazy28 sqr  (asm)                      ", "lazy28 sop2 (asm: a b + c d)           ", "lazy28 sqr, compiler-scheduled         ", "sat32  mul  (fp.cuh)                   "};
+  printf("field id %d: %d x %d-bit carry-free limbs against %d saturated 32-bit limbs\n", P::ID, FpL<P>::L, FpL<P>::W, P::N);
+  const char* names[6] = {"carry-free mul, compiler-scheduled columns", "carry-free mul  (asm: one chain per column)", "carry-free sqr  (asm)                      ", "carry-free sop2 (asm: a b + c d)           ", "carry-free sqr, compiler-scheduled         ", "sat32  mul  (fp.cuh)                       "};
   for (int w : {1, 2, 4, 8}) {
     for (int v = 0; v < 6; v++) {
       int b = 256 * w;

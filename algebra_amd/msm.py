@@ -138,9 +138,10 @@ def pin_bases(curve, bases):
 
 
 def base_cache_config(budget_bytes=-1, auto_prepare_after=-1):
-    """Transparent resident-base cache of the host-array entry (ark_hip_msm_cache_config; OFF by default): numpy base
-    sets passed to msm / msm_bigint are kept on the GPU per (array address, length) and validated on every call by a
-    hash of their full content.  0 bytes disables it."""
+    """Verified resident-base cache of the host-array entry (ark_hip_msm_cache_config; on by default with a quarter of
+    the device memory): numpy base sets passed to msm / msm_bigint are kept on the GPU per (array address, length) and
+    validated on EVERY call by a hash of their full content -- an edited array is re-uploaded, never used stale.
+    0 bytes disables it (every call then streams its bases), -2 restores the default budget."""
     check(lib().ark_hip_msm_cache_config(int(budget_bytes), int(auto_prepare_after)), "ark_hip_msm_cache_config")
 
 

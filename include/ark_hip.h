@@ -92,31 +92,34 @@ int ark_hip_curve_generator(int curve, uint64_t* out_xy);
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int scalars_are_montgomery,
                    uint64_t* out_xyz);
 /* ark_hip_msm_sw is a FUNCTION OF ITS TWO SLICES, like the reference (`bases: &[Affine]` is borrowed for the call,
- * variable_base/mod.rs:59-85): by default bases and scalars stream over PCIe together, piece k+1 under piece k's kernels,
- * and the library retains nothing of them.  Provers hand the SAME base slice -- an SRS -- to call after call
- * (bench-templates/src/macros/ec.rs:223-240 does exactly that); two ways to keep it resident:
+ * variable_base/mod.rs:59-85): whatever the library keeps between calls never changes a result.  Provers hand the SAME
+ * base slice -- an SRS -- to call after call (bench-templates/src/macros/ec.rs:223-240 does exactly that), so device
+ * copies of base slices are kept in two ways:
  *
- * Pinned base sets.  ark_hip_msm_bases_pin(curve, bases, n) uploads the set now and declares bases[0 .. n) IMMUTABLE until
- * the matching ark_hip_msm_bases_unpin(curve, bases, n).  Every ark_hip_msm_sw / ark_hip_msm_sw_small call on this device
- * whose base slice lies inside a pinned range (at a point boundary: the whole set, msm_unchecked's truncation, the steps
- * of msm_chunks / ChunkedPippenger) runs against the resident copy and uploads only its scalars -- no validation, the
- * declaration is the contract (the Rust guard ark_hip::msm::ResidentBases holds the shared borrow for the pin's lifetime,
- * so the compiler enforces it).  Pins of the same (curve, address, n) nest.  ARK_HIP_ERR_NOMEM if the copy does not fit,
- * ARK_HIP_ERR_ARG for an unpin without a pin.
- *
- * Transparent cache (OPT-IN: off unless ark_hip_msm_cache_config / ARK_HIP_BASE_CACHE_MB give it a budget).  Device copies
- * keyed by (curve, host address, length) and validated on EVERY call by a hash of the slice's FULL content: the hash is
- * computed on host threads (ARK_HIP_HASH_THREADS, default 8) while the device already works from the cached copy, and
- * the result is returned only if it matches the hash of what the copy holds -- otherwise the copy is refreshed and the MSM
- * rerun.  Any in-place edit of the slice, of a single limb, is therefore honoured; a hit costs one pass over the host
- * slice instead of its PCIe transfer.  Least-recently-used sets (with their tables) are dropped beyond the budget.
- *   ark_hip_msm_cache_config(budget_bytes, auto_prepare_after): budget < 0 keeps the current value (default 0 = off, or
- *     ARK_HIP_BASE_CACHE_MB), 0 disables and empties the cache; auto_prepare_after = K > 0 builds the per-window table of
- *     a resident set -- pinned or cached -- once the WHOLE set has been the operand K times (default 0 = never, or
+ * Verified cache (on by default).  Device copies keyed by (curve, host address, length), validated on EVERY call by a
+ * hash of the slice's FULL content: host threads (ARK_HIP_HASH_THREADS, default 8) hash the slice while the device already
+ * works from the cached copy, and the result is returned only if the hash equals that of the content the copy was filled
+ * from -- otherwise the copy is refreshed and the MSM rerun.  An in-place edit of the slice, of a single limb, is therefore
+ * honoured on the next call; a hit costs one pass over the host slice instead of its PCIe transfer (2^24 BLS12-381 G1:
+ * 40 ms per call against 48 ms streamed).  A slice that does not fit the budget streams over PCIe with its scalars, piece
+ * k+1 under piece k's kernels.  Least-recently-used sets (with their tables) are dropped beyond the budget.
+ *   ark_hip_msm_cache_config(budget_bytes, auto_prepare_after): budget -1 keeps the current value, -2 restores the
+ *     default (a quarter of the device memory, or ARK_HIP_BASE_CACHE_MB), 0 disables and empties the cache (every call
+ *     then streams bases and scalars and nothing is retained); auto_prepare_after = K > 0 builds the per-window table of a
+ *     resident set -- pinned or cached -- once the WHOLE set has been the operand K times (default 0 = never, or
  *     ARK_HIP_AUTO_PREPARE; a cached set's table counts against the budget), < 0 keeps the current value.
- *   ark_hip_msm_cache_clear: drops the transparent entries (pinned sets stay).
+ *   ark_hip_msm_cache_clear: drops the cached sets (pinned sets stay).
  *   ark_hip_msm_cache_stats: [cached sets, their device bytes, hits, misses, refreshed (content changed), evicted,
- *     pinned sets, pinned hits]. */
+ *     pinned sets, pinned hits].
+ *
+ * Pinned base sets (no host pass at all).  ark_hip_msm_bases_pin(curve, bases, n) uploads the set now and declares
+ * bases[0 .. n) IMMUTABLE until the matching ark_hip_msm_bases_unpin(curve, bases, n).  Every ark_hip_msm_sw /
+ * ark_hip_msm_sw_small call on this device whose base slice lies inside a pinned range (at a point boundary: the whole set,
+ * msm_unchecked's truncation, the steps of msm_chunks / ChunkedPippenger) runs against the resident copy and uploads only
+ * its scalars -- no validation, the declaration is the contract (the Rust guard ark_hip::msm::ResidentBases holds the
+ * shared borrow for the pin's lifetime, so the compiler enforces it).  Pins of the same (curve, address, n) nest; pinned
+ * sets are outside the cache's budget.  ARK_HIP_ERR_NOMEM if the copy does not fit, ARK_HIP_ERR_ARG for an unpin without
+ * a pin. */
 int ark_hip_msm_bases_pin(int curve, const uint64_t* bases, size_t n);
 int ark_hip_msm_bases_unpin(int curve, const uint64_t* bases, size_t n);
 int ark_hip_msm_cache_config(long long budget_bytes, int auto_prepare_after);

@@ -80,7 +80,8 @@ using Bls12_377G1 = CurveTag<ARK_HIP_BLS12_377_G1, 6, ARK_HIP_BLS12_377_FR>;
 using Bls12_377G2 = CurveTag<ARK_HIP_BLS12_377_G2, 12, ARK_HIP_BLS12_377_FR>;
 using Bls12_381G2 = CurveTag<ARK_HIP_BLS12_381_G2, 12, ARK_HIP_BLS12_381_FR>;
 
-// VariableBaseMSM<..>::msm / msm_bigint are functions of their two spans (bases and scalars stream over PCIe together).
+// VariableBaseMSM<..>::msm / msm_bigint are functions of their two spans (a cached device copy of the bases is
+// re-validated on every call by a hash of the span's full content: base_cache_config below).
 // ResidentBases pins a base vector on the GPU for its lifetime: while it lives the caller does not modify the vector, and
 // every msm / msm_bigint / msm_u* whose bases lie inside it runs against the resident copy (ark_hip_msm_bases_pin).
 template <class Curve>
@@ -98,8 +99,8 @@ class ResidentBases {
   const typename Curve::AffineT* p_;
   size_t n_;
 };
-// The opt-in transparent cache (ark_hip_msm_cache_* in ark_hip.h; off by default): base vectors passed again at the same
-// address stay on the GPU, validated on every call by a hash of their full content.
+// The verified cache (ark_hip_msm_cache_* in ark_hip.h; on by default): base vectors passed again at the same address stay
+// on the GPU, validated on every call by a hash of their full content.
 struct BaseCacheStats { uint64_t entries, bytes, hits, misses, refreshed, evicted, pinned, pinned_hits; };
 inline void base_cache_config(long long budget_bytes = -1, int auto_prepare_after = -1) {
   check(ark_hip_msm_cache_config(budget_bytes, auto_prepare_after), "ark_hip_msm_cache_config");

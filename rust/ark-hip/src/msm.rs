@@ -142,9 +142,10 @@ pub fn sw_msm_chunks<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalar
 
 /// A base slice pinned on the GPU for the guard's lifetime (`ark_hip_msm_bases_pin` / `_unpin`).
 ///
-/// `sw_msm` / `sw_msm_bigint` / `sw_msm_small` are functions of their two slices: by default bases and scalars cross
-/// PCIe together on every call and the library keeps nothing.  A prover that calls `G::msm(&srs, ..)` again and again
-/// pins the SRS once:
+/// `sw_msm` / `sw_msm_bigint` / `sw_msm_small` are functions of their two slices.  By default the library keeps a device
+/// copy of a base slice it has seen and re-validates it on every call with a hash of the slice's full content (one host
+/// pass per call, see [`base_cache_config`]); a prover that calls `G::msm(&srs, ..)` again and again can spare even that
+/// pass by pinning the SRS:
 ///
 /// ```ignore
 /// let _resident = ResidentBases::pin(ark_hip::BLS12_381_G1, &srs)?;   // uploads srs; borrows it until dropped
@@ -178,11 +179,11 @@ impl<'a, P: SWCurveConfig> Drop for ResidentBases<'a, P> {
     }
 }
 
-/// The OPT-IN transparent cache behind `sw_msm` / `sw_msm_bigint` (include/ark_hip.h, `ark_hip_msm_cache_*`; off unless
-/// given a budget here or through `ARK_HIP_BASE_CACHE_MB`): device copies keyed by (curve, address, length), validated on
-/// every call by a hash of the slice's FULL content computed on host threads while the device works from the copy; a
-/// changed slice is refreshed and the MSM rerun, so a result never reflects stale bases.  For code that cannot hold a
-/// [`ResidentBases`] guard.  `budget_bytes = Some(0)` turns it off again.
+/// The verified cache behind `sw_msm` / `sw_msm_bigint` (include/ark_hip.h, `ark_hip_msm_cache_*`; on by default with a
+/// quarter of the device memory, `ARK_HIP_BASE_CACHE_MB` overrides): device copies keyed by (curve, address, length),
+/// validated on every call by a hash of the slice's FULL content computed on host threads while the device works from the
+/// copy; a changed slice is refreshed and the MSM rerun, so a result never reflects stale bases.
+/// `budget_bytes = Some(0)` turns it off (every call then streams its bases over PCIe).
 pub fn base_cache_config(budget_bytes: Option<u64>, auto_prepare_after: Option<u32>) -> bool {
     let b = budget_bytes.map(|v| v as core::ffi::c_longlong).unwrap_or(-1);
     let a = auto_prepare_after.map(|v| v as c_int).unwrap_or(-1);

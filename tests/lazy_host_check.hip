@@ -24,7 +24,7 @@ template <class P> Fp<P> lazy_value(const FpL<P>& a) {  // value v (mod p) in ca
   a.pack32(w);
   F t = F::reduce_full(*(const F*)w);   // integer a mod p, = v R' mod p
   // v R = t * (R / R') = t * 2^-(28L - 32N): repeated halving mod p
-  for (int k = 0; k < 28 * FpL<P>::L - 32 * P::N; k++) {
+  for (int k = 0; k < FpL<P>::W * FpL<P>::L - 32 * P::N; k++) {
     // t/2 mod p
     u32 c = 0;
     F x = t;
@@ -38,7 +38,7 @@ template <class P> Fp<P> lazy_value(const FpL<P>& a) {  // value v (mod p) in ca
 template <class P> FpL<P> to_lazy(const Fp<P>& a) {  // canonical a -> lazy value a (radix R'): bits = a 2^(28L-32N) mod p
   typedef Fp<P> F;
   F t = a;
-  for (int k = 0; k < 28 * FpL<P>::L - 32 * P::N; k++) t = F::dbl(t);
+  for (int k = 0; k < FpL<P>::W * FpL<P>::L - 32 * P::N; k++) t = F::dbl(t);
   return FpL<P>::unpack32(t.l);
 }
 template <class P> int run(const char* name, const uint64_t* gen) {
@@ -68,12 +68,20 @@ template <class P> int run(const char* name, const uint64_t* gen) {
       if (!F::eq(lazy_value<P>(h20), lazy_value<P>(h16))) { bad++; if (bad < 5) printf("%s shr_mod<20> fail\n", name); }
     }
     // differences without a carry sweep (semi-normalised), as products' operands; the shifted repack
-    if (!F::eq(lazy_value<P>(L::mul(L::template sub_semi<2>(la, lb), L::template sub_semi<6>(lc, ld))), F::mul(F::sub(a, b), F::sub(c, d)))) { bad++; if (bad < 5) printf("%s sub_semi fail\n", name); }
-    if (!F::eq(lazy_value<P>(L::sqr(L::template sub_semi<6>(la, lb))), F::sqr(F::sub(a, b)))) { bad++; if (bad < 5) printf("%s sqr(sub_semi) fail\n", name); }
+    if constexpr (L::SEMI2) {   // two semi-normalised operands in one product: only where a column has room (14 x 28 bits)
+      if (!F::eq(lazy_value<P>(L::mul(L::template sub_semi<2>(la, lb), L::template sub_semi<6>(lc, ld))), F::mul(F::sub(a, b), F::sub(c, d)))) { bad++; if (bad < 5) printf("%s sub_semi fail\n", name); }
+      if (!F::eq(lazy_value<P>(L::sqr(L::template sub_semi<6>(la, lb))), F::sqr(F::sub(a, b)))) { bad++; if (bad < 5) printf("%s sqr(sub_semi) fail\n", name); }
+    }
+    // the mixed addition's own operand classes: sub_op (semi-normalised or swept, by geometry) squared, times a
+    // normalised value, and as the normalised-or-semi side of Y3's sum of two products
+    if (!F::eq(lazy_value<P>(L::sqr(L::template sub_op<6>(la, lb))), F::sqr(F::sub(a, b)))) { bad++; if (bad < 5) printf("%s sqr(sub_op) fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul(L::template sub_op<2>(la, lb), lc)), F::mul(F::sub(a, b), c))) { bad++; if (bad < 5) printf("%s mul(sub_op) fail\n", name); }
+    if (!F::eq(lazy_value<P>(L::mul(L::template sub_semi<6>(la, lb), lc)), F::mul(F::sub(a, b), c))) { bad++; if (bad < 5) printf("%s mul(sub_semi, n) fail\n", name); }
+    if (!L::SEMI2) { L n = L::template sub_op<6>(la, lb); for (int i = 0; i < L::L - 1; i++) if (n.l[i] > L::MASK) { bad++; printf("%s sub_op not normalised\n", name); break; } }
     if (!F::eq(lazy_value<P>(L::mul(L::template neg_semi<2>(la), lb)), F::mul(F::neg(a), b))) { bad++; if (bad < 5) printf("%s neg_semi fail\n", name); }
     if (!F::eq(lazy_value<P>(L::template sub_b_2c_norm<4>(la, lb, lc)), F::sub(F::sub(a, b), F::dbl(c)))) { bad++; if (bad < 5) printf("%s sub_b_2c_norm fail\n", name); }
     { L n = L::template sub_b_2c_norm<4>(la, lb, lc); for (int i = 0; i < L::L - 1; i++) if (n.l[i] > L::MASK) { bad++; printf("%s sub_b_2c_norm not normalised\n", name); break; } }
-    if (!F::eq(lazy_value<P>(L::sop2(L::template sub_semi<2>(la, lb), L::template sub_semi<6>(lc, ld), L::template neg_semi<2>(la), lb)),
+    if (!F::eq(lazy_value<P>(L::sop2(L::template sub_op<2>(la, lb), L::template sub_semi<6>(lc, ld), L::template neg_semi<2>(la), lb)),
                F::sub(F::mul(F::sub(a, b), F::sub(c, d)), F::mul(a, b)))) { bad++; if (bad < 5) printf("%s sop2(semi) fail\n", name); }
     if (!F::eq(lazy_value<P>(L::mul(L::unpack32_shl(a.l), lb)), F::mul(a, b))) { /* a.l 2^8 = a R': the same residue, unreduced */ bad++; if (bad < 5) printf("%s unpack32_shl fail\n", name); }
     if (!L::mul(L::template sub_semi<1>(la, la), lb).is_zero_or_p()) { bad++; printf("%s is_zero_or_p miss\n", name); }
@@ -187,5 +195,6 @@ int main() {
   int b = 0;
   b += run<BLS12_381_FQ>("BLS12_381_FQ", GEN_BLS12_381_G1);
   b += run<BLS12_377_FQ>("BLS12_377_FQ", GEN_BLS12_377_G1);
+  b += run<BN254_FQ>("BN254_FQ", GEN_BN254_G1);   // 9 x 29-bit limbs
   return b != 0;
 }

@@ -34,10 +34,12 @@ def oracle_aff(cid, bases, scalars, **kw):
 
 @pytest.fixture(autouse=True)
 def default_state():
-    """Every test starts from the library's default: transparent cache off, nothing pinned."""
-    A.base_cache_config(0, 0)
+    """Every test starts from the library's defaults (verified cache on with its default budget, nothing pinned)."""
+    A.base_cache_config(-2, 0)
+    A.base_cache_clear()
     yield
-    A.base_cache_config(0, 0)
+    A.base_cache_config(-2, 0)
+    A.base_cache_clear()
     assert A.base_cache_stats()["pinned"] == 0, "a test leaked a pin"
 
 
@@ -46,27 +48,46 @@ def transparent_cache():
     A.base_cache_config(8 << 30, 0)
     A.base_cache_clear()
     yield
+
+
+@pytest.fixture
+def no_cache():
     A.base_cache_config(0, 0)
+    yield
 
 
 def delta(before, after):
     return {k: after[k] - before[k] for k in ("hits", "misses", "refreshed", "evicted")}
 
 
-# ---- default: a function of the two slices -------------------------------------------------------------------------
-def test_default_retains_nothing_and_honours_a_single_edited_base():
+# ---- default settings: a function of the two slices ------------------------------------------------------------------
+def test_default_settings_honour_a_single_edited_base():
     """n >= 2^16, ONE base edited in place between two calls (index 12345: not one of the 4097 points the
-    round-3 fingerprint sampled), default settings -> the oracle's result for the edited slice."""
+    round-3 fingerprint sampled), DEFAULT settings -> the oracle's result for the edited slice."""
     cid = O.CID["BLS12_381_G1"]
     n = 1 << 16
     bases = O.gen_bases(cid, A4, B4, n).copy()
     scalars = O.gen_scalars(sf(cid), 1, n)
     s0 = A.base_cache_stats()
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+    assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
     bases[12345] = O.gen_bases(cid, C4, A4, 1)[0]               # same array, one point replaced
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
     bases[n - 1] = O.gen_bases(cid, B4, A4, 1)[0]               # and the last one
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
+    d = delta(s0, A.base_cache_stats())
+    assert d == {"hits": 1, "misses": 1, "refreshed": 2, "evicted": 0}, d
+
+
+def test_cache_off_retains_nothing(no_cache):
+    cid = O.CID["BLS12_381_G1"]
+    n = 1 << 14
+    bases = O.gen_bases(cid, A4, B4, n).copy()
+    scalars = O.gen_scalars(sf(cid), 1, n)
+    s0 = A.base_cache_stats()
+    for j in (0, 5000, n - 1):
+        bases[j] = O.gen_bases(cid, C4, A4, 1)[0]
+        assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
     s1 = A.base_cache_stats()
     assert s1 == s0 and s1["entries"] == 0 and s1["pinned"] == 0
 
@@ -102,7 +123,7 @@ def test_pinned_bases_whole_set_and_sub_slices(cname):
         assert rb.n == n
     assert bases.flags.writeable
     s1 = A.base_cache_stats()
-    assert s1["pinned"] == 0 and s1["entries"] == 0
+    assert s1["pinned"] == 0 and s1["entries"] == 0              # pinned ranges never entered the cache
     # after the unpin the array is the caller's again: an edit is honoured
     other = O.gen_bases(cid, C4, B4, n)
     bases = bases.copy()
@@ -209,7 +230,7 @@ def test_streamed_pieces_match_oracle(pieces, monkeypatch, transparent_cache):
             assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), (cname, pieces)
         with A.pin_bases(cid, bases):                           # pinned: scalars only, from the first call on
             assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars)), (cname, pieces)
-    # the default: bases AND scalars stream piecewise (the msm_chunks machinery)
+    # cache off: bases AND scalars stream piecewise (the msm_chunks machinery)
     A.base_cache_config(0, -1)
     cid = O.CID["BLS12_381_G1"]
     bases = O.gen_bases(cid, A4, B4, 5000)
@@ -217,9 +238,9 @@ def test_streamed_pieces_match_oracle(pieces, monkeypatch, transparent_cache):
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, scalars)), oracle_aff(cid, bases, scalars))
 
 
-def test_streamed_pieces_at_size(monkeypatch):
-    # 2^21 pairs through the default piece rules against k*G: bases + scalars streamed in the tapered pieces
-    # (1, 2, 3, 1, 1 eighths), then pinned -- scalars only, in GROWING pieces (each twice the one before: 3 pieces here)
+def test_streamed_pieces_at_size(monkeypatch, no_cache):
+    # 2^21 pairs through the default piece rules against k*G: bases + scalars streamed (eighths; from 2^22 the last
+    # eighth halves down to 2^18 pairs), then pinned -- scalars only, in GROWING pieces (each twice the one before)
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -231,9 +252,9 @@ def test_streamed_pieces_at_size(monkeypatch):
     sc = S.gen_scalars(n, 0x51, r)
     want = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
-    monkeypatch.setenv("ARK_HIP_STREAM_TAPER", "0")            # equal pieces: the same point
+    monkeypatch.setenv("ARK_HIP_STREAM_SCHEDULE", "1,3,9,2,1")  # an uneven schedule: the same point
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
-    monkeypatch.delenv("ARK_HIP_STREAM_TAPER")
+    monkeypatch.delenv("ARK_HIP_STREAM_SCHEDULE")
     m = (3 << 18) + 1001
     want_m = S.mul_gen(cid, S.dlog_of_msm(sc[:m], S.A0, S.B0, r), r)
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[:m], sc[:m])), want_m)   # ragged, unpinned
@@ -247,14 +268,14 @@ def test_streamed_pieces_at_size(monkeypatch):
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases[:m], sc[:m])), want_m)
         assert A.base_cache_stats()["pinned_hits"] - s0["pinned_hits"] == 3
     # the transparent cache at this size: miss, hit, one base edited (hash of 192 MiB on the host threads), hit
+    j = 1234567
+    want_e = S.mul_gen(cid, (S.dlog_of_msm(sc, S.A0, S.B0, r) - S.scalar_int(sc[j]) * S.B0) % r, r)
     A.base_cache_config(4 << 30, 0)
     bases = bases.copy()
     s0 = A.base_cache_stats()
     for _ in range(2):
         assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want)
-    j = 1234567
     bases[j], keep = bases[j - 1], bases[j].copy()              # P_j := P_(j-1): the sum moves by s_j (P_(j-1) - P_j) = -s_j b G
-    want_e = S.mul_gen(cid, (S.dlog_of_msm(sc, S.A0, S.B0, r) - S.scalar_int(sc[j]) * S.B0) % r, r)
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want_e)
     assert np.array_equal(aff(cid, A.msm_bigint(cid, bases, sc)), want_e)
     bases[j] = keep
@@ -305,7 +326,8 @@ def test_multi_device_entry_pins_per_shard(monkeypatch):
     bases = O.gen_bases(cid, A4, B4, n)
     scalars = O.gen_scalars(sf(cid), 8, n)
     want = oracle_aff(cid, bases, scalars)
-    assert np.array_equal(aff(cid, A.msm_bigint_multi(cid, 3, bases, scalars)), want)   # unpinned: every shard streams
+    for _ in range(2):                                          # unpinned: every device caches (and verifies) its shard
+        assert np.array_equal(aff(cid, A.msm_bigint_multi(cid, 3, bases, scalars)), want)
     # a pin lives on ONE device: pin each device's shard there (the split ark_hip_msm_sw_multi uses)
     L = lib()
     cur = L.ark_hip_get_device()

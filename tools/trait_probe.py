@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Times the trait-surface entry (ark_hip_msm_sw from pageable host memory) at one size: first call (bases + scalars
-over PCIe), repeat calls (resident-base cache: scalars only) for several piece counts, cache off, and auto-prepared.
-Run once per ARK_HIP_COPY_THREADS setting (the staging pool is created on first use).  Every result is checked
-against k*G."""
+"""Times the trait-surface entry (ark_hip_msm_sw from pageable host memory) at one size in each of its modes:
+  default      bases + scalars streamed over PCIe in tapered pieces, nothing retained (a function of the two slices);
+  pinned       ark_hip_msm_bases_pin: scalars only, growing pieces (first call after the pin and repeat calls);
+  transparent  the opt-in cache validated by a full-content hash on host threads (miss, hit);
+  prepared     pinned + auto-prepared per-window table.
+Every result is checked against k*G.  ARK_HIP_COPY_THREADS / ARK_HIP_HASH_THREADS are read by the library."""
 import argparse
 import os
 import sys
@@ -20,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=24)
     ap.add_argument("--curve", default="BLS12_381_G1")
-    ap.add_argument("--pieces", default="1,2,4,8")
+    ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--auto-prepare", action="store_true")
     args = ap.parse_args()
     import torch
@@ -35,10 +37,12 @@ def main():
     want = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
     dsc = torch.from_numpy(sc.view(np.int64)).cuda()
     torch.cuda.synchronize()
-    tag = "threads=%s n=2^%d %s" % (os.environ.get("ARK_HIP_COPY_THREADS", "default(4)"), args.log_n, args.curve)
+    tag = "copy_threads=%s hash_threads=%s n=2^%d %s" % (os.environ.get("ARK_HIP_COPY_THREADS", "0"),
+                                                        os.environ.get("ARK_HIP_HASH_THREADS", "8"), args.log_n, args.curve)
 
-    def timed(fn, reps):
-        fn()
+    def timed(fn, reps, warm=True):
+        if warm:
+            fn()
         t0 = time.perf_counter()
         for _ in range(reps):
             res = fn()
@@ -47,33 +51,40 @@ def main():
     def ok(res):
         return bool(np.array_equal(A.into_affine(cid, res), want))
 
-    ms, res = timed(lambda: A.msm_bigint(cid, bases, dsc), 3)
-    print("%s  resident (ark_hip_msm_sw_device)            %8.2f ms  exact=%s" % (tag, ms, ok(res)), flush=True)
-    A.base_cache_clear()
-    t0 = time.perf_counter()
-    res = A.msm_bigint(cid, hb, sc)
-    first = (time.perf_counter() - t0) * 1e3
+    def line(what, ms, res, extra=""):
+        print("%s  %-58s %8.2f ms  %.3e scalar-muls/s  exact=%s %s" % (tag, what, ms, n / (ms * 1e-3), ok(res), extra), flush=True)
+
     gb = (hb.nbytes + sc.nbytes) / 1e9
-    print("%s  first call  (miss: %.2f GB over PCIe)        %8.2f ms  exact=%s" % (tag, gb, first, ok(res)), flush=True)
-    for p in [int(x) for x in args.pieces.split(",")]:
-        os.environ["ARK_HIP_STREAM_PIECES"] = str(p)
-        ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), 3)
-        print("%s  repeat call (hit), %2d piece(s)               %8.2f ms  exact=%s  %.3e scalar-muls/s"
-              % (tag, p, ms, ok(res), n / (ms * 1e-3)), flush=True)
-    os.environ.pop("ARK_HIP_STREAM_PIECES", None)
-    ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), 3)
-    print("%s  repeat call (hit), default pieces             %8.2f ms  exact=%s  cache=%s"
-          % (tag, ms, ok(res), A.base_cache_stats()), flush=True)
+    ms, res = timed(lambda: A.msm_bigint(cid, bases, dsc), args.reps)
+    line("resident (ark_hip_msm_sw_device)", ms, res)
+    A.base_cache_config(0, 0)
+    ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), args.reps)
+    line("default: bases + scalars streamed (%.2f GB), tapered" % gb, ms, res)
+    os.environ["ARK_HIP_STREAM_TAPER"] = "0"
+    ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), args.reps)
+    line("default, equal pieces (ARK_HIP_STREAM_TAPER=0)", ms, res)
+    os.environ.pop("ARK_HIP_STREAM_TAPER")
+    t0 = time.perf_counter()
+    pin = A.pin_bases(cid, hb)
+    pin_ms = (time.perf_counter() - t0) * 1e3
+    ms1, res = timed(lambda: A.msm_bigint(cid, hb, sc), 1, warm=False)
+    line("pinned: first call after the pin (pin itself %.1f ms)" % pin_ms, ms1, res)
+    ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), args.reps)
+    line("pinned: repeat call, growing pieces", ms, res, str(A.base_cache_stats()))
     if args.auto_prepare:
         A.base_cache_config(-1, 1)
         A.msm_bigint(cid, hb, sc)
-        A.msm_bigint(cid, hb, sc)
-        ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), 3)
-        print("%s  repeat call, auto-prepared table              %8.2f ms  exact=%s" % (tag, ms, ok(res)), flush=True)
+        ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), args.reps)
+        line("pinned + auto-prepared table", ms, res)
         A.base_cache_config(-1, 0)
-    A.base_cache_config(0, -1)
-    ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), 2)
-    print("%s  cache off (bases + scalars streamed)          %8.2f ms  exact=%s" % (tag, ms, ok(res)), flush=True)
+    pin.unpin()
+    A.base_cache_config(64 << 30, 0)
+    ms1, res = timed(lambda: A.msm_bigint(cid, hb, sc), 1, warm=False)
+    line("transparent cache: miss (fill + hash)", ms1, res)
+    ms, res = timed(lambda: A.msm_bigint(cid, hb, sc), args.reps)
+    line("transparent cache: hit (speculative MSM + full hash)", ms, res, str(A.base_cache_stats()))
+    hb[n // 3, 0] ^= np.uint64(0)   # (no edit: the refresh path is a test's business; here only timings)
+    A.base_cache_config(0, 0)
 
 
 if __name__ == "__main__":
