@@ -151,8 +151,9 @@ int batchmul_run(const void* d_table, int window, const void* d_scalars, size_t 
   if (n == 0) return 0;
   const int outer = batchmul_outer(window);
   bool lazy = false;
-  if constexpr (C::LAZY_A) lazy = msm_lazy_enabled();
-  if constexpr (C::LAZY_A) {
+  constexpr bool LAZY_BM = C::LAZY_A && C::FA::LANES == 1;   // G2 keeps one whole Fp2 element per lane here (saturated limbs)
+  if constexpr (LAZY_BM) lazy = msm_lazy_enabled();
+  if constexpr (LAZY_BM) {
     if (lazy)
       hipLaunchKernelGGL((batchmul_lazy_kernel<C>), dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, (const char*)d_table,
                          (const u32*)d_scalars, n, mont, window, outer, (char*)d_tmp);

@@ -996,10 +996,10 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
     step = sizes.back();   // the largest piece sizes the ring buffers
   } else if (taper && host_bases && n >= ((size_t)1 << 21) && !getenv("ARK_HIP_STREAM_PIECES") &&
              !(getenv("ARK_HIP_STREAM_TAPER") && getenv("ARK_HIP_STREAM_TAPER")[0] == '0')) {
-    // bases AND scalars cross PCIe (2^24 BLS12-381 G1: 2 GiB, ~40 ms of copy against 36 ms of kernels): the copy sets the
-    // pace and what the call adds to it is the LAST piece's kernels + the reduction.  Equal eighths -- every upload waits
-    // for the kernels two pieces back (two ring slots), so large middle pieces stall the copy: measured 54.4 ms with a
-    // 2,4,10,8,4,2,1,1 / 32 schedule against 47.8 ms for eighths -- with the last eighth halved down to >= 2^18 pairs.
+    // bases AND scalars cross PCIe (2^24 BLS12-381 G1: 2 GiB, ~40 ms of copy against 36 ms of kernels).  Equal eighths are
+    // the best schedule measured (47.6 ms): every upload waits for the kernels two pieces back (two ring slots), so large
+    // middle pieces stall the copy (2,4,10,8,4,2,1,1 / 32: 54.4 ms), and a halving tail (.., 4, 2, 1, 1 / 64: 48.7 ms) or
+    // sixteenths (49.4 ms) pay more per piece than the shorter last piece saves (profiles/r4_trait_modes_and_schedules_sessionB.txt).
     // ARK_HIP_STREAM_SCHEDULE="a,b,c,.." (weights) overrides for experiments.
     std::vector<size_t> wts;
     if (const char* e = getenv("ARK_HIP_STREAM_SCHEDULE")) {
@@ -1008,15 +1008,7 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
         if (*q == ',') q++;
       }
     }
-    if (wts.empty()) {
-      wts.assign(7, 8);
-      size_t tail = 8;
-      while (tail > 1 && (n / 64) * (tail / 2) >= ((size_t)1 << 18) && wts.size() < 10) {
-        tail /= 2;
-        wts.push_back(tail);
-      }
-      wts.push_back(tail);
-    }
+    if (wts.empty()) wts.assign(8, 1);
     size_t wsum = 0;
     for (size_t w : wts) wsum += w;
     size_t left = n;
@@ -2372,10 +2364,11 @@ int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64
 }
 
 int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64_t* other, uint64_t* out, size_t n) {
-  if (curve < 0 || curve > 4 || !acc || !out || kind < 2 || kind > 7) return ARK_HIP_ERR_ARG;
+  const bool lazy_kind = kind >= 12 && kind <= 15;   // the carry-free forms of kinds 2 / 3 / 4 (testops.cuh)
+  if (curve < 0 || curve > 4 || !acc || !out || kind < 2 || (kind > 7 && !lazy_kind)) return ARK_HIP_ERR_ARG;
   size_t fb = (size_t)CURVES[curve].fe_words * 8;
   size_t abytes = n * fb * (kind == 7 ? 2 : 4);
-  size_t bbytes = (kind == 2 || kind == 3) ? n * fb * 2 : (kind == 4 ? n * fb * 4 : 0);
+  size_t bbytes = (kind == 2 || kind == 3 || kind == 12 || kind == 13) ? n * fb * 2 : ((kind == 4 || kind >= 14) ? n * fb * 4 : 0);
   size_t rbytes = n * fb * (kind == 6 ? 3 : 4);
   if (bbytes && !other) return ARK_HIP_ERR_ARG;
   return run_elementwise(abytes, bbytes, rbytes, acc, bbytes ? other : nullptr, out, point_op_fn(curve), kind, n);

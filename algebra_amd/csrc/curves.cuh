@@ -44,7 +44,7 @@ struct BLS12_377_G2 {
   static constexpr int ACC_MIN_WAVES = 1;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 3;
-  static constexpr bool LAZY_A = false;
+  static constexpr bool LAZY_A = true;    // accumulate / reduction kernels on carry-free 28-bit limbs, lane pairs (fp28x2.cuh)
   typedef Fp2<BLS12_377_FQ, 5> F;
   typedef Fp2Half<BLS12_377_FQ, 5> FA;    // bucket accumulation: one Fp2 element per lane PAIR (fp.cuh)
   static constexpr bool RELAXED_A = true;
@@ -54,7 +54,7 @@ struct BLS12_381_G2 {
   static constexpr int ACC_MIN_WAVES = 1;
   static constexpr bool RELAXED = false;
   static constexpr int ID = 4;
-  static constexpr bool LAZY_A = false;
+  static constexpr bool LAZY_A = true;
   typedef Fp2<BLS12_381_FQ, 1> F;
   typedef Fp2Half<BLS12_381_FQ, 1> FA;    // bucket accumulation: one Fp2 element per lane PAIR (fp.cuh)
   static constexpr bool RELAXED_A = true;

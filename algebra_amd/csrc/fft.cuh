@@ -362,6 +362,383 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
   }
 }
 
+// ---- the same pass on carry-free 9 x 29-bit limbs (fp28.cuh with W = 29) ------------------------------------------
+// Why: the saturated Fr product is 128 v_mad_u64_u32 + 128 v_addc_co_u32 (+ moves) = 295 vector instructions; on 9 limbs
+// of 29 bits a column of 9 + 9 products fits the 64-bit accumulator: 162 multiply-adds + 44 others = 206
+// (profiles/r4_ubench_product_rate_29bit.txt: 155 against 123 G products/s at two waves per SIMD, 177 against 134 at
+// eight).  Sums are limb-wise additions, differences add a spread multiple of p (no borrow chain), and only what is never
+// multiplied -- the sum outputs -- is swept.
+//
+// Representation.  DATA keeps the reference's Montgomery residues (x R, R = 2^256) as plain integers in 9 x 29-bit limbs;
+// TWIDDLES and coset powers are stored canonical (8 x 32 bits in HBM) as w 2^261 mod p, so that the carry-free product
+// a w 2^261 / 2^261 returns data form.  2^261 / p >= 64 for the three scalar fields (LZ_RP), which is the room everything
+// below lives in:
+//   tile invariant: every element has normalised limbs (< 2^29) and a value below 3.01 p
+//   s  = x + x'                         limbs < 2^30, value < 6.02 p
+//   d  = (x - x' + 4p) w                difference semi-normalised (limbs < 3 2^29) x canonical twiddle:
+//                                       column 9 x 3 2^58 + 9 x 2^58 < 2^63.2; value < 7.01 / 64 + 1 < 1.11
+//   y0 = s0 + s1                        limbs < 2^31, value < 12.04 p -> reduce_sweep: q = estimate of floor(y0 / p) from the
+//                                       top limb, ONE pass  limb_i = y0_i + q (2^261 - p)_i + carry  -> normalised, < 3.01 p
+//   y1 = (s0 - s1 + 7p) w               limbs < 2.5 2^30: column 9 x 2.5 2^59 + 9 x 2^58 = 54 2^58 < 2^64; value < 1.21
+//   y2 = d0 + d1                        swept; value < 2.22
+//   y3 = (d0 - d1 + 2p) w               value < 1.05
+// Between passes the 9 limbs travel as 8 + 1 words (a 32-byte plane and a 4-byte plane of the ping buffer); the first
+// pass repacks the caller's canonical input, the last pass's stores end in an exact reduction to [0, p).
+template <class FP>
+struct Fft29 {
+  typedef FpL<FP> L;
+  static_assert(L::W == 29 && L::L == 9 && FP::N == 8, "laid out for the 254 / 255-bit scalar fields");
+  static_assert(FP::LZ_RP >= 64, "value bounds below assume 2^261 / p >= 64");
+  static constexpr u32 MASK = L::MASK;
+  static constexpr u32 comp(int i) { return i == 0 ? (1u << 29) - FP::LZ_KP[1][0] : MASK - FP::LZ_KP[1][i]; }   // 2^261 - p
+  static constexpr u32 PTOP = FP::LZ_KP[1][8];
+  static constexpr u32 QM = (u32)((1ull << 32) / (PTOP + 1));
+
+  ARK_DEV static L sum(const L& a, const L& b) { return L::add_lazy(a, b); }
+  // a - b + K p, limbs of b below H 2^29: never negative, limbs below (limbs of a) + (H + 1) 2^29
+  template <int K, int H>
+  ARK_DEV static L dif(const L& a, const L& b) {
+    L r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] - b.l[i] + L::template kp_spread_any<K, H>(i);
+    return r;
+  }
+  // limbs < 2^31.4, value V < 2^261 -> normalised limbs, the same residue, below 3.01 p.  q = floor(top limb / (p_top + 1))
+  // by one multiply-high never exceeds floor(V / p) and falls short of it by at most 2 (the limbs below the top one weigh
+  // < 6 units of it, the 9-bit reciprocal costs < 1); V + q (2^261 - p) = (V - q p) + q 2^261: the carry out of the top
+  // limb is q itself and is dropped.
+  ARK_DEV static L reduce_sweep(const L& v) {
+    const u32 q = __umulhi(v.l[8], QM);
+    L r;
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const u64 acc = (u64)q * comp(i) + (u64)(v.l[i] + carry);
+      r.l[i] = (u32)acc & MASK;
+      carry = (u32)(acc >> 29);
+    }
+    return r;
+  }
+  ARK_DEV static L sweep(const L& v) {   // limbs < 2^31 -> normalised, value unchanged (< 2^261)
+    L r;
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const u32 t = v.l[i] + carry;
+      r.l[i] = t & MASK;
+      carry = t >> 29;
+    }
+    r.l[8] = v.l[8] + carry;
+    return r;
+  }
+  ARK_DEV static L cond_sub_p(const L& r) {   // normalised r: r >= p ? r - p : r
+    L t;
+    int borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int d = (int)r.l[i] - (int)FP::LZ_KP[1][i] + borrow;
+      t.l[i] = (u32)d & MASK;
+      borrow = d >> 29;
+    }
+    const int top = (int)r.l[8] - (int)FP::LZ_KP[1][8] + borrow;
+    t.l[8] = (u32)top;
+    L o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = top < 0 ? r.l[i] : t.l[i];
+    return o;
+  }
+  ARK_DEV static L canon(const L& v) { return cond_sub_p(cond_sub_p(reduce_sweep(v))); }   // -> [0, p)
+  ARK_DEV static L unpack(const uint4& a, const uint4& b) {   // 8 x 32-bit words -> 9 x 29-bit limbs (the integer unchanged)
+    const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return L::unpack32(w);
+  }
+  ARK_DEV static L load_canonical(const u32* g) {
+    const uint4* q = (const uint4*)g;
+    return unpack(q[0], q[1]);
+  }
+  ARK_DEV static void pack(const L& x, uint4& a, uint4& b) {   // normalised value below 2^256 -> 8 x 32-bit words
+    u32 w[8];
+    x.pack32(w);
+    a = make_uint4(w[0], w[1], w[2], w[3]);
+    b = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+};
+
+struct FftPass29Args {
+  FftPassArgs a;
+  const u32* src9;   // 9th limbs of the source (nullptr: the source holds canonical 8-word elements -- the caller's input)
+  u32* dst9;         // 9th limbs of the destination (unused by the last pass, which stores canonical elements)
+};
+
+template <class FP>
+__global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
+                                                                 FftPass29Args pa) {
+  typedef Fft29<FP> A;
+  typedef FpL<FP> L;
+  const FftPassArgs& a = pa.a;
+  extern __shared__ uint4 lds[];
+  const int kp = a.kp, t = a.t, k = a.k;
+  const u32 E = 1u << (kp + t);
+  uint4* pl0 = lds;            // limbs 0..3
+  uint4* pl1 = lds + E;        // limbs 4..7
+  u32* pl2 = (u32*)(lds + 2 * E);   // limb 8
+  const u32 tile = blockIdx.x;
+  const int lo_shift = k - a.s0 - kp;
+  const u32 T1 = (1u << t) - 1u;
+  const u32 Q1 = (1u << kp) - 1u;
+  const u32 tid = threadIdx.x;
+  u32 mid = 0, hi_bits = 0;
+  if (!a.last) {
+    mid = tile & ((1u << (lo_shift - t)) - 1u);
+    hi_bits = tile >> (lo_shift - t);
+  }
+  auto lds_get = [&](u32 i) -> L {
+    const uint4 p = pl0[i], q = pl1[i];
+    L x;
+    x.l[0] = p.x; x.l[1] = p.y; x.l[2] = p.z; x.l[3] = p.w;
+    x.l[4] = q.x; x.l[5] = q.y; x.l[6] = q.z; x.l[7] = q.w;
+    x.l[8] = pl2[i];
+    return x;
+  };
+  auto lds_put = [&](u32 i, const L& x) {
+    pl0[i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    pl1[i] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    pl2[i] = x.l[8];
+  };
+  // ---- load tile: issue every global load, then fill LDS ----
+  {
+    uint4 v0[FFT_MAX_EPT], v1[FFT_MAX_EPT];
+    u32 v8[FFT_MAX_EPT];
+    size_t ps[FFT_MAX_EPT];
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      v8[it] = 0;
+      if (e < E) {
+        size_t pos;
+        if (!a.last) {
+          u32 q = e >> t, r = e & T1;
+          pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
+        } else {
+          u32 r = e >> kp, q = e & Q1;
+          pos = ((size_t)r << (k - t)) | ((size_t)tile << kp) | q;
+        }
+        ps[it] = pos;
+        const size_t spos = a.zskip ? (pos & (((size_t)1 << (k - a.zskip)) - 1)) : pos;
+        const uint4* g = (const uint4*)(src + spos * 8);
+        v0[it] = g[0];
+        v1[it] = g[1];
+        if (pa.src9) v8[it] = pa.src9[spos];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      if (e < E) {
+        const size_t pos = ps[it];
+        const size_t spos = a.zskip ? (pos & (((size_t)1 << (k - a.zskip)) - 1)) : pos;
+        L x;
+        if (pa.src9) {
+          x.l[0] = v0[it].x; x.l[1] = v0[it].y; x.l[2] = v0[it].z; x.l[3] = v0[it].w;
+          x.l[4] = v1[it].x; x.l[5] = v1[it].y; x.l[6] = v1[it].z; x.l[7] = v1[it].w;
+          x.l[8] = v8[it];
+        } else {
+          x = A::unpack(v0[it], v1[it]);   // canonical input: below p
+        }
+        if (a.pre_lo) {   // coset pre-scaling: x *= h^pos (tables hold h^i 2^261)
+          const L pw = L::mul(A::load_canonical(a.pre_hi + (spos >> PW_LO_BITS) * 8),
+                              A::load_canonical(a.pre_lo + (spos & ((1u << PW_LO_BITS) - 1)) * 8));   // < 1.02
+          x = L::mul(x, pw);                                                                           // < 1.02
+        }
+        if (a.zskip) {
+          const u32 blk = (u32)(pos >> (k - a.zskip));
+          const size_t ex = (spos * (size_t)bitrev32(blk, a.zskip)) & (((size_t)1 << k) - 1);
+          if (ex != 0) {
+            const size_t half = (size_t)1 << (k - 1);
+            x = L::mul(x, A::load_canonical(a.roots + (ex & (half - 1)) * 8));
+            if (ex >= half) x = L::template neg<2>(x);  // w^(n/2) = -1: 2p - x, swept (x < 1.02)
+          }
+        }
+        lds_put(e, x);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- kp butterfly stages in LDS, two at a time (the organisation of fft_pass_kernel) ----
+  int ls = 0;
+  for (; ls + 1 < kp; ls += 2) {
+    const u32 lg = 1u << (kp - 1 - ls), qt = lg >> 1;
+    const int s = a.s0 + ls;
+    const bool tail = a.last && qt == 1;   // the transform's last two stages: only w^(n/4) is not 1; outputs go to the exact reduction
+    u32 idx[FFT_MAX_EPT / 4][4];
+    uint4 wa0[FFT_MAX_EPT / 4][2], wa1[FFT_MAX_EPT / 4][2], wb[FFT_MAX_EPT / 4][2];
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
+      const u32 g = tid + it * FFT_THREADS;
+      if (g < E / 4) {
+        u32 gq, r;
+        if (!a.last) { r = g & T1; gq = g >> t; }
+        else { gq = g & ((1u << (kp - 2)) - 1u); r = g >> (kp - 2); }
+        const u32 j0 = gq & (qt - 1u);
+        const u32 q0 = ((gq & ~(qt - 1u)) << 2) | j0;
+        size_t ta0, ta1, tb;
+        if (!a.last) {
+          const size_t col = ((size_t)mid << t) | r;
+#pragma unroll
+          for (int m = 0; m < 4; m++) idx[it][m] = ((q0 + m * qt) << t) | r;
+          ta0 = ((((size_t)j0) << lo_shift) | col) << s;
+          ta1 = ((((size_t)(j0 + qt)) << lo_shift) | col) << s;
+          tb = ((((size_t)j0) << lo_shift) | col) << (s + 1);
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; m++) idx[it][m] = (r << kp) | (q0 + m * qt);
+          ta0 = (size_t)j0 << s;
+          ta1 = (size_t)(j0 + qt) << s;
+          tb = (size_t)j0 << (s + 1);
+        }
+        const uint4* g1 = (const uint4*)(a.roots + ta1 * 8);
+        wa1[it][0] = g1[0];
+        wa1[it][1] = g1[1];
+        if (!tail) {   // a trivial twiddle is multiplied like any other (roots[0] = 2^261 mod p): no divergent branch
+          const uint4* g0 = (const uint4*)(a.roots + ta0 * 8);
+          wa0[it][0] = g0[0];
+          wa0[it][1] = g0[1];
+          const uint4* g2 = (const uint4*)(a.roots + tb * 8);
+          wb[it][0] = g2[0];
+          wb[it][1] = g2[1];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
+      const u32 g = tid + it * FFT_THREADS;
+      if (g < E / 4) {
+        const L x0 = lds_get(idx[it][0]), x1 = lds_get(idx[it][1]), x2 = lds_get(idx[it][2]), x3 = lds_get(idx[it][3]);
+        // first stage, gap lg: (x0, x2) and (x1, x3)                    fft.rs:190-198 butterfly_fn_io
+        const L s0 = A::sum(x0, x2), s1 = A::sum(x1, x3);
+        const L d1 = L::mul(A::template dif<4, 1>(x1, x3), A::unpack(wa1[it][0], wa1[it][1]));
+        L y0, y1, y2, y3;
+        if (!tail) {
+          const L d0 = L::mul(A::template dif<4, 1>(x0, x2), A::unpack(wa0[it][0], wa0[it][1]));
+          const L w = A::unpack(wb[it][0], wb[it][1]);
+          // second stage, gap lg/2: (s0, s1) and (d0, d1), one twiddle for both
+          y0 = A::reduce_sweep(A::sum(s0, s1));
+          y1 = L::mul(A::template dif<7, 2>(s0, s1), w);
+          y2 = A::sweep(A::sum(d0, d1));
+          y3 = L::mul(A::template dif<2, 1>(d0, d1), w);
+        } else {
+          const L d0 = A::template dif<4, 1>(x0, x2);   // value < 7.01, limbs < 3 2^29
+          y0 = A::sum(s0, s1);                          // < 12.04
+          y1 = A::template dif<7, 2>(s0, s1);           // < 13.02, limbs < 2.5 2^30
+          y2 = A::sum(d0, d1);                          // < 8.12
+          y3 = A::template dif<2, 1>(d0, d1);           // < 9.01, limbs < 2.5 2^30
+        }
+        lds_put(idx[it][0], y0);
+        lds_put(idx[it][1], y1);
+        lds_put(idx[it][2], y2);
+        lds_put(idx[it][3], y3);
+      }
+    }
+    __syncthreads();
+  }
+  for (; ls < kp; ls++) {
+    const u32 lg = 1u << (kp - 1 - ls);
+    const int s = a.s0 + ls;
+    const bool tail = a.last && lg == 1;   // the transform's last stage: every twiddle is 1
+    u32 i0s[FFT_MAX_EPT / 2], i1s[FFT_MAX_EPT / 2];
+    uint4 w0[FFT_MAX_EPT / 2], w1[FFT_MAX_EPT / 2];
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 2; it++) {
+      u32 b = tid + it * FFT_THREADS;
+      if (b < E / 2) {
+        u32 i0, i1;
+        size_t tw;
+        if (!a.last) {
+          u32 r = b & T1, qq = b >> t;
+          u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
+          i0 = (q << t) | r;
+          i1 = i0 + (lg << t);
+          tw = ((((size_t)(q & (lg - 1))) << lo_shift) | ((size_t)mid << t) | r) << s;
+        } else {
+          u32 qq = b & ((1u << (kp - 1)) - 1u), r = b >> (kp - 1);
+          u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
+          i0 = (r << kp) | q;
+          i1 = i0 + lg;
+          tw = ((size_t)(q & (lg - 1))) << s;
+        }
+        i0s[it] = i0;
+        i1s[it] = i1;
+        if (!tail) {
+          const uint4* g = (const uint4*)(a.roots + tw * 8);
+          w0[it] = g[0];
+          w1[it] = g[1];
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT / 2; it++) {
+      u32 b = tid + it * FFT_THREADS;
+      if (b < E / 2) {
+        const u32 i0 = i0s[it], i1 = i1s[it];
+        const L lo = lds_get(i0), hi = lds_get(i1);
+        L sm = A::sum(lo, hi), df = A::template dif<4, 1>(lo, hi);   // < 6.02 / < 7.01
+        if (!tail) {
+          sm = A::reduce_sweep(sm);
+          df = L::mul(df, A::unpack(w0[it], w1[it]));
+        }
+        lds_put(i0, sm);
+        lds_put(i1, df);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- store tile ----
+  if (!a.last) {
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      if (e < E) {
+        u32 q = e >> t, r = e & T1;
+        size_t pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
+        uint4* g = (uint4*)(dst + pos * 8);
+        g[0] = pl0[e];
+        g[1] = pl1[e];
+        pa.dst9[pos] = pl2[e];
+      }
+    }
+  } else {
+    // position p = r<<(k-t) | tile<<kp | q holds X[bitrev_k(p)]  (replaces derange(), fft.rs:373-380)
+    const int tb = k - kp - t;
+    const size_t tile_rev = bitrev32(tile, tb);
+#pragma unroll
+    for (int it = 0; it < FFT_MAX_EPT; it++) {
+      u32 e = tid + it * FFT_THREADS;
+      if (e < E) {
+        u32 r2 = e & T1, q2 = e >> t;  // output-side coordinates
+        size_t opos = ((size_t)q2 << (k - kp)) | (tile_rev << t) | r2;
+        u32 i = (bitrev32(r2, t) << kp) | bitrev32(q2, kp);
+        L x = lds_get(i);   // the tail stages' raw outputs: limbs < 2.5 2^30, value < 13.02 p
+        if (a.post_lo || a.post_const) {
+          L pw;
+          if (a.post_lo)
+            pw = L::mul(A::load_canonical(a.post_hi + (opos >> PW_LO_BITS) * 8),
+                        A::load_canonical(a.post_lo + (opos & ((1u << PW_LO_BITS) - 1)) * 8));   // < 1.02
+          else
+            pw = A::load_canonical(a.post_const);
+          x = A::cond_sub_p(L::mul(x, pw));   // column 9 x 2.5 2^59 + 9 x 2^58 < 2^64; value < 13.02 * 1.02 / 64 + 1 < 1.21
+        } else {
+          x = A::canon(x);
+        }
+        uint4 o0, o1;
+        A::pack(x, o0, o1);
+        uint4* g = (uint4*)(dst + opos * 8);
+        g[0] = o0;
+        g[1] = o1;
+      }
+    }
+  }
+}
+
 // ---- G-point transform along the slow axis of a [G][cols] array (multi-GPU exchange step) ----------------
 // out[j][c] = sum_i root^(i j) in[i][c], natural order in and out, G in {2,4,8,16}.  One lane per column: the G
 // values travel through registers (radix-2 decimation in frequency, then a bit-reversed write-back).

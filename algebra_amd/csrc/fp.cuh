@@ -767,6 +767,7 @@ struct Fp2Half {
   static constexpr int BYTES = B::BYTES;           // bytes this lane holds
   static constexpr int FULL_BYTES = 2 * B::BYTES;  // bytes of the whole element in memory (c0 | c1)
   static constexpr int LANES = 2;
+  static constexpr int NEG_BETA_ = NEG_BETA;
   static constexpr bool FUSED_Y3 = true;
   B v;
 

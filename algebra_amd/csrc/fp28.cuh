@@ -422,25 +422,27 @@ struct FpL {
     for (int i = 0; i < L; i++) r.l[i] = a.l[i] - b.l[i] + kp_spread<K, 1>(i);
     return r;
   }
+  // a - b + K p swept to normalised limbs (a's limbs below 3 2^W, b normalised): an unsigned sweep, the spread limbs of K p
+  // cannot go negative
+  template <int K>
+  ARK_HD static FpL sub_sweep(const FpL& a, const FpL& b) {
+    FpL r;
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+      const u32 v = a.l[i] - b.l[i] + kp_spread_any<K, 1>(i) + carry;
+      r.l[i] = v & MASK;
+      carry = v >> W;
+    }
+    r.l[L - 1] = a.l[L - 1] - b.l[L - 1] + kp_spread_any<K, 1>(L - 1) + carry;
+    return r;
+  }
   // a - b + K p as an operand that may meet ANOTHER semi-normalised operand in a product (a square of it, R t in Y3):
-  // semi-normalised where the limb width leaves room for that (SEMI2: 14 x 28 bits), otherwise swept to normalised
-  // limbs (9 x 29 bits) -- an unsigned sweep, the spread limbs cannot go negative
+  // semi-normalised where the limb width leaves room for that (SEMI2: 14 x 28 bits), otherwise swept (9 x 29 bits)
   template <int K>
   ARK_HD static FpL sub_op(const FpL& a, const FpL& b) {
-    if constexpr (SEMI2) {
-      return sub_semi<K>(a, b);
-    } else {
-      FpL r;
-      u32 carry = 0;
-#pragma unroll
-      for (int i = 0; i < L - 1; i++) {
-        const u32 v = a.l[i] - b.l[i] + kp_spread<K, 1>(i) + carry;
-        r.l[i] = v & MASK;
-        carry = v >> W;
-      }
-      r.l[L - 1] = a.l[L - 1] - b.l[L - 1] + kp_spread<K, 1>(L - 1) + carry;
-      return r;
-    }
+    if constexpr (SEMI2) return sub_semi<K>(a, b);
+    else return sub_sweep<K>(a, b);
   }
   // limb i of k p for ANY k with k p < 2^(W L) (the LZ_KP table stops at 8): compile-time arithmetic on LZ_KP[1]
   static constexpr u32 kp_limb(int k, int i) {

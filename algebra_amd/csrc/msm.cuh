@@ -31,6 +31,7 @@
 #include <math.h>
 #include "curves.cuh"
 #include "ec28.cuh"
+#include "lazyk.cuh"
 #include "msm_sort.cuh"
 
 namespace arkhip {
@@ -401,23 +402,17 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_lazy_k
                                                                   const u32* __restrict__ order, u32 nbuckets,
                                                                   const u32* __restrict__ d_thresh, int HB, int LB,
                                                                   int accum, char* __restrict__ buckets) {
-  typedef typename C::F F;
-  typedef typename F::P P;
-  typedef FpL<P> FL;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef LazyK<C> K;            // prime-field curves: one lane per bucket; G2: one lane PAIR (uniform control flow)
+  typedef typename K::FM F;
+  u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / K::LANES;
   if (t >= nbuckets) return;
   u32 g = order ? order[t] : t;
   u32 j = offsets[g], end = offsets[g + 1];
   if (end - j > *d_thresh) return;  // left to the heavy-bucket kernels
   if (accum && j == end) return;    // nothing to add to the stored sum
   char* cell = buckets + (size_t)msm_slot_to_bucket(g, HB, LB) * XYZZ<F>::BYTES;
-  XYZZL<P> acc;
-  if (accum) {
-    acc = lazy_from_bucket<P>(XYZZ<F>::load(cell));
-  } else {
-    acc.inf = true;
-    acc.x = acc.y = acc.zz = acc.zzz = FL::zero();
-  }
+  typename K::Acc acc = K::inf();
+  if (accum) acc = K::from_bucket(XYZZ<F>::load(cell));
   if (j < end) {
     u32 e = sorted[j];
     u32 e1 = j + 1 < end ? sorted[j + 1] : 0;
@@ -431,11 +426,9 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_lazy_k
         if (j + 2 < end) e2 = sorted[j + 2];
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
-        FL lx, ly;
-        lazy_from_affine<P>(p.x, F::cond_neg(p.y, (e >> 31) != 0), lx, ly);  // negative digit: -P
-        if (xyzz_madd_lazy<P>(acc, lx, ly)) {  // the base equals the accumulated point (duplicate bases): doubling
-          XYZZL<P> dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
-          xyzz_mdbl_lazy<P>(dbl, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
+        if (K::madd(acc, p, (e >> 31) != 0)) {  // the base equals the accumulated point (duplicate bases): doubling
+          typename K::Acc dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
+          K::mdbl(dbl, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
           acc = dbl;
         }
       }
@@ -446,7 +439,7 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_lazy_k
       j++;
     }
   }
-  lazy_to_bucket<P>(acc).store(cell);
+  K::to_bucket(acc).store(cell);
 }
 
 template <class C>
@@ -454,16 +447,13 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_shared
     const char* __restrict__ table, size_t wstride, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
     const u32* __restrict__ order, u32 nbuckets, int W, int B, const u32* __restrict__ d_thresh, int HB, int LB,
     char* __restrict__ buckets) {
-  typedef typename C::F F;
-  typedef typename F::P P;
-  typedef FpL<P> FL;
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  typedef LazyK<C> K;
+  typedef typename K::FM F;
+  u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / K::LANES;
   if (t >= nbuckets) return;
   const u32 s = order ? order[t] : t;
   const u32 heavy_thresh = *d_thresh;
-  XYZZL<P> acc;
-  acc.inf = true;
-  acc.x = acc.y = acc.zz = acc.zzz = FL::zero();
+  typename K::Acc acc = K::inf();
   int w = 0;
   u32 na = offsets[s], nb2 = offsets[s + 1];
   u32 j = 0, end = 0;
@@ -510,11 +500,9 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_shared
         have2 = next_entry(e2, wb2);
       }
       if (!p.is_zero()) {
-        FL lx, ly;
-        lazy_from_affine<P>(p.x, F::cond_neg(p.y, (e >> 31) != 0), lx, ly);  // negative digit: -P
-        if (xyzz_madd_lazy<P>(acc, lx, ly)) {  // the base equals the accumulated point (duplicate bases): doubling
-          XYZZL<P> dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
-          xyzz_mdbl_lazy<P>(dbl, wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
+        if (K::madd(acc, p, (e >> 31) != 0)) {  // the base equals the accumulated point (duplicate bases): doubling
+          typename K::Acc dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
+          K::mdbl(dbl, wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
           acc = dbl;
         }
       }
@@ -526,7 +514,7 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_shared
       have1 = have2;
     }
   }
-  lazy_to_bucket<P>(acc).store(buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * XYZZ<F>::BYTES);
+  K::to_bucket(acc).store(buckets + (size_t)msm_slot_to_bucket(s, HB, LB) * XYZZ<F>::BYTES);
 }
 
 // ---- K4s: bucket accumulation over a PREPARED base set ---------------------------------------------
@@ -723,59 +711,26 @@ struct AccOps<C, false> {
 
 template <class C>
 struct AccOps<C, true> {
-  typedef typename C::F F;       // Fp<P>: the Fp384 G1 curves
-  typedef typename F::P P;
-  typedef FpL<P> FL;
+  typedef LazyK<C> K;            // carry-free limbs: ec28.cuh (one lane per point) or ec28x2.cuh (G2: one lane pair)
+  typedef typename K::FM F;
   typedef XYZZ<F> Pt;
-  typedef XYZZL<P> Acc;
-  static constexpr u32 LANES = 1;
-  static constexpr size_t ACC_BYTES = ((4 * FL::L + 1) * 4 + 15) / 16 * 16;   // 4 x 14 limbs + the infinity flag: 240 B
-  ARK_DEV static Acc zero() {
-    Acc a;
-    a.inf = true;
-    a.x = a.y = a.zz = a.zzz = FL::zero();
-    return a;
-  }
-  ARK_DEV static Acc from_pt(const Pt& p) { return lazy_from_bucket<P>(p); }
+  typedef typename K::Acc Acc;
+  static constexpr u32 LANES = K::LANES;
+  static constexpr size_t ACC_BYTES = ((size_t)K::WORDS * 4 + 15) / 16 * 16;   // G1: 4 x 14 limbs + flag = 240 B; G2: 464 B per pair
+  ARK_DEV static Acc zero() { return K::inf(); }
+  ARK_DEV static Acc from_pt(const Pt& p) { return K::from_bucket(p); }
   ARK_DEV static void madd(Acc& acc, const F& x, const F& y) {   // (x, y): a non-identity base, the digit's sign in y
-    FL lx, ly;
-    lazy_from_affine<P>(x, y, lx, ly);
-    if (xyzz_madd_lazy<P>(acc, lx, ly)) {   // equal points
-      Acc d;
-      xyzz_mdbl_lazy_xy<P>(d, lx, ly);
+    const Affine<F> p{x, y};
+    if (K::madd(acc, p, false)) {   // equal points: the doubling of the base, through its canonical coordinates (rare)
+      const Acc d = K::from_bucket(xyzz_mdbl<F>(x, y));
       acc = d;
     }
   }
-  ARK_DEV static void add(Acc& acc, const Pt& b) {
-    const XYZZOperands<P> o = lazy_operands_of<P>(b);
-    xyzz_add_lazy<P>(acc, o.x, o.y, o.zz, o.zzz, o.inf);
-  }
-  ARK_DEV static void add_acc(Acc& acc, const Acc& b) { xyzz_add_lazy<P>(acc, b.x, b.y, b.zz, b.zzz, b.inf); }
-  ARK_DEV static Pt fin(const Acc& a) { return lazy_to_bucket<P>(a); }
-  ARK_DEV static void park(const Acc& a, char* slot) {
-    u32* w = (u32*)slot;
-#pragma unroll
-    for (int i = 0; i < FL::L; i++) {
-      w[i] = a.x.l[i];
-      w[FL::L + i] = a.y.l[i];
-      w[2 * FL::L + i] = a.zz.l[i];
-      w[3 * FL::L + i] = a.zzz.l[i];
-    }
-    w[4 * FL::L] = a.inf ? 1u : 0u;
-  }
-  ARK_DEV static Acc unpark(const char* slot) {
-    const u32* w = (const u32*)slot;
-    Acc a;
-#pragma unroll
-    for (int i = 0; i < FL::L; i++) {
-      a.x.l[i] = w[i];
-      a.y.l[i] = w[FL::L + i];
-      a.zz.l[i] = w[2 * FL::L + i];
-      a.zzz.l[i] = w[3 * FL::L + i];
-    }
-    a.inf = w[4 * FL::L] != 0u;
-    return a;
-  }
+  ARK_DEV static void add(Acc& acc, const Pt& b) { K::add(acc, b); }
+  ARK_DEV static void add_acc(Acc& acc, const Acc& b) { K::add_acc(acc, b); }
+  ARK_DEV static Pt fin(const Acc& a) { return K::to_bucket(a); }
+  ARK_DEV static void park(const Acc& a, char* slot) { K::park(a, slot); }
+  ARK_DEV static Acc unpark(const char* slot) { return K::unpark(slot); }
   ARK_DEV static void tree(Acc& acc, char* sh, u32 slot, u32 width) {
     park(acc, sh + (size_t)slot * ACC_BYTES);
     __syncthreads();
@@ -799,7 +754,7 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
                                                                 const uint2* __restrict__ items, size_t wstride, int B,
                                                                 char* __restrict__ partials) {
   typedef AccOps<C> Ops;
-  typedef typename Ops::F F;
+  typedef typename Ops::F F;           // the field as it lives in memory (Fp, or the lane-pair Fp2Half)
   typedef typename Ops::Pt Pt;
   constexpr u32 NS = 64 / Ops::LANES;  // slots per wave
   extern __shared__ uint4 heavy_lds[];
@@ -914,8 +869,10 @@ __global__ void __launch_bounds__(64) msm_apply_heavy_kernel(const u32* __restri
 // Per window the buckets X[0..mwin) carry weights 1..mwin.  A slot folds the chunk of L consecutive buckets
 // [tL, (t+1)L) with a running sum:  S_t = sum_r X[tL+r],  A_t = sum_r (r+1) X[tL+r], so that
 //   sum_k k B_k = sum_t A_t + L * sum_t t S_t          (parallel form of mod.rs:478-484)
+// (two waves per SIMD for the one-lane-per-point curves; the lane-pair G2 form keeps two accumulators of 112 limbs and an
+// addition's temporaries per lane: one wave per SIMD, its overflow in AGPRs instead of scratch memory)
 template <class C>
-__global__ void __launch_bounds__(128, 2) msm_reduce_level_kernel(const char* __restrict__ in, u32 L, u32 total_out,
+__global__ void __launch_bounds__(128, (C::LAZY_A && C::FA::LANES == 2) ? 1 : 2) msm_reduce_level_kernel(const char* __restrict__ in, u32 L, u32 total_out,
                                                                char* __restrict__ outS, char* __restrict__ outA) {
   typedef AccOps<C> Ops;
   typedef typename Ops::Pt Pt;
@@ -1518,7 +1475,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     if (pl.shared) {
       if constexpr (C::LAZY_A) {
         if (lazy)
-          hipLaunchKernelGGL((msm_accumulate_shared_lazy_kernel<C>), dim3((u32)((nbk + 255) / 256)), dim3(256), 0, st,
+          hipLaunchKernelGGL((msm_accumulate_shared_lazy_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
                              (const char*)d_points, wstride, G.sorted, G.offsets, G.order, (u32)nbk, W, Bbits,
                              (const u32*)G.hctr + 2, HB, LB, G.buckets);
       }
@@ -1531,7 +1488,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     } else {
       if constexpr (C::LAZY_A) {
         if (lazy)
-          hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((G.nslots + 255) / 256)), dim3(256), 0, st,
+          hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((G.nslots * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
                              (const char*)d_points, G.sorted, G.offsets, G.order, (u32)G.nslots, (const u32*)G.hctr + 2, HB, LB,
                              accum, G.buckets);
       }

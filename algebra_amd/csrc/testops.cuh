@@ -3,6 +3,7 @@
 #pragma once
 #include "curves.cuh"
 #include "fp28.cuh"
+#include "lazyk.cuh"
 
 namespace arkhip {
 
@@ -158,9 +159,50 @@ int sw_normalize_batch_launch(const void* in, void* out, size_t n, hipStream_t s
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// kinds 12..15: the additions of the accumulate / reduction kernels in their carry-free form (LazyK: one lane per point, or
+// one lane PAIR over Fp2), stored bucket in -> stored bucket out:
+//   12 / 13  acc +/- affine (the mixed addition; equal points double the base)      14  acc += stored bucket (repacked
+//   operand)      15  acc += accumulator (both sides small)
+template <class C>
+__global__ void __launch_bounds__(128) test_lazy_point_op_kernel(int kind, const char* __restrict__ acc_in,
+                                                                 const char* __restrict__ other, char* __restrict__ out,
+                                                                 size_t n) {
+  typedef LazyK<C> K;
+  typedef typename K::FM F;
+  typedef XYZZ<F> Pt;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / K::LANES;
+  if (i >= n) return;
+  typename K::Acc acc = K::from_bucket(Pt::load(acc_in + i * Pt::BYTES));
+  if (kind == 12 || kind == 13) {
+    const char* src = other + i * Affine<F>::BYTES;
+    const Affine<F> p = Affine<F>::load(src);
+    if (!p.is_zero()) {
+      if (K::madd(acc, p, kind == 13)) {
+        typename K::Acc d;
+        K::mdbl(d, src, kind == 13);
+        acc = d;
+      }
+    }
+  } else if (kind == 14) {
+    K::add(acc, Pt::load(other + i * Pt::BYTES));
+  } else {
+    const typename K::Acc o = K::from_bucket(Pt::load(other + i * Pt::BYTES));
+    K::add_acc(acc, o);
+  }
+  K::to_bucket(acc).store(out + i * Pt::BYTES);
+}
+
 template <class C>
 int test_point_op_launch(int kind, const void* acc, const void* other, void* out, size_t n, hipStream_t s) {
   if (n == 0) return 0;
+  if (kind >= 12 && kind <= 15) {
+    if constexpr (C::LAZY_A) {
+      hipLaunchKernelGGL((test_lazy_point_op_kernel<C>), dim3((unsigned)((n * LazyK<C>::LANES + 127) / 128)), dim3(128), 0, s, kind,
+                         (const char*)acc, (const char*)other, (char*)out, n);
+      return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    return -1;
+  }
   hipLaunchKernelGGL((test_point_op_kernel<C>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, kind,
                      (const char*)acc, (const char*)other, (char*)out, n);
   return hipGetLastError() == hipSuccess ? 0 : -1000;

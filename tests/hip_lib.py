@@ -9,7 +9,8 @@ from algebra_amd._lib import check, lib
 
 OPS = dict(add=0, sub=1, mul=2, sqr=3, neg=4, dbl=5, into_bigint=7, from_bigint=8,
            lazy_mul=20, lazy_sqr=21, lazy_sop2=22)   # the 28-bit-limb device forms (csrc/testops.cuh)
-PKIND = dict(bkt_add_aff=2, bkt_sub_aff=3, bkt_add_bkt=4, bkt_double=5, bkt_to_jac=6, aff_double_to_bkt=7)
+PKIND = dict(bkt_add_aff=2, bkt_sub_aff=3, bkt_add_bkt=4, bkt_double=5, bkt_to_jac=6, aff_double_to_bkt=7,
+             lazy_add_aff=12, lazy_sub_aff=13, lazy_add_bkt=14, lazy_add_acc=15)   # carry-free forms (LazyK, testops.cuh)
 
 
 def _p(a):

@@ -81,6 +81,12 @@ def _norm(cid, xyzz):
     return np.stack(out)
 
 
+def _canonical(cid, xyzz):
+    """every coordinate reduced once more by the oracle (x + 0): unchanged exactly when it already was canonical."""
+    flat = np.ascontiguousarray(xyzz, dtype=np.uint64).reshape(-1)
+    return O.basefield_op(cid, "add", flat, np.zeros_like(flat)).reshape(xyzz.shape)
+
+
 @pytest.mark.parametrize("cname", O.CURVES)
 def test_point_ops_match_oracle(cname):
     cid = O.CID[cname]
@@ -115,6 +121,11 @@ def test_point_ops_match_oracle(cname):
         got = H.point_op(cid, kind, bk, other)
         exp = np.stack([O.point_op(cid, kind, bk[i], other[i]) for i in range(n)])
         assert np.array_equal(_norm(cid, got), _norm(cid, exp)), (cname, kind)
+        # the same addition as the accumulate kernels run it: carry-free limbs (14 x 28 / 9 x 29 bits; G2: one lane pair
+        # per point), stored bucket in -> stored (canonical) bucket out, doubling and infinity branches included
+        lz = H.point_op(cid, kind.replace("bkt_", "lazy_"), bk, other)
+        assert np.array_equal(_norm(cid, lz), _norm(cid, exp)), (cname, kind, "lazy")
+        assert np.array_equal(lz.reshape(n, 4, fw)[:, :, :], _canonical(cid, lz).reshape(n, 4, fw)), (cname, kind, "canonical limbs")
     # bucket + bucket, including equal operands and the identity
     ob = bk[::-1].copy()
     ob[3] = bk[3]
@@ -122,6 +133,12 @@ def test_point_ops_match_oracle(cname):
     got = H.point_op(cid, "bkt_add_bkt", bk, ob)
     exp = np.stack([O.point_op(cid, "bkt_add_bkt", bk[i], ob[i]) for i in range(n)])
     assert np.array_equal(_norm(cid, got), _norm(cid, exp)), (cname, "bkt_add_bkt")
+    ob[7] = bk[7].copy()                                        # inverse operands: infinity
+    ob[7][fw:2 * fw] = O.basefield_op(cid, "neg", bk[7][fw:2 * fw])
+    exp = np.stack([O.point_op(cid, "bkt_add_bkt", bk[i], ob[i]) for i in range(n)])
+    for kind in ("lazy_add_bkt", "lazy_add_acc"):               # the reduction / heavy-run kernels' full addition
+        lz = H.point_op(cid, kind, bk, ob)
+        assert np.array_equal(_norm(cid, lz), _norm(cid, exp)), (cname, kind)
     got = H.point_op(cid, "bkt_double", bk)
     exp = np.stack([O.point_op(cid, "bkt_double", bk[i]) for i in range(n)])
     assert np.array_equal(_norm(cid, got), _norm(cid, exp)), (cname, "bkt_double")

@@ -66,14 +66,22 @@ def test_headline_2_24_prepared_base_set(headline):
 
 
 def test_headline_2_24_host_pointer_entry(headline):
-    """ark_hip_msm_sw from pageable host memory: streamed (default), pinned first call and repeat, Montgomery scalars."""
+    """ark_hip_msm_sw from pageable host memory: cache off (bases + scalars streamed), default settings (miss, then a hit
+    validated by the full-content hash of 1.5 GiB), pinned first call and repeat, Montgomery scalars."""
     h = headline
     cid, n = h["cid"], h["n"]
     host_bases = h["bases"].cpu().numpy().view(np.uint64).reshape(n, -1)
+    A.base_cache_config(0, -1)
     s0 = A.base_cache_stats()
     assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, host_bases, h["sc"])), h["kg"])
     s1 = A.base_cache_stats()
     assert s1["entries"] == 0 and s1["pinned"] == 0 and s1["pinned_hits"] == s0["pinned_hits"]   # nothing retained
+    A.base_cache_config(-2, -1)                                  # the default: verified cache
+    for _ in range(2):
+        assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, host_bases, h["sc"])), h["kg"])
+    s2 = A.base_cache_stats()
+    assert s2["misses"] - s1["misses"] == 1 and s2["hits"] - s1["hits"] == 1 and s2["bytes"] >= host_bases.nbytes
+    A.base_cache_clear()
     with A.pin_bases(cid, host_bases):
         for _ in range(2):
             assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, host_bases, h["sc"])), h["kg"])
