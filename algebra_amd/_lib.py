@@ -100,6 +100,8 @@ SYMBOLS = {
     "ark_hip_fft_in_place_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p]),
     "ark_hip_ifft_in_place_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p]),
     "ark_hip_fr_mul_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_poly_mul": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "ark_hip_sw_normalize_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ark_hip_fr_pow": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ark_hip_fft_axis_device": (C.c_int, [C.c_int, C.c_void_p, C.c_uint, C.c_size_t, C.c_void_p]),
     "ark_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -112,6 +114,7 @@ SYMBOLS = {
     "ark_hip_fft_sharded_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_int]),
     "ark_hip_fft_shard_local_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "ark_hip_fft_shard_cross_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "ark_hip_fft_set_kernel": (C.c_int, [C.c_int]),
     "ark_hip_fft_set_timing": (C.c_int, [C.c_int]),
     "ark_hip_fft_last_timing": (C.c_int, [C.POINTER(C.c_double)]),
     "ark_hip_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

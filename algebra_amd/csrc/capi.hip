@@ -2096,6 +2096,70 @@ int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r
   return mark_producer(sc.c);
 }
 
+// `&DensePolynomial * &DensePolynomial` (poly/src/polynomial/univariate/dense.rs:641-656): zero if either factor is zero;
+// otherwise evaluate both over the radix-2 domain of size >= na + nb - 1 (evaluate_over_domain_by_ref, univariate/mod.rs:
+// 305-360), multiply the evaluations pointwise (Evaluations *=) and interpolate (evaluations/univariate/mod.rs:40-50).
+// HOST pointers in and out; in between everything stays on the device: ONE upload of the two coefficient vectors (the zero
+// padding is written on the device -- or never read: degree-aware transforms), the two forward transforms in flight
+// together, the pointwise product, the inverse transform, ONE download of the na + nb - 1 coefficients.
+// out: room for na + nb - 1 elements; *out_len: the product's coefficient count with leading zeros dropped, as
+// DensePolynomial::from_coefficients_vec leaves it (0: the zero polynomial).  ARK_HIP_ERR_ARG when the field's 2-adicity
+// cannot hold the domain (the reference panics: "field is not smooth enough to construct domain").
+int ark_hip_poly_mul(int field, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t* out_len) {
+  if (!out_len || (na && !a) || (nb && !b)) return ARK_HIP_ERR_ARG;
+  *out_len = 0;
+  auto all_zero = [](const uint64_t* p, size_t n) {
+    for (size_t i = 0; i < 4 * n; i++)
+      if (p[i]) return false;
+    return true;
+  };
+  if (na == 0 || nb == 0 || all_zero(a, na) || all_zero(b, nb)) return 0;   // DensePolynomial::is_zero
+  if (!out) return ARK_HIP_ERR_ARG;
+  const size_t len = na + nb - 1;
+  ark_hip_radix2_domain dom;
+  if (int rc = ark_hip_radix2_domain_new(field, len, &dom)) return rc;
+  const size_t n = (size_t)dom.size;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  if (c->stage_a.cap < n * 32 || c->stage_b.cap < n * 32) {
+    if (int rc = sync_compute(c)) return rc;
+    if (c->stage_a.ensure(n * 32) || c->stage_b.ensure(n * 32)) return ARK_HIP_ERR_NOMEM;
+  }
+  if (int rc = c->stager.upload(c->stage_a.p, a, na * 32, c->stream)) return rc;
+  if (int rc = c->stager.upload(c->stage_b.p, b, nb * 32, c->stream)) return rc;
+  // forward transforms: short inputs take the degree-aware path (their padding is never read beyond the next power of
+  // two); the two run on two streams (ark_hip_fft_batch_in_place_device's arrangement)
+  auto pad = [&](void* d, size_t have) -> int {
+    const int zlog = degree_aware_zlog(&dom, have);
+    const size_t upto = n >> zlog;
+    if (upto > have) ARK_HIP_TRY(hipMemsetAsync((char*)d + have * 32, 0, (upto - have) * 32, c->stream));
+    return zlog;
+  };
+  const int za = pad(c->stage_a.p, na), zb = pad(c->stage_b.p, nb);
+  if (za < 0 || zb < 0) return za < 0 ? za : zb;
+  if (!c->fft_ev[0])
+    for (int j = 0; j < 3; j++) ARK_HIP_TRY(hipEventCreateWithFlags(&c->fft_ev[j], hipEventDisableTiming));
+  if (!c->fft_side[0]) ARK_HIP_TRY(hipStreamCreateWithFlags(&c->fft_side[0], hipStreamNonBlocking));
+  ARK_HIP_TRY(hipEventRecord(c->fft_ev[0], c->stream));
+  ARK_HIP_TRY(hipStreamWaitEvent(c->fft_side[0], c->fft_ev[0], 0));
+  int rc = fft_any(c, field, &dom, c->stage_a.p, 0, za, c->stream);
+  if (rc == 0) rc = fft_any(c, field, &dom, c->stage_b.p, 0, zb, c->fft_side[0]);
+  (void)hipEventRecord(c->fft_ev[1], c->fft_side[0]);
+  (void)hipStreamWaitEvent(c->stream, c->fft_ev[1], 0);
+  if (rc == 0) rc = fr_mul_dispatch(field, c->stage_a.p, c->stage_b.p, c->stage_a.p, n, c->stream);
+  if (rc == 0) rc = fft_any(c, field, &dom, c->stage_a.p, 1, 0, c->stream);
+  if (rc) {
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+  }
+  ARK_HIP_TRY(hipMemcpyAsync(out, c->stage_a.p, len * 32, hipMemcpyDeviceToHost, c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  size_t top = len;   // truncate_leading_zeros (dense.rs)
+  while (top > 0 && !(out[4 * top - 1] | out[4 * top - 2] | out[4 * top - 3] | out[4 * top - 4])) top--;
+  *out_len = top;
+  return 0;
+}
+
 // out = base^exp in Fr (host arithmetic): domain elements / twiddles for hosts without field code of their own
 int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out) {
   if (!base || !out) return ARK_HIP_ERR_ARG;
@@ -2117,6 +2181,14 @@ int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, co
   return mark_producer(sc.c);
 }
 
+// 0: the saturated pass kernel (default), 1: the carry-free 9 x 29-bit pass kernel, -1: back to the environment's choice
+int ark_hip_fft_set_kernel(int variant) {
+  if (variant < -1 || variant > 1) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  std::lock_guard<std::mutex> lock(sc.c->fft.mu);
+  sc.c->fft.kernel_variant = variant;
+  return 0;
+}
 int ark_hip_fft_set_timing(int enable) {
   ARK_SCOPE(sc);
   sc.c->fft_timing = enable != 0;
@@ -2327,6 +2399,25 @@ int ark_hip_sw_normalize_batch_device(int curve, const void* d_jac, void* d_out_
   int rc = normalize_dispatch(curve, d_jac, d_out_xy, n, sc.c->stream);
   if (rc) return rc;
   ARK_HIP_TRY(hipStreamSynchronize(sc.c->stream));
+  return 0;
+}
+
+// The same from HOST memory (what the Rust hook behind CurveGroup::normalize_batch hands over, group.rs:302-319): one
+// upload of the n Projective points, the lane-batched inversion kernel, one download of the n Affine points.
+int ark_hip_sw_normalize_batch(int curve, const uint64_t* jac_points, size_t n, uint64_t* out_xy) {
+  if (curve < 0 || curve > 4 || (n && (!jac_points || !out_xy))) return ARK_HIP_ERR_ARG;
+  if (n == 0) return 0;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  const size_t fb = (size_t)CURVES[curve].fe_words * 8;
+  if (c->stage_a.cap < n * 3 * fb || c->stage_b.cap < n * 2 * fb) {
+    if (int rc = sync_compute(c)) return rc;
+    if (c->stage_a.ensure(n * 3 * fb) || c->stage_b.ensure(n * 2 * fb)) return ARK_HIP_ERR_NOMEM;
+  }
+  if (int rc = c->stager.upload(c->stage_a.p, jac_points, n * 3 * fb, c->stream)) return rc;
+  if (int rc = normalize_dispatch(curve, c->stage_a.p, c->stage_b.p, n, c->stream)) return rc;
+  ARK_HIP_TRY(hipMemcpyAsync(out_xy, c->stage_b.p, n * 2 * fb, hipMemcpyDeviceToHost, c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -394,10 +394,10 @@ struct Fft29 {
   static constexpr u32 PTOP = FP::LZ_KP[1][8];
   static constexpr u32 QM = (u32)((1ull << 32) / (PTOP + 1));
 
-  ARK_DEV static L sum(const L& a, const L& b) { return L::add_lazy(a, b); }
+  ARK_HD static L sum(const L& a, const L& b) { return L::add_lazy(a, b); }
   // a - b + K p, limbs of b below H 2^29: never negative, limbs below (limbs of a) + (H + 1) 2^29
   template <int K, int H>
-  ARK_DEV static L dif(const L& a, const L& b) {
+  ARK_HD static L dif(const L& a, const L& b) {
     L r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = a.l[i] - b.l[i] + L::template kp_spread_any<K, H>(i);
@@ -407,8 +407,8 @@ struct Fft29 {
   // by one multiply-high never exceeds floor(V / p) and falls short of it by at most 2 (the limbs below the top one weigh
   // < 6 units of it, the 9-bit reciprocal costs < 1); V + q (2^261 - p) = (V - q p) + q 2^261: the carry out of the top
   // limb is q itself and is dropped.
-  ARK_DEV static L reduce_sweep(const L& v) {
-    const u32 q = __umulhi(v.l[8], QM);
+  ARK_HD static L reduce_sweep(const L& v) {
+    const u32 q = (u32)(((u64)v.l[8] * QM) >> 32);
     L r;
     u32 carry = 0;
 #pragma unroll
@@ -419,7 +419,7 @@ struct Fft29 {
     }
     return r;
   }
-  ARK_DEV static L sweep(const L& v) {   // limbs < 2^31 -> normalised, value unchanged (< 2^261)
+  ARK_HD static L sweep(const L& v) {   // limbs < 2^31 -> normalised, value unchanged (< 2^261)
     L r;
     u32 carry = 0;
 #pragma unroll
@@ -431,7 +431,7 @@ struct Fft29 {
     r.l[8] = v.l[8] + carry;
     return r;
   }
-  ARK_DEV static L cond_sub_p(const L& r) {   // normalised r: r >= p ? r - p : r
+  ARK_HD static L cond_sub_p(const L& r) {   // normalised r: r >= p ? r - p : r
     L t;
     int borrow = 0;
 #pragma unroll
@@ -447,16 +447,28 @@ struct Fft29 {
     for (int i = 0; i < 9; i++) o.l[i] = top < 0 ? r.l[i] : t.l[i];
     return o;
   }
-  ARK_DEV static L canon(const L& v) { return cond_sub_p(cond_sub_p(reduce_sweep(v))); }   // -> [0, p)
-  ARK_DEV static L unpack(const uint4& a, const uint4& b) {   // 8 x 32-bit words -> 9 x 29-bit limbs (the integer unchanged)
+  ARK_HD static L canon(const L& v) { return cond_sub_p(cond_sub_p(reduce_sweep(v))); }   // -> [0, p)
+  ARK_HD static L unpack(const uint4& a, const uint4& b) {   // 8 x 32-bit words -> 9 x 29-bit limbs (the integer unchanged)
     const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     return L::unpack32(w);
   }
-  ARK_DEV static L load_canonical(const u32* g) {
+  ARK_HD static L limbs9(const uint4& a, const uint4& b, u32 top) {   // a twiddle as fetched: canonical 8 words, or (A/B
+#if ARK_FFT29_UNPACKED_TW                                                // build) an entry of the unpacked table
+    L x;
+    x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w;
+    x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w;
+    x.l[8] = top;
+    return x;
+#else
+    (void)top;
+    return unpack(a, b);
+#endif
+  }
+  ARK_HD static L load_canonical(const u32* g) {
     const uint4* q = (const uint4*)g;
     return unpack(q[0], q[1]);
   }
-  ARK_DEV static void pack(const L& x, uint4& a, uint4& b) {   // normalised value below 2^256 -> 8 x 32-bit words
+  ARK_HD static void pack(const L& x, uint4& a, uint4& b) {   // normalised value below 2^256 -> 8 x 32-bit words
     u32 w[8];
     x.pack32(w);
     a = make_uint4(w[0], w[1], w[2], w[3]);
@@ -466,12 +478,27 @@ struct Fft29 {
 
 struct FftPass29Args {
   FftPassArgs a;
+  const u32* roots9; // the twiddle table is stored UNPACKED: a.roots holds limbs 0..7 of w^j 2^261 mod p, roots9 limb 8
+                     // (the per-butterfly repack of a canonical entry cost 22 instructions x 3 twiddles per 4-point group)
   const u32* src9;   // 9th limbs of the source (nullptr: the source holds canonical 8-word elements -- the caller's input)
   u32* dst9;         // 9th limbs of the destination (unused by the last pass, which stores canonical elements)
 };
 
+#ifndef ARK_FFT29_FENCE
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ARK_FFT29_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define ARK_FFT29_FENCE
+#endif
+#endif
+#ifndef ARK_FFT29_MIN_WAVES
+#define ARK_FFT29_MIN_WAVES 1   // waves per SIMD the register allocation must leave room for (A/B builds)
+#endif
+#ifndef ARK_FFT29_UNPACKED_TW
+#define ARK_FFT29_UNPACKED_TW 0 // 1: twiddle table stored as 8 + 1 words of 29-bit limbs (A/B builds; measured slower: the 4-byte
+#endif                          // gathers of the ninth limbs double the twiddle traffic -- profiles/r4_fft_carry_free_ab.txt)
 template <class FP>
-__global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
+__global__ void __launch_bounds__(FFT_THREADS, ARK_FFT29_MIN_WAVES) fft_pass29_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
                                                                  FftPass29Args pa) {
   typedef Fft29<FP> A;
   typedef FpL<FP> L;
@@ -555,7 +582,9 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __re
           const size_t ex = (spos * (size_t)bitrev32(blk, a.zskip)) & (((size_t)1 << k) - 1);
           if (ex != 0) {
             const size_t half = (size_t)1 << (k - 1);
-            x = L::mul(x, A::load_canonical(a.roots + (ex & (half - 1)) * 8));
+            const size_t ri = ex & (half - 1);
+            const uint4* rg = (const uint4*)(a.roots + ri * 8);
+            x = L::mul(x, A::limbs9(rg[0], rg[1], ARK_FFT29_UNPACKED_TW ? pa.roots9[ri] : 0u));
             if (ex >= half) x = L::template neg<2>(x);  // w^(n/2) = -1: 2p - x, swept (x < 1.02)
           }
         }
@@ -572,6 +601,7 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __re
     const bool tail = a.last && qt == 1;   // the transform's last two stages: only w^(n/4) is not 1; outputs go to the exact reduction
     u32 idx[FFT_MAX_EPT / 4][4];
     uint4 wa0[FFT_MAX_EPT / 4][2], wa1[FFT_MAX_EPT / 4][2], wb[FFT_MAX_EPT / 4][2];
+    u32 wa0t[FFT_MAX_EPT / 4], wa1t[FFT_MAX_EPT / 4], wbt[FFT_MAX_EPT / 4];
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
       const u32 g = tid + it * FFT_THREADS;
@@ -599,13 +629,16 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __re
         const uint4* g1 = (const uint4*)(a.roots + ta1 * 8);
         wa1[it][0] = g1[0];
         wa1[it][1] = g1[1];
+        wa1t[it] = ARK_FFT29_UNPACKED_TW ? pa.roots9[ta1] : 0u;
         if (!tail) {   // a trivial twiddle is multiplied like any other (roots[0] = 2^261 mod p): no divergent branch
           const uint4* g0 = (const uint4*)(a.roots + ta0 * 8);
           wa0[it][0] = g0[0];
           wa0[it][1] = g0[1];
+          wa0t[it] = ARK_FFT29_UNPACKED_TW ? pa.roots9[ta0] : 0u;
           const uint4* g2 = (const uint4*)(a.roots + tb * 8);
           wb[it][0] = g2[0];
           wb[it][1] = g2[1];
+          wbt[it] = ARK_FFT29_UNPACKED_TW ? pa.roots9[tb] : 0u;
         }
       }
     }
@@ -613,21 +646,36 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __re
     for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
       const u32 g = tid + it * FFT_THREADS;
       if (g < E / 4) {
-        const L x0 = lds_get(idx[it][0]), x1 = lds_get(idx[it][1]), x2 = lds_get(idx[it][2]), x3 = lds_get(idx[it][3]);
         // first stage, gap lg: (x0, x2) and (x1, x3)                    fft.rs:190-198 butterfly_fn_io
-        const L s0 = A::sum(x0, x2), s1 = A::sum(x1, x3);
-        const L d1 = L::mul(A::template dif<4, 1>(x1, x3), A::unpack(wa1[it][0], wa1[it][1]));
+        // (the pairs are read, summed and differenced one after the other -- ARK_FFT29_FENCE keeps the scheduler from hoisting
+        // all four elements and three unpacked twiddles into registers at once)
+        L s0, s1, e0, e1;
+        {
+          const L x0 = lds_get(idx[it][0]), x2 = lds_get(idx[it][2]);
+          s0 = A::sum(x0, x2);
+          e0 = A::template dif<4, 1>(x0, x2);
+        }
+        ARK_FFT29_FENCE;
+        {
+          const L x1 = lds_get(idx[it][1]), x3 = lds_get(idx[it][3]);
+          s1 = A::sum(x1, x3);
+          e1 = A::template dif<4, 1>(x1, x3);
+        }
+        ARK_FFT29_FENCE;
+        const L d1 = L::mul(e1, A::limbs9(wa1[it][0], wa1[it][1], wa1t[it]));
+        ARK_FFT29_FENCE;
         L y0, y1, y2, y3;
         if (!tail) {
-          const L d0 = L::mul(A::template dif<4, 1>(x0, x2), A::unpack(wa0[it][0], wa0[it][1]));
-          const L w = A::unpack(wb[it][0], wb[it][1]);
+          const L d0 = L::mul(e0, A::limbs9(wa0[it][0], wa0[it][1], wa0t[it]));
+          ARK_FFT29_FENCE;
+          const L w = A::limbs9(wb[it][0], wb[it][1], wbt[it]);
           // second stage, gap lg/2: (s0, s1) and (d0, d1), one twiddle for both
           y0 = A::reduce_sweep(A::sum(s0, s1));
           y1 = L::mul(A::template dif<7, 2>(s0, s1), w);
           y2 = A::sweep(A::sum(d0, d1));
           y3 = L::mul(A::template dif<2, 1>(d0, d1), w);
         } else {
-          const L d0 = A::template dif<4, 1>(x0, x2);   // value < 7.01, limbs < 3 2^29
+          const L d0 = e0;                              // value < 7.01, limbs < 3 2^29
           y0 = A::sum(s0, s1);                          // < 12.04
           y1 = A::template dif<7, 2>(s0, s1);           // < 13.02, limbs < 2.5 2^30
           y2 = A::sum(d0, d1);                          // < 8.12
@@ -647,6 +695,7 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __re
     const bool tail = a.last && lg == 1;   // the transform's last stage: every twiddle is 1
     u32 i0s[FFT_MAX_EPT / 2], i1s[FFT_MAX_EPT / 2];
     uint4 w0[FFT_MAX_EPT / 2], w1[FFT_MAX_EPT / 2];
+    u32 w8[FFT_MAX_EPT / 2];
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT / 2; it++) {
       u32 b = tid + it * FFT_THREADS;
@@ -672,6 +721,7 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __re
           const uint4* g = (const uint4*)(a.roots + tw * 8);
           w0[it] = g[0];
           w1[it] = g[1];
+          w8[it] = ARK_FFT29_UNPACKED_TW ? pa.roots9[tw] : 0u;
         }
       }
     }
@@ -684,7 +734,7 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass29_kernel(const u32* __re
         L sm = A::sum(lo, hi), df = A::template dif<4, 1>(lo, hi);   // < 6.02 / < 7.01
         if (!tail) {
           sm = A::reduce_sweep(sm);
-          df = L::mul(df, A::unpack(w0[it], w1[it]));
+          df = L::mul(df, A::limbs9(w0[it], w1[it], w8[it]));
         }
         lds_put(i0, sm);
         lds_put(i1, df);
@@ -781,15 +831,29 @@ __global__ void __launch_bounds__(256) fft_axis_kernel(const u32* src, u32* dst,
 
 // ---- host side: cached twiddle tables + pass plan ------------------------------------------------
 struct FftTables {
-  DevBuf roots;   // n/2 entries
+  DevBuf roots;   // n/2 entries (form 1: limbs 0..7 of the unpacked 9 x 29-bit entries)
+  DevBuf roots9;  // form 1: limb 8 of every entry
   DevBuf small;   // scratch for the two-level build + generator copy
 };
+// canonical 8-word entries -> 9 x 29-bit limbs, in place for limbs 0..7 (+ the 9th-limb plane)
+template <class FP>
+__global__ void __launch_bounds__(256) fft_unpack_table_kernel(u32* __restrict__ tab, size_t count, u32* __restrict__ tab9) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  const FpL<FP> x = Fft29<FP>::load_canonical(tab + j * 8);
+  uint4* g = (uint4*)(tab + j * 8);
+  g[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+  g[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+  tab9[j] = x.l[8];
+}
 struct FftKey {
   int field, k;
   std::array<uint64_t, 4> gen;
+  int form = 0;   // 0: w^j R (the saturated kernel's operands); 1: w^j 2^261 (the carry-free kernel's)
   bool operator<(const FftKey& o) const {
     if (field != o.field) return field < o.field;
     if (k != o.k) return k < o.k;
+    if (form != o.form) return form < o.form;
     return gen < o.gen;
   }
 };
@@ -799,9 +863,11 @@ struct FftKey {
 struct FftPwKey {
   int field, k;                      // k = -1: a single constant
   std::array<uint64_t, 4> base, mul; // mul = 0: none
+  int form = 0;                      // as FftKey::form
   bool operator<(const FftPwKey& o) const {
     if (field != o.field) return field < o.field;
     if (k != o.k) return k < o.k;
+    if (form != o.form) return form < o.form;
     if (base != o.base) return base < o.base;
     return mul < o.mul;
   }
@@ -815,9 +881,10 @@ struct FftWorkspace {
   uint64_t axis_root[4] = {0, 0, 0, 0};
   DevBuf stage;                        // host-pointer entry: device copy of the data
   hipEvent_t ev[10] = {};              // pass timing (created on first use, reused)
+  int kernel_variant = -1;             // -1: environment (ARK_HIP_FFT_LAZY), 0: saturated pass kernel, 1: carry-free
   std::mutex mu;
   void release() {
-    for (auto& kv : tables) { kv.second.roots.release(); kv.second.small.release(); }
+    for (auto& kv : tables) { kv.second.roots.release(); kv.second.roots9.release(); kv.second.small.release(); }
     tables.clear();
     for (auto& kv : powers) kv.second.release();
     powers.clear();
@@ -827,6 +894,10 @@ struct FftWorkspace {
     for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   }
 };
+static inline bool fft_lazy_env() {
+  static const bool v = getenv("ARK_HIP_FFT_LAZY") && getenv("ARK_HIP_FFT_LAZY")[0] == '1';
+  return v;
+}
 struct FftTimings { float total = 0; float pass[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int npass = 0; };
 
 // root^k, k < G/2, for fft_axis_launch: built into the workspace's own small buffer (stream-ordered; `root4` is host
@@ -880,44 +951,59 @@ int fft_axis_run(FftWorkspace& ws, const void* d_src, void* d_dst, unsigned G, s
 }
 
 
+// form29: entries w^j 2^261 mod p instead of w^j R -- the whole table (or its `hi` factor) starts from the Montgomery residue
+// of 2^5, whose integer is 2^261 mod p (FP::LZ_CIN)
 template <class FP>
-int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t stream, const u32** out) {
+int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t stream, const u32** out, bool form29 = false,
+                  const u32** out9 = nullptr) {
   typedef Fp<FP> F;
-  FftKey key{FP::ID, k, {root4[0], root4[1], root4[2], root4[3]}};
+  FftKey key{FP::ID, k, {root4[0], root4[1], root4[2], root4[3]}, form29 ? 1 : 0};
   auto it = ws.tables.find(key);
-  if (it != ws.tables.end()) { *out = (const u32*)it->second.roots.p; return 0; }
+  if (it != ws.tables.end()) {
+    *out = (const u32*)it->second.roots.p;
+    if (out9) *out9 = (const u32*)it->second.roots9.p;
+    return 0;
+  }
   FftTables tb;  // built here, entered into the cache only once complete (a failed build must not leave a null table)
   struct Guard {
     FftTables* t;
-    ~Guard() { if (t) { t->roots.release(); t->small.release(); } }
+    ~Guard() { if (t) { t->roots.release(); t->roots9.release(); t->small.release(); } }
   } guard{&tb};
   size_t half = k >= 1 ? ((size_t)1 << (k - 1)) : 1;
   if (tb.roots.ensure(half * F::BYTES)) return -3;
+  if (form29 && ARK_FFT29_UNPACKED_TW && tb.roots9.ensure(half * 4)) return -3;
   const int LB = 11;
   size_t nlo = half < ((size_t)1 << LB) ? half : ((size_t)1 << LB);
   size_t nhi = half >> LB; if (nhi == 0) nhi = 1;
-  if (tb.small.ensure((1 + nlo + nhi) * F::BYTES)) return -3;
+  if (tb.small.ensure((2 + nlo + nhi) * F::BYTES)) return -3;
   u32* d_gen = (u32*)tb.small.p;
-  u32* d_lo = d_gen + F::N;
+  u32* d_cin = d_gen + F::N;
+  u32* d_lo = d_cin + F::N;
   u32* d_hi = d_lo + nlo * F::N;
   ARK_HIP_TRY(hipMemcpyAsync(d_gen, root4, F::BYTES, hipMemcpyHostToDevice, stream));
+  ARK_HIP_TRY(hipMemcpyAsync(d_cin, FP::LZ_CIN, F::BYTES, hipMemcpyHostToDevice, stream));
+  const u32* scale = form29 ? (const u32*)d_cin : (const u32*)nullptr;
   if (half <= ((size_t)1 << LB)) {
     hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, d_gen, (u64)1,
-                       (u32)half, (const u32*)nullptr, (u32*)tb.roots.p);
+                       (u32)half, scale, (u32*)tb.roots.p);
   } else {
     hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nlo + 255) / 256)), dim3(256), 0, stream, d_gen, (u64)1,
                        (u32)nlo, (const u32*)nullptr, d_lo);
     hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nhi + 255) / 256)), dim3(256), 0, stream, d_gen,
-                       (u64)1 << LB, (u32)nhi, (const u32*)nullptr, d_hi);
+                       (u64)1 << LB, (u32)nhi, scale, d_hi);
     hipLaunchKernelGGL((fft_expand_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, d_lo, d_hi,
                        LB, half, (u32*)tb.roots.p);
   }
+  if (form29 && ARK_FFT29_UNPACKED_TW)
+    hipLaunchKernelGGL((fft_unpack_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, (u32*)tb.roots.p,
+                       half, (u32*)tb.roots9.p);
   ARK_HIP_TRY(hipGetLastError());
   ARK_HIP_TRY(hipStreamSynchronize(stream));  // root4 is a caller stack pointer
   FftTables& slot = ws.tables[key];
   slot = tb;          // DevBuf is a plain handle: ownership moves to the cache
   guard.t = nullptr;
   *out = (const u32*)slot.roots.p;
+  if (out9) *out9 = (const u32*)slot.roots9.p;
   return 0;
 }
 
@@ -934,11 +1020,13 @@ static inline int fft_powers_make_room(FftWorkspace& ws) {
 
 // lo/hi power tables of `base4` for a size-2^k transform (hi optionally multiplied by `mul4`), or -- k < 0 -- the single
 // constant `base4`, resident and cached.  base4 / mul4 are host pointers.
+// form29: BOTH factors carry 2^261 instead of R (the carry-free kernel multiplies them with its own product, which divides
+// by 2^261 once), and so does a single constant.
 template <class FP>
 int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_t* mul4, hipStream_t stream,
-                   const u32** lo, const u32** hi) {
+                   const u32** lo, const u32** hi, bool form29 = false) {
   typedef Fp<FP> F;
-  FftPwKey key{FP::ID, k, {base4[0], base4[1], base4[2], base4[3]}, {0, 0, 0, 0}};
+  FftPwKey key{FP::ID, k, {base4[0], base4[1], base4[2], base4[3]}, {0, 0, 0, 0}, form29 ? 1 : 0};
   if (mul4) key.mul = {mul4[0], mul4[1], mul4[2], mul4[3]};
   auto it = ws.powers.find(key);
   if (it == ws.powers.end()) {
@@ -949,16 +1037,35 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
       DevBuf* b;
       ~Guard() { if (b) b->release(); }
     } guard{&buf};
-    if (buf.ensure((nlo + nhi + 2) * F::BYTES)) return -3;
+    if (buf.ensure((nlo + nhi + 3) * F::BYTES)) return -3;
     u32* base = (u32*)buf.p;
-    u32* d_c = base + (nlo + nhi) * F::N;  // [base | mul]
-    ARK_HIP_TRY(hipMemcpyAsync(d_c, base4, F::BYTES, hipMemcpyHostToDevice, stream));
-    if (mul4) ARK_HIP_TRY(hipMemcpyAsync(d_c + F::N, mul4, F::BYTES, hipMemcpyHostToDevice, stream));
+    u32* d_c = base + (nlo + nhi) * F::N;  // [base | mul | 2^261 mod p]
+    // host-side scaling of the hi factor / the constant: m 2^261 = mont_mul(m R, 2^261 mod p)
+    uint64_t hi_mul[4], cin[4];
+    memcpy(cin, FP::LZ_CIN, 32);
+    const uint64_t* hi_mul_p = mul4;
+    if (form29) {
+      const F c = F::load(cin);
+      const F m = mul4 ? F::mul(F::load(mul4), c) : c;
+      m.store(hi_mul);
+      hi_mul_p = hi_mul;
+    }
+    if (k < 0 && form29) {
+      const F v = F::mul(F::load(base4), F::load(cin));
+      uint64_t tmpc[4];
+      v.store(tmpc);
+      ARK_HIP_TRY(hipMemcpyAsync(d_c, tmpc, F::BYTES, hipMemcpyHostToDevice, stream));
+      ARK_HIP_TRY(hipStreamSynchronize(stream));  // tmpc is a stack array
+    } else {
+      ARK_HIP_TRY(hipMemcpyAsync(d_c, base4, F::BYTES, hipMemcpyHostToDevice, stream));
+    }
+    if (hi_mul_p) ARK_HIP_TRY(hipMemcpyAsync(d_c + F::N, hi_mul_p, F::BYTES, hipMemcpyHostToDevice, stream));
+    ARK_HIP_TRY(hipMemcpyAsync(d_c + 2 * F::N, FP::LZ_CIN, F::BYTES, hipMemcpyHostToDevice, stream));
     if (k >= 0) {
       hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)(nlo / 256)), dim3(256), 0, stream, d_c, (u64)1, (u32)nlo,
-                         (const u32*)nullptr, base);
+                         form29 ? (const u32*)(d_c + 2 * F::N) : (const u32*)nullptr, base);
       hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nhi + 255) / 256)), dim3(256), 0, stream, d_c, (u64)nlo,
-                         (u32)nhi, mul4 ? (const u32*)(d_c + F::N) : (const u32*)nullptr, base + nlo * F::N);
+                         (u32)nhi, hi_mul_p ? (const u32*)(d_c + F::N) : (const u32*)nullptr, base + nlo * F::N);
       ARK_HIP_TRY(hipGetLastError());
     }
     ARK_HIP_TRY(hipStreamSynchronize(stream));  // base4 / mul4 are caller memory
@@ -989,23 +1096,29 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
   std::lock_guard<std::mutex> lock(ws.mu);
   if (k < 0 || k > 30 || k > FP::TWO_ADICITY) return -2;
   const size_t n = (size_t)1 << k;
+  // which pass kernel: saturated 32-bit limbs (default) or carry-free 9 x 29-bit limbs (ARK_HIP_FFT_LAZY=1 /
+  // ark_hip_fft_set_kernel(1)).  The carry-free product is 27 % faster in a loop, the carry-free PASS is not: 18.6 % fewer
+  // vector instructions, but 148 registers (three waves per SIMD instead of four), the vector ALU busy 76 % of the time
+  // instead of 90 % -- 0.53-0.56 against 0.52-0.53 ms at 2^22 (profiles/r4_fft_carry_free_ab.txt).  Kept, tested, not default.
+  const bool lazy29 = ws.kernel_variant < 0 ? fft_lazy_env() : ws.kernel_variant == 1;
   const u32* roots = nullptr;
+  const u32* roots9 = nullptr;
   if (k >= 1) {
-    int rc = fft_get_roots<FP>(ws, k, root4, stream, &roots);
+    int rc = fft_get_roots<FP>(ws, k, root4, stream, &roots, lazy29, &roots9);
     if (rc) return rc;
   }
   // coset scaling tables (cached per offset): x[i] *= h^i on the way in; out[i] *= postc * h^-i on the way out
   if (int rc = fft_powers_make_room(ws)) return rc;
   const u32 *pre_lo = nullptr, *pre_hi = nullptr, *post_lo = nullptr, *post_hi = nullptr, *post_const = nullptr;
   if (pre4) {
-    int rc = fft_get_powers<FP>(ws, k, pre4, nullptr, stream, &pre_lo, &pre_hi);
+    int rc = fft_get_powers<FP>(ws, k, pre4, nullptr, stream, &pre_lo, &pre_hi, lazy29);
     if (rc) return rc;
   }
   if (post4) {
-    int rc = fft_get_powers<FP>(ws, k, post4, postc4, stream, &post_lo, &post_hi);
+    int rc = fft_get_powers<FP>(ws, k, post4, postc4, stream, &post_lo, &post_hi, lazy29);
     if (rc) return rc;
   } else if (postc4) {
-    int rc = fft_get_powers<FP>(ws, -1, postc4, nullptr, stream, &post_const, nullptr);
+    int rc = fft_get_powers<FP>(ws, -1, postc4, nullptr, stream, &post_const, nullptr, lazy29);
     if (rc) return rc;
   }
   if (k == 0) {
@@ -1051,10 +1164,12 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
   }
   u32* data = (u32*)d_data;
   u32* tmp = nullptr;
+  u32* tmp9 = nullptr;   // carry-free passes: the 9th limbs of the ping buffer's elements (a 4-byte plane behind the 32-byte one)
   if (P > 1 || zlog) {
     DevBuf& tb = ws.tmps[stream];
-    if (tb.ensure(n * F::BYTES)) return -3;
+    if (tb.ensure(n * (F::BYTES + 4))) return -3;
     tmp = (u32*)tb.p;
+    tmp9 = tmp + n * F::N;
   }
   int s0 = zlog;
   for (int i = 0; i < P; i++) {
@@ -1084,8 +1199,21 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     else if (i == P - 1) { src = tmp; dst = data; }
     else { src = tmp; dst = tmp; }
     u32 tiles = (u32)(n >> (kps[i] + ti));
-    size_t lds_bytes = ((size_t)2 << (kps[i] + ti)) * sizeof(uint4);
-    hipLaunchKernelGGL((fft_pass_kernel<FP>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, a);
+    if (lazy29) {
+      FftPass29Args pa;
+      pa.a = a;
+      pa.roots9 = roots9;
+      pa.src9 = src == tmp ? tmp9 : nullptr;    // the caller's buffer holds canonical elements, the ping buffer 9 limbs
+      pa.dst9 = dst == tmp ? tmp9 : nullptr;
+      if (P == 1 && zlog) {   // single pass into the ping buffer: canonical out (it is the last pass), copied back below
+        pa.dst9 = nullptr;
+      }
+      const size_t lds_bytes = ((size_t)1 << (kps[i] + ti)) * 36;
+      hipLaunchKernelGGL((fft_pass29_kernel<FP>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, pa);
+    } else {
+      size_t lds_bytes = ((size_t)2 << (kps[i] + ti)) * sizeof(uint4);
+      hipLaunchKernelGGL((fft_pass_kernel<FP>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, a);
+    }
     if (tm) ARK_HIP_TRY(hipEventRecord(ev[nev++], stream));
     s0 += kps[i];
   }

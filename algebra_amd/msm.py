@@ -520,10 +520,16 @@ def msm_u64(curve, bases, scalars):
 
 
 def normalize_batch(curve, points):
-    """CurveGroup::normalize_batch (group.rs:302-319) on the device: Projective points (CUDA tensor, 3*fe_words u64
-    per point) -> Affine points (CUDA tensor of the same dtype)."""
-    import torch
+    """CurveGroup::normalize_batch (group.rs:302-319) on the device: Projective points (CUDA tensor or numpy array,
+    3*fe_words u64 per point) -> Affine points (same kind)."""
     cid = cv.curve_id(curve)
+    if not _is_torch(points):   # host array: the entry the Rust hook behind CurveGroup::normalize_batch binds
+        p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, cv.projective_words(cid))
+        out = np.zeros((p.shape[0], cv.affine_words(cid)), dtype=np.uint64)
+        check(lib().ark_hip_sw_normalize_batch(cid, p.ctypes.data_as(C.c_void_p), p.shape[0], out.ctypes.data_as(C.c_void_p)),
+              "ark_hip_sw_normalize_batch")
+        return out
+    import torch
     assert points.is_cuda and points.is_contiguous()
     n = points.numel() * points.element_size() // (8 * cv.projective_words(cid))
     out = torch.empty(n * cv.affine_words(cid) * 8 // points.element_size(), dtype=points.dtype, device=points.device)

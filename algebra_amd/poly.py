@@ -11,6 +11,20 @@ from ._lib import check, lib
 from .domain import Radix2EvaluationDomain
 
 
+def poly_mul_host(field, a, b):
+    """`&a * &b` through the ONE host-pointer C entry the Rust hook binds (ark_hip_poly_mul: one upload, the three
+    transforms and the pointwise product on the device, one download).  numpy in, numpy out (leading zeros dropped)."""
+    fid = cv.field_id(field)
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    cap = max(a.shape[0] + b.shape[0] - 1, 1)
+    out = np.zeros((cap, 4), dtype=np.uint64)
+    out_len = C.c_size_t(0)
+    check(lib().ark_hip_poly_mul(fid, a.ctypes.data_as(C.c_void_p), a.shape[0], b.ctypes.data_as(C.c_void_p), b.shape[0],
+                                 out.ctypes.data_as(C.c_void_p), C.byref(out_len)), "ark_hip_poly_mul")
+    return out[: out_len.value]
+
+
 def poly_mul(field, a, b):
     """Coefficients of a*b (numpy uint64 [len, 4], Montgomery Fr).  Zero polynomial (empty input) -> empty."""
     import torch

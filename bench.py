@@ -42,9 +42,16 @@ FIELD = "BLS12_381_FR"
 R_MOD = S.R[FIELD]  # bls12_381 fr.rs:4-5
 A0, B0 = S.A0, S.B0
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# hardware-anchored multiply bound: v_mad_u64_u32 issues at 27.73e12 lane-ops/s on this chip
-# (profiles/r1_ubench_instruction_rates.txt, line 1); a Montgomery Fp384 product needs 2 * 12^2 = 288 of them
-MAD_U64_U32_PER_S = 27.73e12
+# hardware-anchored multiply bound: the BEST issue rate of v_mad_u64_u32 measured on this chip -- 34.96e12 lane-ops/s, four
+# independent chains per lane at eight waves per SIMD (profiles/r3_issue_rates.txt); the same loop at the accumulate
+# kernel's two waves per SIMD issues 26.6e12/s (same file), reported beside it as a second, labelled figure.  No figure is
+# quoted against a loop the kernel beats.
+MAD_U64_U32_PER_S = 34.96e12
+MAD_U64_U32_PER_S_TWO_WAVES = 26.6e12
+# Fr products: the carry-free 9 x 29-bit product back to back in a loop, best measured rate (eight waves per SIMD) and the
+# rate at two waves (profiles/r4_ubench_product_rate_29bit.txt, BLS12-381 Fr)
+FR_PRODUCTS_PER_S = {"carry-free": 177.2e9, "saturated": 135.7e9}
+FR_PRODUCTS_PER_S_TWO_WAVES = {"carry-free": 154.5e9, "saturated": 121.5e9}
 # multiply-adds per mixed addition.  Saturated 32-bit limbs (ec.cuh): 8 products of 2 * 12^2 + one sum of two products
 # under a single reduction (3 * 12^2), each followed by a carry instruction.  Carry-free 28-bit limbs (ec28.cuh, the
 # default for the Fp384 G1 curves): 6 products of 2 * 14^2, 2 squares of 105 + 14^2, one two-product sum of 3 * 14^2.
@@ -84,7 +91,7 @@ def pmc_traffic(kernel, log_n):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json,
     produced by tools/pmc_traffic.py on this same command; FETCH_SIZE / WRITE_SIZE collected in separate passes,
     corrected as MI355X_MICROARCH.md prescribes).  None when no matching measurement is committed."""
-    for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -176,6 +183,15 @@ def main():
 
     if world == 1:
         exchange = "none (one GPU)"
+    else:
+        # what RCCL itself saw: the library communicator's rank / world and the RCCL build
+        cr, cw = C.c_int(-1), C.c_int(-1)
+        L.ark_hip_comm_info(C.byref(cr), C.byref(cw))
+        try:
+            nv = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            nv = "unknown"
+        exchange += "; library communicator rank %d of %d; RCCL %s" % (cr.value, cw.value, nv)
     log_local = args.log_n if args.log_n is not None else LOG_PER_GPU
     n = 1 << log_local                      # pairs on this GPU
     n_total = n * world                     # pairs of the one MSM
@@ -289,29 +305,49 @@ def main():
     if extras and world == 1:
         try:
             hb = bases.cpu().numpy().view(np.uint64).reshape(n, -1)   # ordinary (pageable) host memory, like a Rust Vec
+
+            def timed_calls(reps):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    res = A.msm_bigint(cid, hb, scalars_h)
+                return (time.perf_counter() - t0) * 1e3 / reps, res
+
+            ok_all = True
+            A.base_cache_config(0, 0)                                  # nothing retained: bases + scalars streamed
+            A.msm_bigint(cid, hb, scalars_h)                           # (ring buffers allocated)
+            off_ms, res = timed_calls(3)
+            ok_all &= bool(np.array_equal(A.into_affine(cid, res), want))
+            A.base_cache_config(-2, 0)                                 # the default: verified cache
             A.base_cache_clear()
             s0 = A.base_cache_stats()
-            t0 = time.perf_counter()
-            r_first = A.msm_bigint(cid, hb, scalars_h)
-            first_ms = (time.perf_counter() - t0) * 1e3
-            reps = 4
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                r_rep = A.msm_bigint(cid, hb, scalars_h)
-            rep_ms = (time.perf_counter() - t0) * 1e3 / reps
+            first_ms, res = timed_calls(1)
+            ok_all &= bool(np.array_equal(A.into_affine(cid, res), want))
+            rep_ms, res = timed_calls(4)
+            ok_all &= bool(np.array_equal(A.into_affine(cid, res), want))
             s1 = A.base_cache_stats()
+            A.base_cache_clear()
+            with A.pin_bases(cid, hb):
+                A.msm_bigint(cid, hb, scalars_h)
+                pin_ms, res = timed_calls(4)
+            ok_all &= bool(np.array_equal(A.into_affine(cid, res), want))
             trait = {"what": "ark_hip_msm_sw(host bases, host scalars): the call behind SWCurveConfig::msm / the msm_bigint "
-                             "hook; PCIe-inclusive, pageable host memory; repeat calls hit the resident-base cache and "
-                             "upload only the 2^%d x 32 B of scalars, streamed in pieces" % log_local,
+                             "hook; PCIe-inclusive, pageable host memory.  DEFAULT settings = the verified resident-base "
+                             "cache: a repeat call works from the device copy while 8 host threads hash the full 2^%d x 96 B "
+                             "slice, and returns only if the hash matches (an edited slice is re-uploaded and the MSM rerun); "
+                             "`cache_off`: bases + scalars streamed on every call, nothing retained; `pinned`: "
+                             "ark_hip_msm_bases_pin (the Rust ResidentBases guard), no host pass at all" % log_local,
                      "first_call_ms": first_ms, "repeat_call_ms": rep_ms, "repeat_value": n / (rep_ms * 1e-3),
+                     "cache_off_call_ms": off_ms, "pinned_repeat_call_ms": pin_ms,
                      "host_bytes_first_call": int(hb.nbytes + scalars_h.nbytes), "host_bytes_repeat_call": int(scalars_h.nbytes),
                      "cache": {k: s1[k] - s0[k] for k in ("hits", "misses", "refreshed", "evicted")},
-                     "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, r_first), want)
-                                             and np.array_equal(A.into_affine(cid, r_rep), want))}
-            A.base_cache_clear()
+                     "bit_exact_vs_kG": ok_all}
             del hb
         except Exception as e:  # noqa: BLE001
             trait = {"error": repr(e)[:200]}
+            try:
+                A.base_cache_config(-2, 0)
+            except Exception:  # noqa: BLE001
+                pass
 
     # ---- BASELINE config 4: ONE 2^26 MSM split over the ranks (strong scaling; N = 1: the whole job on one GPU) ----
     config4 = None
@@ -385,27 +421,43 @@ def main():
                 others["%s MSM 2^%d" % (cname, lg)] = {"error": repr(e)[:200]}
 
     # ---- FFT leg (rank 0's GPU; the FFT config is single-GPU) ---------------------------------------
+    # the reference's bench shapes (poly/benches/fft.rs:71-152): in-place FFT, IFFT and their coset variants on Vec<Fr>
     fft = None
     if rank == 0 and args.fft_steps > 0:
         kf = args.fft_log_n
         nf = 1 << kf
         dom = A.Radix2EvaluationDomain.new(FIELD, nf)
-        x = torch.from_numpy(gen_scalars(nf, 7).view(np.int64)).cuda()  # canonical < r is a valid Montgomery residue too
+        seven = np.array(S.limbs4(7 * (1 << 256) % R_MOD), dtype=np.uint64)   # Fr::GENERATOR, Montgomery form (fft.rs:107)
+        cos = dom.get_coset(seven)
+        x_h = gen_scalars(nf, 7)                                        # canonical < r is a valid Montgomery residue too
+        x = torch.from_numpy(x_h.view(np.int64)).cuda()
         y = x.clone()
         torch.cuda.synchronize()
         fwd = L.ark_hip_fft_in_place_device
         inv = L.ark_hip_ifft_in_place_device
-        sref = C.byref(dom._s)
+        sref, cref = C.byref(dom._s), C.byref(cos._s)
         for _ in range(2):
             check(fwd(dom.field, sref, y.data_ptr()), "fft")
             check(inv(dom.field, sref, y.data_ptr()), "ifft")
         check(L.ark_hip_synchronize(), "sync")
         roundtrip_ok = bool(torch.equal(x, y))
-        e0 = time.perf_counter()
-        for _ in range(args.fft_steps):
-            check(fwd(dom.field, sref, y.data_ptr()), "fft")
+        for _ in range(2):
+            check(fwd(cos.field, cref, y.data_ptr()), "coset fft")
+            check(inv(cos.field, cref, y.data_ptr()), "coset ifft")
         check(L.ark_hip_synchronize(), "sync")
-        fft_ms = (time.perf_counter() - e0) * 1e3 / args.fft_steps
+        roundtrip_ok = roundtrip_ok and bool(torch.equal(x, y))
+
+        def timed_dev(fn, ref):
+            e0 = time.perf_counter()
+            for _ in range(args.fft_steps):
+                check(fn(dom.field, ref, y.data_ptr()), "fft")
+            check(L.ark_hip_synchronize(), "sync")
+            return (time.perf_counter() - e0) * 1e3 / args.fft_steps
+
+        fft_ms = timed_dev(fwd, sref)
+        ifft_ms = timed_dev(inv, sref)
+        cfft_ms = timed_dev(fwd, cref)
+        cifft_ms = timed_dev(inv, cref)
         # per-pass device times of one transform (HIP events on the library stream)
         check(L.ark_hip_fft_set_timing(1), "fft timing")
         check(fwd(dom.field, sref, y.data_ptr()), "fft")
@@ -413,6 +465,7 @@ def main():
         L.ark_hip_fft_last_timing(ft)
         check(L.ark_hip_fft_set_timing(0), "fft timing")
         dev_ms = ft[0]
+        npass = int(ft[1])
         # the same transform as a batch of 8 polynomials (three in flight: ark_hip_fft_batch_in_place_device)
         ys = [x.clone() for _ in range(8)]
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in ys])
@@ -426,18 +479,89 @@ def main():
         batch_ms = (time.perf_counter() - e0) * 1e3 / (8 * reps_b)
         batch_same = bool(torch.equal(ys[0], ys[7]))
         del ys
+        # the trait surface: Vec<Fr> in host memory, in place (radix2/mod.rs:140-153) -- both PCIe crossings inside the call
+        hx = x_h.copy()
+        dom.fft_in_place(hx)
+        t1 = time.perf_counter()
+        host_reps = 3
+        for _ in range(host_reps):
+            dom.fft_in_place(hx)
+        host_ms = (time.perf_counter() - t1) * 1e3 / host_reps
+        del hx
+        # multiply work: every two-stage round costs one Fr product per element, a single-stage round half of one; the
+        # transform's last two stages multiply only by w^(n/4) (a quarter), its very last stage not at all
+        lazy_fft = os.environ.get("ARK_HIP_FFT_LAZY", "0").startswith("1")   # the library's own switch (fft.cuh): default saturated
+        kps = None
+        products = None
+        if not lazy_fft:
+            # n/2 per stage minus the trivial twiddles the saturated kernel skips (one per block of every stage: n - 1 in all)
+            products = float(nf // 2 * kf - (nf - 1))
+        if lazy_fft and kf > 10:
+            P_ = (kf + 7) // 8
+            base_, rem_ = kf // P_, kf % P_
+            kps = [base_ + (1 if i < rem_ else 0) for i in range(P_)]
+            for i in range(P_):                       # the plan's pairing of odd passes (fft.cuh fft_run_device)
+                for j in range(P_ - 1, i, -1):
+                    if kps[i] % 2 and kps[j] % 2 and kps[i] < 8 and kps[j] > 2:
+                        kps[i] += 1
+                        kps[j] -= 1
+                        break
+            products = 0.0
+            for i, kp_ in enumerate(kps):
+                products += nf * (kp_ // 2) + (nf / 2) * (kp_ % 2)
+                if i == len(kps) - 1:
+                    products -= (nf / 2) if kp_ % 2 else (3 * nf / 4)
+        fft_cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O  # test infrastructure: used here only as the timed CPU baseline
+            cores = usable_cores()
+            fid = O.FID[FIELD]
+            O.fft(fid, x_h, kf, None, False, cores)                     # warm-up (page faults, thread start)
+            t1 = time.perf_counter()
+            creps = 3
+            for _ in range(creps):
+                ref_out = O.fft(fid, x_h, kf, None, False, cores)
+            cpu_s = (time.perf_counter() - t1) / creps
+            z = x.clone()
+            check(fwd(dom.field, sref, z.data_ptr()), "fft")
+            check(L.ark_hip_synchronize(), "sync")
+            same = bool(np.array_equal(z.cpu().numpy().view(np.uint64).reshape(-1), ref_out))
+            fft_cpu = {"value": nf / cpu_s, "unit": "elements/s", "cores": cores, "kind": "port",
+                       "sample": "the whole 2^%d transform, the oracle's threaded in-order radix-2 FFT (oracle/: restatement of "
+                                 "radix2/fft.rs), %.2f s per transform on %d threads; GPU result limb for limb equal: %s"
+                                 % (kf, cpu_s, cores, same)}
+        kname = "fft_pass29_kernel" if lazy_fft else "fft_pass_kernel"
         fft = {
             "metric": "BLS12-381 Fr radix-2 FFT elements/sec (2^%d, in place, device resident)" % kf,
             "value": nf / (fft_ms * 1e-3), "unit": "elements/s", "ms_per_step": fft_ms,
-            "device_ms": dev_ms, "passes": [ft[2 + i] for i in range(int(ft[1]))],
+            "device_ms": dev_ms, "passes": [ft[2 + i] for i in range(npass)],
+            "shapes_ms": {"fft": fft_ms, "ifft": ifft_ms, "coset_fft": cfft_ms, "coset_ifft": cifft_ms},
             "ifft_fft_roundtrip_exact": roundtrip_ok,
+            "arithmetic": "exact integers on v_mad_u64_u32: %s" % ("carry-free 9 x 29-bit limbs" if lazy_fft else "saturated 32-bit limbs"),
             "batch_of_8": {"what": "8 polynomials over the same domain per call, three transforms in flight",
                            "ms_per_transform": batch_ms, "value": nf / (batch_ms * 1e-3), "results_agree": batch_same},
-            "roofline": {"bound": "hbm", "kernel": "fft_pass_kernel (x%d passes)" % int(ft[1]),
+            "trait_surface": {"what": "ark_hip_fft_in_place on a host Vec<Fr> (the call behind Radix2EvaluationDomain::"
+                                      "fft_in_place): 2 x %d MiB over PCIe inside the call, pageable memory" % (nf * 32 >> 20),
+                              "ms_per_call": host_ms, "value": nf / (host_ms * 1e-3)},
+            "cpu_baseline": fft_cpu,
+            "roofline": {"bound": "hbm", "kernel": "%s (x%d passes)" % (kname, npass),
                          "achieved": 64.0 * nf / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": 64.0 * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic("fft_pass_kernel", kf)[0],
-                         "traffic_source": pmc_traffic("fft_pass_kernel", kf)[1]},
+                         "traffic": pmc_traffic(kname, kf)[0],
+                         "traffic_source": pmc_traffic(kname, kf)[1],
+                         "alu": None if products is None else {
+                             "what": "Fr products/s executed by the transform (%.3g products%s) vs the best rate of the same "
+                                     "product back to back in a loop on this chip"
+                                     % (products, "" if kps is None else ", pass plan %s" % kps),
+                             "achieved": products / (dev_ms * 1e-3),
+                             "peak": FR_PRODUCTS_PER_S["carry-free" if lazy_fft else "saturated"],
+                             "frac": products / (dev_ms * 1e-3) / FR_PRODUCTS_PER_S["carry-free" if lazy_fft else "saturated"],
+                             "two_waves": {"peak": FR_PRODUCTS_PER_S_TWO_WAVES["carry-free" if lazy_fft else "saturated"],
+                                           "frac": products / (dev_ms * 1e-3)
+                                           / FR_PRODUCTS_PER_S_TWO_WAVES["carry-free" if lazy_fft else "saturated"]},
+                             "peak_source": "profiles/r4_ubench_product_rate_29bit.txt (BLS12-381 Fr): saturated product 135.7 G/s "
+                                            "at eight waves per SIMD / 121.5 at two; carry-free 177.2 / 154.5"}},
         }
 
     # ---- sharded FFT leg (N > 1): 2^fft_log_n coefficients per GPU, all-to-all exchanges over RCCL ----------
@@ -549,10 +673,13 @@ def main():
                                                         "saturated 32-bit limbs: 8 products + one two-product sum"),
                                  "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
                                  "frac": mads_per_s / MAD_U64_U32_PER_S,
-                                 "peak_source": "profiles/r1_ubench_instruction_rates.txt (v_mad_u64_u32); re-measured in "
-                                                "round 3 with four independent chains per lane: 28.1-30.6e12/s at eight "
-                                                "waves per SIMD across boxes, 23.7e12/s at the kernel's two waves "
-                                                "(profiles/r3_ubench_product_rate.txt)"},
+                                 "two_waves": {"what": "the same instruction's issue rate at the kernel's occupancy (two "
+                                                       "waves per SIMD, 219 VGPRs)",
+                                               "peak": MAD_U64_U32_PER_S_TWO_WAVES,
+                                               "frac": mads_per_s / MAD_U64_U32_PER_S_TWO_WAVES},
+                                 "peak_source": "profiles/r3_issue_rates.txt: v_mad_u64_u32, four independent chains per "
+                                                "lane -- 34.96e12 lane-ops/s at eight waves per SIMD (the best rate "
+                                                "measured on this chip: `peak`), 26.6e12/s at two waves"},
                          "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
             "cpu_baseline": cpu,
             "trait_surface": trait,

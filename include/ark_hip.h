@@ -238,6 +238,8 @@ int ark_hip_sw_add_affine_device(int curve, const void* d_in, void* d_out, size_
 /* CurveGroup::normalize_batch (ec/src/models/short_weierstrass/group.rs:302-319) for n Projective points in
  * device memory -> n Affine points in device memory; identity -> (0, 0). */
 int ark_hip_sw_normalize_batch_device(int curve, const void* d_jac, void* d_out_xy, size_t n);
+/* the same from host memory: n Projective in, n Affine out (the Rust hook behind CurveGroup::normalize_batch) */
+int ark_hip_sw_normalize_batch(int curve, const uint64_t* jac_points, size_t n, uint64_t* out_xy);
 
 /* ---- Radix-2 evaluation domain ----
  * Mirror of Radix2EvaluationDomain<F>'s public fields (poly/src/domain/radix2/mod.rs:22-42). */
@@ -284,6 +286,13 @@ int ark_hip_fft_batch_in_place_device(int field, const ark_hip_radix2_domain* do
  * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
  * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */
 int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
+/* `&DensePolynomial * &DensePolynomial` (poly/src/polynomial/univariate/dense.rs:641-656: evaluate both factors over the
+ * radix-2 domain of size >= na + nb - 1, multiply pointwise, interpolate) from HOST coefficient vectors: ONE upload of a and
+ * b, both forward transforms in flight together (short factors on the degree-aware path), the pointwise product and the
+ * inverse transform on the device, ONE download.  out: room for na + nb - 1 elements; *out_len: coefficients of the product
+ * with leading zeros dropped as DensePolynomial::from_coefficients_vec leaves them (0: a factor was the zero polynomial).
+ * ARK_HIP_ERR_ARG when the field's two-adicity cannot hold the domain (the reference panics there). */
+int ark_hip_poly_mul(int field, const uint64_t* a, size_t na, const uint64_t* b, size_t nb, uint64_t* out, size_t* out_len);
 /* base^exp in Fr on the host (domain elements / twiddles for hosts without field code of their own) */
 int ark_hip_fr_pow(int field, const uint64_t* base, uint64_t exp, uint64_t* out);
 /* the G-point transform along the slow axis of a [G][cols] device array (G = 2, 4, 8 or 16), in place:
@@ -331,6 +340,9 @@ int ark_hip_fft_shard_local_device(int field, const ark_hip_radix2_domain* dom, 
                                    int inverse);
 int ark_hip_fft_shard_cross_device(int field, const ark_hip_radix2_domain* dom, int world, const void* d_src, void* d_dst,
                                    int inverse);
+/* Which pass kernel the transforms of the current device use: 0 = saturated 32-bit limbs (default), 1 = carry-free 9 x 29-bit
+ * limbs (same results bit for bit; measured no faster: DESIGN.md section 5), -1 = the environment's choice (ARK_HIP_FFT_LAZY). */
+int ark_hip_fft_set_kernel(int variant);
 int ark_hip_fft_set_timing(int enable);
 /* [total_ms, npass, pass0_ms, pass1_ms, ...] of the last timed device transform */
 int ark_hip_fft_last_timing(double out[10]);

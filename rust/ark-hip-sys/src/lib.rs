@@ -113,6 +113,8 @@ extern "C" {
                                     scalars_are_montgomery: c_int, d_out_xy: *mut c_void) -> c_int;
     pub fn ark_hip_sw_sum(curve: c_int, jac_points: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_sw_normalize_batch_device(curve: c_int, d_jac: *const c_void, d_out_xy: *mut c_void, n: usize) -> c_int;
+    /// `CurveGroup::normalize_batch` from host memory: n Projective in, n Affine out.
+    pub fn ark_hip_sw_normalize_batch(curve: c_int, jac_points: *const u64, n: usize, out_xy: *mut u64) -> c_int;
     pub fn ark_hip_fft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;
     pub fn ark_hip_ifft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;
     pub fn ark_hip_fft_in_place_degree_aware(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64,
@@ -122,6 +124,10 @@ extern "C" {
     pub fn ark_hip_fft_batch_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *const *mut c_void,
                                              count: usize, inverse: c_int) -> c_int;
     pub fn ark_hip_fr_mul_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    /// `&DensePolynomial * &DensePolynomial` from host coefficient vectors: one upload, three transforms and the pointwise
+    /// product on the device, one download; `out_len` = coefficients with leading zeros dropped.
+    pub fn ark_hip_poly_mul(field: c_int, a: *const u64, na: usize, b: *const u64, nb: usize, out: *mut u64,
+                            out_len: *mut usize) -> c_int;
     pub fn ark_hip_msm_prepared_multi(n_gpus: c_int, shards: *const *const ark_hip_msm_bases, scalars: *const u64, n: usize,
                                       scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
     // one process per GPU: the library's own RCCL communicator (include/ark_hip.h, "RCCL inside the library")
@@ -233,4 +239,35 @@ pub fn radix2_fft_in_place<F: FftField, T: Copy>(
         return false;
     }
     true
+}
+
+/// `&DensePolynomial<F> * &DensePolynomial<F>` (poly/src/polynomial/univariate/dense.rs:641-656) on the GPU when `F` is a
+/// served scalar field: both coefficient vectors cross PCIe once, the two forward transforms, the pointwise product and
+/// the inverse transform stay on the device, the product's coefficients come back once (2^20 x 2^20: 64 MiB up, 64 MiB
+/// down around ~1.5 ms of kernels, instead of three host-pointer transforms with a CPU pointwise product in between).
+/// Called by ark-poly's `hip` feature (patches/0005).  `None` -- the caller runs the CPU code -- when `F` is not served,
+/// a factor is zero (the CPU path returns `DensePolynomial::zero()`), the product is too small to be worth the trip, the
+/// field's two-adicity cannot hold the domain (the reference then picks a mixed-radix domain or panics) or the device
+/// reports an error.  The returned vector has no leading zeros (`from_coefficients_vec` would drop them anyway).
+pub fn poly_mul<F: FftField>(a: &[F], b: &[F]) -> Option<ark_std::vec::Vec<F>> {
+    const MIN_LEN: usize = 1 << 12; // below this the CPU's own FFT wins against two PCIe crossings
+    if core::mem::size_of::<F>() != 32 || core::mem::align_of::<F>() != core::mem::align_of::<u64>() {
+        return None;
+    }
+    let fid = fr_field_id::<F>()?;
+    if a.is_empty() || b.is_empty() || a.len() + b.len() - 1 < MIN_LEN {
+        return None;
+    }
+    let cap = a.len() + b.len() - 1;
+    let mut out: ark_std::vec::Vec<F> = ark_std::vec::Vec::with_capacity(cap);
+    let mut out_len: usize = 0;
+    let rc = unsafe {
+        ark_hip_poly_mul(fid, a.as_ptr() as *const u64, a.len(), b.as_ptr() as *const u64, b.len(),
+                         out.as_mut_ptr() as *mut u64, &mut out_len)
+    };
+    if rc != 0 || out_len == 0 || out_len > cap {
+        return None; // (out_len == 0: a zero factor -- the CPU path builds the zero polynomial)
+    }
+    unsafe { out.set_len(out_len) }; // the library wrote `cap` canonical Montgomery residues; the first out_len are kept
+    Some(out)
 }

@@ -1,10 +1,12 @@
 //! ark-hip: plugs libark_hip.so (MI355X MSM + radix-2 FFT) into ark-ec / ark-poly 0.6.
 //!
 //! Two ways in:
-//! * **patched arkworks** (patches/0001-0003): the upstream curve configs override `SWCurveConfig::msm` /
+//! * **patched arkworks** (patches/0001-0005): the upstream curve configs override `SWCurveConfig::msm` /
 //!   `msm_bigint` behind their `hip` feature and call [`msm::sw_msm`] / [`msm::sw_msm_bigint`]; `G1Projective` stays
 //!   the same type, `VariableBaseMSM::{msm, msm_unchecked, msm_bigint, msm_chunks}`, `ChunkedPippenger` and
-//!   `HashMapPippenger` all reach the GPU.  ark-poly's `hip` feature does the same for `Radix2EvaluationDomain`.
+//!   `HashMapPippenger` all reach the GPU, and so do `CurveGroup::normalize_batch` and `ScalarMul::batch_mul`
+//!   (patches/0004).  ark-poly's `hip` feature does the same for `Radix2EvaluationDomain` (0003) and for
+//!   `&DensePolynomial * &DensePolynomial` (0005: one upload, one download).
 //! * **unmodified arkworks**: [`hip_sw_config!`] declares a wrapper `SWCurveConfig` (every item of the trait
 //!   delegated, `msm` on the GPU) and [`domain::HipRadix2EvaluationDomain`] wraps the evaluation domain.
 //!
@@ -19,4 +21,4 @@ pub use ark_hip_sys as sys;
 pub use ark_hip_sys::{BLS12_377_G1, BLS12_377_G2, BLS12_381_G1, BLS12_381_G2, BN254_G1};
 pub use msm::{sw_msm, sw_msm_bigint};
 #[cfg(feature = "ec-hook")]
-pub use msm::sw_msm_small;
+pub use msm::{sw_batch_mul, sw_msm_small, sw_normalize_batch};

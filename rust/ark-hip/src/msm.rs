@@ -353,6 +353,38 @@ impl<P: SWCurveConfig> Drop for BatchMulTable<P> {
     }
 }
 
+/// `CurveGroup::normalize_batch` (ec/src/models/short_weierstrass/group.rs:302-319) on the device: one upload of the
+/// Projective points, a lane-batched Montgomery inversion (ff/src/fields/mod.rs:358-385 per lane), one download of the
+/// Affine points (identity -> `Affine::identity()`, the all-zero encoding of `ZeroFlag = ()`).  The hook patches/0004 adds
+/// to `SWCurveConfig` calls this; `None` (the CPU path runs) below 2^12 points, on a layout mismatch or a device error.
+#[cfg(feature = "ec-hook")]
+pub fn sw_normalize_batch<P: SWCurveConfig>(curve: c_int, v: &[Projective<P>]) -> Option<Vec<Affine<P>>> {
+    const MIN_POINTS: usize = 1 << 12; // PCIe both ways: 240 B per BLS12-381 G1 point against ~0.2 us of CPU work
+    if v.len() < MIN_POINTS || !layout_ok::<P, P::ScalarField>(curve) {
+        return None;
+    }
+    let mut out: Vec<Affine<P>> = Vec::with_capacity(v.len());
+    let rc = unsafe { sys::ark_hip_sw_normalize_batch(curve, v.as_ptr() as *const u64, v.len(), out.as_mut_ptr() as *mut u64) };
+    if rc != 0 {
+        return None;
+    }
+    unsafe { out.set_len(v.len()) }; // every element written by the library
+    Some(out)
+}
+
+/// `ScalarMul::batch_mul` (ec/src/scalar_mul/mod.rs:106-109: `BatchMulPreprocessing::new(self, v.len())` +
+/// `batch_mul_with_preprocessing`) on the device: the table of multiples is built in GPU memory (sized from `v.len()` by the
+/// device's own cost rule), the batch is one mixed addition per table row and scalar, the affine results come back once.
+/// The hook patches/0004 adds to `SWCurveConfig` calls this; `None` below 2^10 scalars, on a layout mismatch or an error.
+#[cfg(feature = "ec-hook")]
+pub fn sw_batch_mul<P: SWCurveConfig>(curve: c_int, base: &Projective<P>, v: &[P::ScalarField]) -> Option<Vec<Affine<P>>> {
+    const MIN_SCALARS: usize = 1 << 10;
+    if v.len() < MIN_SCALARS {
+        return None;
+    }
+    BatchMulTable::<P>::new(curve, *base, v.len())?.batch_mul(v)
+}
+
 /// Page-locked host buffer of scalars (ark_hip_host_alloc): uploads at full PCIe rate and truly asynchronously.
 pub struct PinnedScalars<S: Copy> {
     ptr: *mut S,
@@ -470,6 +502,16 @@ macro_rules! hip_sw_config {
                          scalars: ark_ec::scalar_mul::variable_base::SmallScalars<'_>)
                          -> ark_ec::short_weierstrass::Projective<Self> {
                 $crate::msm::sw_msm_small::<Self>($id, bases, scalars)
+            }
+            #[cfg(feature = "ec-hook")]
+            fn normalize_batch(v: &[ark_ec::short_weierstrass::Projective<Self>])
+                               -> Option<ark_std::vec::Vec<ark_ec::short_weierstrass::Affine<Self>>> {
+                $crate::msm::sw_normalize_batch::<Self>($id, v)
+            }
+            #[cfg(feature = "ec-hook")]
+            fn batch_mul(base: &ark_ec::short_weierstrass::Projective<Self>, v: &[Self::ScalarField])
+                         -> Option<ark_std::vec::Vec<ark_ec::short_weierstrass::Affine<Self>>> {
+                $crate::msm::sw_batch_mul::<Self>($id, base, v)
             }
             #[inline]
             fn serialize_with_mode<W: ark_serialize::Write>(item: &ark_ec::short_weierstrass::Affine<Self>, writer: W,

@@ -190,11 +190,121 @@ template <class P> int run(const char* name, const uint64_t* gen) {
   printf("%s: %s (%d bad)\n", name, bad ? "FAIL" : "ok", bad);
   return bad;
 }
+#include "fft.cuh"
+// The arithmetic of the carry-free FFT pass (fft.cuh Fft29, 9 x 29-bit limbs) on the host: reduce_sweep / sweep / canon /
+// dif at the EXTREMES the kernel's bounds allow (limbs up to 2.5 2^30, values up to 13.02 p), which random transforms
+// do not reach, and one 4-point group of two stages against the saturated arithmetic.
+template <class FP> int run_fft29(const char* name) {
+  typedef Fp<FP> F;
+  typedef FpL<FP> L;
+  typedef Fft29<FP> A;
+  std::mt19937_64 g(11);
+  int bad = 0;
+  auto value_of = [&](const L& x) -> F {   // integer value of the limbs mod p, as a canonical Fp (plain integer, no Montgomery factor)
+    // sum l_i 2^(29 i) mod p by Horner over canonical adds / doublings
+    F acc = F::zero();
+    for (int i = 8; i >= 0; i--) {
+      for (int b = 0; b < 29; b++) acc = F::dbl(acc);
+      u32 w[8] = {x.l[i], 0, 0, 0, 0, 0, 0, 0};
+      F li = F::reduce_full(*(const F*)w);
+      acc = F::add(acc, li);
+    }
+    return acc;
+  };
+  auto lt_kp = [&](const L& x, int k) -> bool {   // normalised x < k p ?
+    for (int i = 8; i >= 0; i--) {
+      const u32 kp = L::kp_limb(k, i);
+      if (x.l[i] != kp) return x.l[i] < kp;
+    }
+    return false;
+  };
+  for (int it = 0; it < 20000; it++) {
+    // an un-normalised value as the sum outputs have them: up to four tile elements (normalised limbs, values c + j p
+    // below 3.01 p) added limb-wise: limbs below 2^31, value below 12.04 p
+    L v = L::zero();
+    const int terms = 1 + (int)(g() % 4);
+    for (int t = 0; t < terms; t++) {
+      F r = rnd<FP>(g);
+      if (it % 7 == 0) for (int i = 0; i < 8; i++) r.l[i] = FP::P[i] - (i == 0 ? 1 + (u32)(g() % 3) : 0);   // p - 1, p - 2, ..
+      const L rl = L::unpack32(r.l);
+      const int j = it % 5 == 0 ? 2 : (int)(g() % 3);
+      L e;
+      for (int i = 0; i < 9; i++) e.l[i] = rl.l[i] + L::kp_limb(j, i);
+      e = A::sweep(e);
+      for (int i = 0; i < 9; i++) v.l[i] += e.l[i];
+    }
+    const F want = value_of(v);
+    const L rs = A::reduce_sweep(v);
+    bool norm = true;
+    for (int i = 0; i < 9; i++) norm &= rs.l[i] <= L::MASK;
+    if (!norm || !F::eq(value_of(rs), want) || !lt_kp(rs, 4)) { bad++; if (bad < 5) printf("%s reduce_sweep fail (terms %d)\n", name, terms); }
+    if (!lt_kp(rs, 3) && bad < 5) printf("%s note: reduce_sweep output >= 3p\n", name);
+    const L cn = A::canon(v);
+    u32 w8[8];
+    cn.pack32(w8);
+    if (!F::eq(*(const F*)w8, want) || !lt_kp(cn, 1)) { bad++; if (bad < 5) printf("%s canon fail\n", name); }
+    {
+      const L sw = A::sweep(v);
+      bool n2 = true;
+      for (int i = 0; i < 8; i++) n2 &= sw.l[i] <= L::MASK;
+      if (!n2 || !F::eq(value_of(sw), want)) { bad++; if (bad < 5) printf("%s sweep fail\n", name); }
+    }
+  }
+  // one 4-point group of two DIF stages with random twiddles against the saturated arithmetic, inputs at the invariant's
+  // edge (normalised limbs, values up to 3 p: x = c + j p)
+  for (int it = 0; it < 3000; it++) {
+    F c[4], w[3];
+    L x[4], wl[3];
+    for (int m = 0; m < 4; m++) {
+      c[m] = rnd<FP>(g);
+      x[m] = L::unpack32(c[m].l);
+      const int j = (int)(g() % 3);   // + j p, re-normalised
+      L t;
+      for (int i = 0; i < 9; i++) t.l[i] = x[m].l[i] + L::kp_limb(j, i);
+      x[m] = A::sweep(t);
+    }
+    for (int m = 0; m < 3; m++) {
+      w[m] = rnd<FP>(g);
+      // twiddle form: w 2^261 mod p, canonical: mont_mul(w R, 2^261 mod p) with w[m] read as w R
+      u32 cin[8];
+      for (int i = 0; i < 8; i++) cin[i] = FP::LZ_CIN[i];
+      wl[m] = L::unpack32(F::mul(w[m], *(const F*)cin).l);
+    }
+    const L s0 = A::sum(x[0], x[2]), s1 = A::sum(x[1], x[3]);
+    const L d0 = L::mul(A::template dif<4, 1>(x[0], x[2]), wl[0]);
+    const L d1 = L::mul(A::template dif<4, 1>(x[1], x[3]), wl[1]);
+    const L y[4] = {A::reduce_sweep(A::sum(s0, s1)), L::mul(A::template dif<7, 2>(s0, s1), wl[2]), A::sweep(A::sum(d0, d1)),
+                    L::mul(A::template dif<2, 1>(d0, d1), wl[2])};
+    const F fs0 = F::add(c[0], c[2]), fs1 = F::add(c[1], c[3]);
+    const F fd0 = F::mul(F::sub(c[0], c[2]), w[0]), fd1 = F::mul(F::sub(c[1], c[3]), w[1]);
+    const F fy[4] = {F::add(fs0, fs1), F::mul(F::sub(fs0, fs1), w[2]), F::add(fd0, fd1), F::mul(F::sub(fd0, fd1), w[2])};
+    for (int m = 0; m < 4; m++) {
+      bool norm = true;
+      for (int i = 0; i < 9; i++) norm &= y[m].l[i] <= L::MASK;
+      const L cn = A::canon(y[m]);
+      u32 w8[8];
+      cn.pack32(w8);
+      if (!norm || !lt_kp(y[m], 4) || !F::eq(*(const F*)w8, fy[m])) { bad++; if (bad < 8) printf("%s butterfly group output %d fail\n", name, m); }
+    }
+    // the tail stages' raw outputs through the exact reduction
+    const L raw1 = A::template dif<7, 2>(s0, s1), raw3 = A::template dif<2, 1>(A::template dif<4, 1>(x[0], x[2]), d1);
+    u32 w8[8];
+    A::canon(raw1).pack32(w8);
+    if (!F::eq(*(const F*)w8, F::sub(fs0, fs1))) { bad++; if (bad < 8) printf("%s raw y1 fail\n", name); }
+    A::canon(raw3).pack32(w8);
+    if (!F::eq(*(const F*)w8, F::sub(F::sub(c[0], c[2]), fd1))) { bad++; if (bad < 8) printf("%s raw y3 fail\n", name); }
+  }
+  printf("%s fft29: %s (%d bad)\n", name, bad ? "FAIL" : "ok", bad);
+  return bad;
+}
 #include "curve_consts.hpp"
 int main() {
   int b = 0;
   b += run<BLS12_381_FQ>("BLS12_381_FQ", GEN_BLS12_381_G1);
   b += run<BLS12_377_FQ>("BLS12_377_FQ", GEN_BLS12_377_G1);
   b += run<BN254_FQ>("BN254_FQ", GEN_BN254_G1);   // 9 x 29-bit limbs
+  b += run_fft29<BLS12_381_FR>("BLS12_381_FR");
+  b += run_fft29<BN254_FR>("BN254_FR");
+  b += run_fft29<BLS12_377_FR>("BLS12_377_FR");
   return b != 0;
 }

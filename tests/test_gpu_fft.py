@@ -112,4 +112,32 @@ def test_polynomial_multiplication_on_device(fname):
             prod = O.field_op(fid, "mul", np.tile(a[i], (lb, 1)), b).reshape(lb, 4)
             exp[i:i + lb] = O.field_op(fid, "add", exp[i:i + lb], prod).reshape(lb, 4)
         assert np.array_equal(got, exp), (fname, la, lb)
+        # the ONE host-pointer entry the Rust hook behind `&a * &b` binds (ark_hip_poly_mul): same coefficients
+        assert np.array_equal(A.poly_mul_host(fname, a, b), exp), (fname, la, lb, "host entry")
     assert A.poly_mul(fname, np.zeros((0, 4), dtype=np.uint64), rand_fr(fid, 3, 1)).shape == (0, 4)
+    # DensePolynomial::is_zero: an empty or all-zero factor gives the zero polynomial (dense.rs:646-648)
+    assert A.poly_mul_host(fname, np.zeros((0, 4), dtype=np.uint64), rand_fr(fid, 3, 1)).shape == (0, 4)
+    assert A.poly_mul_host(fname, rand_fr(fid, 3, 1), np.zeros((5, 4), dtype=np.uint64)).shape == (0, 4)
+    # leading zeros of the product are dropped (from_coefficients_vec): (x - 1)(x + 1) in characteristic != 2 keeps 3,
+    # a factor padded with zero coefficients keeps none of the padding
+    a = rand_fr(fid, 6, 5)
+    a[4:] = 0
+    b = rand_fr(fid, 9, 6)
+    got = A.poly_mul_host(fname, a, b)
+    assert got.shape[0] == 4 + 9 - 1 and np.array_equal(got, A.poly_mul(fname, a[:4], b))
+
+
+def test_polynomial_multiplication_host_entry_at_size():
+    """2^20 x 2^20 coefficients through ark_hip_poly_mul (domain 2^21: one H2D of 64 MiB, one D2H of 64 MiB) against the
+    device-resident composition, and linearity: (a + a') b = a b + a' b."""
+    fname = "BLS12_381_FR"
+    fid = O.FID[fname]
+    n = 1 << 20
+    a, a2, b = rand_fr(fid, n, 1), rand_fr(fid, n, 2), rand_fr(fid, n - 7, 3)
+    ab = A.poly_mul_host(fname, a, b)
+    assert ab.shape[0] == 2 * n - 8
+    assert np.array_equal(ab, A.poly_mul(fname, a, b))
+    s = O.field_op(fid, "add", a, a2).reshape(n, 4)
+    lhs = A.poly_mul_host(fname, s, b)
+    rhs = O.field_op(fid, "add", ab, A.poly_mul_host(fname, a2, b)).reshape(-1, 4)
+    assert np.array_equal(lhs, rhs)

@@ -164,3 +164,5 @@ def test_normalize_batch_on_device(cname):
     d = torch.from_numpy(pts.view(np.int64)).cuda()
     got = A.normalize_batch(cid, d).cpu().numpy().view(np.uint64).reshape(n, -1)
     assert np.array_equal(got, O.to_affine(cid, pts))
+    # the host-pointer entry the Rust hook behind CurveGroup::normalize_batch binds
+    assert np.array_equal(A.normalize_batch(cid, pts), O.to_affine(cid, pts))

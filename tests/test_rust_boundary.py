@@ -71,15 +71,47 @@ def _trait_items():
     return golden
 
 
-def test_patches_apply_to_the_reference_tree():
+def test_patches_apply_to_the_reference_tree(tmp_path):
+    """The series applies IN ORDER (0004 / 0005 build on the hooks 0001-0003 add) to a scratch copy of the subtrees it
+    touches -- the reference itself is never written."""
     if not os.path.isdir(REF):
         pytest.skip("reference tree not present on this box")
+    import shutil
     patches = sorted(p for p in os.listdir(os.path.join(ROOT, "patches")) if p.endswith(".patch"))
-    assert len(patches) >= 3
+    assert len(patches) >= 5
+    work = tmp_path / "ref"
+    work.mkdir()
+    for sub in ("ec", "poly", "curves"):
+        shutil.copytree(os.path.join(REF, sub), str(work / sub), symlinks=True)
+    shutil.copy(os.path.join(REF, "Cargo.toml"), str(work / "Cargo.toml"))
     for p in patches:
-        r = subprocess.run(["git", "apply", "--check", "-p1", os.path.join(ROOT, "patches", p)], cwd=REF,
-                           capture_output=True, text=True)
+        r = subprocess.run(["git", "apply", "-p1", os.path.join(ROOT, "patches", p)], cwd=str(work), capture_output=True, text=True)
         assert r.returncode == 0, (p, r.stderr)
+    # the hooks 0004 / 0005 add are there and reach the shims
+    grp = open(str(work / "ec/src/models/short_weierstrass/group.rs")).read()
+    assert "P::normalize_batch(v)" in grp and "P::batch_mul(&self, v)" in grp
+    g1 = open(str(work / "curves/bls12_381/src/curves/g1.rs")).read()
+    assert "ark_hip::sw_normalize_batch::<Self>(ark_hip::BLS12_381_G1, v)" in g1
+    assert "ark_hip::sw_batch_mul::<Self>(ark_hip::BLS12_381_G1, base, v)" in g1
+    dense = open(str(work / "poly/src/polynomial/univariate/dense.rs")).read()
+    assert "ark_hip_sys::poly_mul(&self.coeffs, &other.coeffs)" in dense
+
+
+def test_f2_f3_callers_are_hooked():
+    """SURVEY 8(f2)/(f3): `&DensePolynomial * &DensePolynomial`, `CurveGroup::normalize_batch` and `ScalarMul::batch_mul` reach
+    the device from Rust: the shims exist, bind host-pointer C entries the header declares, and the wrapper macro overrides
+    the two SWCurveConfig hooks."""
+    sys_rs = open(os.path.join(ROOT, "rust", "ark-hip-sys", "src", "lib.rs")).read()
+    assert "pub fn poly_mul<F: FftField>(a: &[F], b: &[F]) -> Option<" in sys_rs and "ark_hip_poly_mul(fid," in sys_rs
+    msm_rs = open(os.path.join(ROOT, "rust", "ark-hip", "src", "msm.rs")).read()
+    assert "pub fn sw_normalize_batch<" in msm_rs and "sys::ark_hip_sw_normalize_batch(" in msm_rs
+    assert "pub fn sw_batch_mul<" in msm_rs and "BatchMulTable::<P>::new(curve, *base, v.len())" in msm_rs
+    macro = msm_rs[msm_rs.index("macro_rules! hip_sw_config"):]
+    assert "fn normalize_batch(" in macro and "fn batch_mul(" in macro
+    decl = _c_decls()
+    assert decl["ark_hip_poly_mul"] == 7 and decl["ark_hip_sw_normalize_batch"] == 4
+    p4 = open(os.path.join(ROOT, "patches", "0004-ark-ec-normalize-batch-and-batch-mul-hooks.patch")).read()
+    assert p4.count("ark_hip::sw_normalize_batch::<Self>") == 5 and p4.count("ark_hip::sw_batch_mul::<Self>") == 5
 
 
 def test_wrapper_config_macro_covers_every_trait_item():

@@ -8,10 +8,13 @@
 #   kt                   rocprofv3 --kernel-trace of a short bench            -> kernel_stats.txt
 #   pmc                  FETCH_SIZE / WRITE_SIZE passes + gather calibration  -> pmc_traffic.json, pmc_*.txt
 #   sq                   SQ counters (VALU / wait / busy) of a short bench    -> pmc_sq.txt
+#   env:VAR=VAL          export VAR=VAL for the steps that follow (A/B switches: ARK_HIP_FFT_LAZY=0, ARK_HIP_MSM_LAZY=0)
 #   n2gloo               bench.py --gpus 2 over gloo, ranks sharing the GPU   -> bench_n2_gloo.json
 #   soak:N               tools/soak.py N                                      -> soak.log
 #   mulbench             csrc/ubench/mulbench_*.bin (prebuilt, travel as .bin)-> mulbench.txt
 #   msm:CURVE:LOGN[:MODE[:REPS]]   tools/msm_bench.py, ARK_HIP_MSM_LAZY=1 and 0 -> msm.txt
+#   fft[:LO:HI]          tools/fft_shapes.py (the reference's five bench shapes), ARK_HIP_FFT_LAZY=1 and 0 -> fft.txt
+#   fftv[:LO:HI]         tools/fft_shapes.py on the shipped library and every algebra_amd/variants/*.so -> fftv.txt
 #   ab:CURVE:LOGN[:MODE] every algebra_amd/variants/*.so x LAZY in {1,0}, twice -> ab.txt
 #   py:SCRIPT[:ARGS]     python tools/SCRIPT ARGS (':' separates arguments)   -> py_SCRIPT.txt
 tag=$1; shift
@@ -47,9 +50,9 @@ for step in "$@"; do
       rm -rf $O/p_fetch $O/p_write $O/p_cal ;;
     sq)
       cd /tmp
-      timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $O/p_sq -o s -- $SHORT > $O/sq.out 2> $O/sq.err
+      timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/p_sq -o s -- $SHORT > $O/sq.out 2> $O/sq.err
       cd $R
-      python tools/rocpd_stats.py $(db p_sq) --pmc --min-us 100 > $O/pmc_sq.txt 2>> $O/post.err
+      python tools/rocpd_stats.py $(db p_sq) --pmc --min-us 50 > $O/pmc_sq$suffix.txt 2>> $O/post.err
       rm -rf $O/p_sq ;;
     n2gloo)
       (ARK_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 3 --warmup 1 --log-n 21 --fft-log-n 20 --fft-steps 4 > $O/bench_n2_gloo.json) 2> $O/bench_n2_gloo.err ;;
@@ -60,11 +63,20 @@ for step in "$@"; do
       for lz in 1 0; do
         (echo "== ARK_HIP_MSM_LAZY=$lz"; ARK_HIP_MSM_LAZY=$lz timeout 600 python tools/msm_bench.py ${a[1]} ${a[2]} ${a[4]:-3} ${a[3]:-plain}) >> $O/msm.txt 2>> $O/msm.err
       done ;;
+    fft)
+      for lz in 1 0; do
+        (echo "== ARK_HIP_FFT_LAZY=$lz"; ARK_HIP_FFT_LAZY=$lz timeout 600 python tools/fft_shapes.py ${a[1]:-16} ${a[2]:-24}) >> $O/fft.txt 2>> $O/fft.err
+      done ;;
+    fftv)
+      for v in algebra_amd/libark_hip.so $(ls algebra_amd/variants/*.so); do
+        (echo "== $v"; ARK_HIP_LIB=$PWD/$v timeout 600 python tools/fft_shapes.py ${a[1]:-20} ${a[2]:-24}) >> $O/fftv.txt 2>> $O/fftv.err
+      done ;;
     ab)
       for rep in 1 2; do for v in $(ls algebra_amd/variants/*.so); do for lz in 1 0; do
         (echo "== $v LAZY=$lz ${a[1]} ${a[2]}"; ARK_HIP_MSM_LAZY=$lz ARK_HIP_LIB=$PWD/$v timeout 300 python tools/msm_bench.py ${a[1]} ${a[2]} 3 ${a[3]:-plain}) >> $O/ab.txt 2>> $O/ab.err
       done; done; done ;;
     py) (echo "== ${a[@]:1}"; timeout 900 python tools/${a[1]} ${a[@]:2}) >> $O/py_${a[1]%.py}.txt 2>> $O/py_${a[1]%.py}.err ;;
+    env) export "${a[1]}"; suffix="_${a[1]//=/_}" ;;   # env:VAR=VAL -- exported for the steps that follow
     *) echo "unknown step $step" >> $O/errors.log ;;
   esac
   echo "$step done $(date +%s)" >> $O/steps.log
