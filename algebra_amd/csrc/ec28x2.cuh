@@ -54,6 +54,10 @@ __device__ __attribute__((noinline)) void lazy2_mdbl(XYZZL2<FL2>& acc, const cha
   acc = lazy2_from_bucket<FL2>(xyzz_mdbl<M>(b.x, M::cond_neg(b.y, neg)));
 }
 template <class FL2>
+__device__ __attribute__((noinline)) void lazy2_mdbl_xy(XYZZL2<FL2>& acc, const typename FL2::M& x, const typename FL2::M& y) {
+  acc = lazy2_from_bucket<FL2>(xyzz_mdbl<typename FL2::M>(x, y));
+}
+template <class FL2>
 __device__ __attribute__((noinline)) void lazy2_dbl_via_canonical(XYZZL2<FL2>& acc) {
   typedef typename FL2::M M;
   acc = lazy2_from_bucket<FL2>(xyzz_dbl<M>(lazy2_to_bucket<FL2>(acc)));

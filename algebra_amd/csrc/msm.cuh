@@ -719,13 +719,7 @@ struct AccOps<C, true> {
   static constexpr size_t ACC_BYTES = ((size_t)K::WORDS * 4 + 15) / 16 * 16;   // G1: 4 x 14 limbs + flag = 240 B; G2: 464 B per pair
   ARK_DEV static Acc zero() { return K::inf(); }
   ARK_DEV static Acc from_pt(const Pt& p) { return K::from_bucket(p); }
-  ARK_DEV static void madd(Acc& acc, const F& x, const F& y) {   // (x, y): a non-identity base, the digit's sign in y
-    const Affine<F> p{x, y};
-    if (K::madd(acc, p, false)) {   // equal points: the doubling of the base, through its canonical coordinates (rare)
-      const Acc d = K::from_bucket(xyzz_mdbl<F>(x, y));
-      acc = d;
-    }
-  }
+  ARK_DEV static void madd(Acc& acc, const F& x, const F& y) { K::madd_xy(acc, x, y); }   // (x, y): a non-identity base, the digit's sign in y
   ARK_DEV static void add(Acc& acc, const Pt& b) { K::add(acc, b); }
   ARK_DEV static void add_acc(Acc& acc, const Acc& b) { K::add_acc(acc, b); }
   ARK_DEV static Pt fin(const Acc& a) { return K::to_bucket(a); }
@@ -1038,7 +1032,12 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
         const double walk = lmax * per_add + W * 5e-6;                          // + run switches of a shared bucket
         if (nbk <= lanes || walk > acc) acc = walk;
       } else if (fp2) {
-        const double chain = (entries / nbk) * 14e-6 * mul_cost;  // one lane pair walks one (window, bucket) run
+        // G2 plain path on the carry-free lane-pair kernels, fitted on BLS12-377 G2 2^16 / 2^20 / 2^22, c = 13 .. 21
+        // (profiles/r4_planner_sweeps.txt): 0.40 ns per entry, rising for narrow windows (c = 15: 0.47, c = 14: 0.63); one
+        // lane pair walks one (window, bucket) run at 38 us per dependent addition, the most loaded run sets the floor
+        acc = entries * 0.40e-9 * (1.0 + ldexp(1.0, 13 - c));
+        const double load = entries / nbk;
+        const double chain = (load + 3.0 * sqrt(load) + 2.0) * 38e-6;
         if (chain > acc) acc = chain;
       } else {
         // Fp384 G1 on 28-bit limbs (round 3): 7.0e9 instead of 5.5e9 mixed additions/s (plain_k = 0.79; BN254, on
@@ -1060,6 +1059,12 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       const double red0_lat = (fp2 && shared) ? 0.6e-3 : 2.0 * 8.0 * 21e-6 * mul_cost;  // latency floor of the reduction (G2: measured 0.62-0.76 ms for 2^12..2^16 buckets)
       if (red0_lat > red0) red0 = red0_lat;
       double bits_stage = 0.5e-3 * mul_cost;                    // bit-sliced stage + host tail
+      if (!shared && fp2) {
+        // measured reduction of the plain G2 path: 0.45 ms + 2.6 ns per bucket up to ~10^6 buckets (short level-0 chunks: the
+        // bit-sliced stage is almost half of it), 1.25 ns per bucket beyond (same sweeps)
+        red0 = 0.45e-3 + nbk * (nbk < 1.2e6 ? 2.6e-9 : 1.25e-9);
+        bits_stage = 0.0;
+      }
       if (!shared && !fp2) {
         // plain path, fitted on BLS12-381 2^16 .. 2^24 (profiles/r3_window_sweep.txt): 0.2 ms + 0.45 ns per bucket
         // + 1.4 ns per bucket for the first 3e5 (few buckets leave the chip's lanes idle, the chains dominate)
@@ -1508,9 +1513,43 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     ARK_HIP_TRY(hipEventRecord(ws.grp_ev[1], ws.side));
   }
   if (piece && piece->after_prev) ARK_HIP_TRY(hipStreamWaitEvent(stream, piece->after_prev, 0));  // the buckets' previous writer
+  // bucket reduction of the windows [w0, w0 + wg): level 0 (chunked running sums), the bit-sliced sums, the chunk sums
+  constexpr u32 LNr = C::FA::LANES;
+  const bool two_level = nchunks > 1;
+  auto reduce_windows = [&](size_t w0, size_t wg, hipStream_t st) {
+    const size_t bo = w0 * m * Pt::BYTES;                       // (S, A) pairs of window w0
+    const size_t po = w0 * (size_t)Q * nchunks * Pt::BYTES;     // chunk partials of window w0
+    hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * wg * LNr + 127) / 128)), dim3(128), 0, st,
+                       (const char*)d_buckets + w0 * mwin * Pt::BYTES, L0, (u32)(m * wg), (char*)ws.lvlS[0].p + bo,
+                       (char*)ws.lvlA[0].p + bo);
+    constexpr size_t ACCBr = AccOps<C>::ACC_BYTES;
+    const u32 rthreads = ACCBr * (256 / LNr) > 49152 ? 128 : 256;  // LDS tree within 48 KiB
+    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, (u32)wg), dim3(rthreads), (rthreads / LNr) * ACCBr, st,
+                       (const char*)ws.lvlS[0].p + bo, (const char*)ws.lvlA[0].p + bo, (u32)m, nbits, chunk,
+                       (char*)ws.lvlS[1].p + po);
+    if (two_level)
+      hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)(wg * Q)), dim3(64), (64 / LNr) * AccOps<C>::ACC_BYTES, st,
+                         (const char*)ws.lvlS[1].p + po, (u32)(wg * Q), nchunks, (char*)ws.lvlA[1].p + w0 * Q * Pt::BYTES);
+  };
+  const bool whole_job = !piece || piece->last;   // (a non-final piece of a streamed MSM leaves the reduction to the last one)
+  // Two window groups: group 0's reduction -- latency-bound chains and LDS trees below ~2^22 pairs -- runs on the side stream
+  // UNDER group 1's accumulate kernel (the side stream has finished group 1's sort by then).
+  // Measured and OFF by default (ARK_HIP_MSM_SPLIT_REDUCE=1 enables): the reduction's additions compete with the accumulate
+  // kernel for the same vector ALU, and what the overlap hides is less than what two half-size launches add -- 2^20 3.82 ->
+  // 4.05 ms, 2^22 11.33 -> 11.66, 2^24 36.8 -> 37.9 with both overlaps on (profiles/r4_split_reduce_window_groups_ab.txt).
+  static const bool split_env = getenv("ARK_HIP_MSM_SPLIT_REDUCE") && getenv("ARK_HIP_MSM_SPLIT_REDUCE")[0] == '1';
+  const bool split_reduce = split_env && ngroups == 2 && whole_job && Wr == W;
   if (int rc = accumulate_group(grp[0], stream)) return rc;
   if (ngroups == 2) {
+    if (split_reduce) {
+      ARK_HIP_TRY(hipEventRecord(ws.grp_ev[0], stream));
+      ARK_HIP_TRY(hipStreamWaitEvent(ws.side, ws.grp_ev[0], 0));
+    }
     ARK_HIP_TRY(hipStreamWaitEvent(stream, ws.grp_ev[1], 0));
+    if (split_reduce) {
+      reduce_windows(0, (size_t)grp[0].Wg, ws.side);
+      ARK_HIP_TRY(hipEventRecord(ws.grp_ev[1], ws.side));
+    }
     if (int rc = accumulate_group(grp[1], stream)) return rc;
   }
   if (timing) ARK_HIP_TRY(hipEventRecord(job.ev[4], stream));
@@ -1528,21 +1567,13 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     return slot;
   }
 
-  constexpr u32 LNr = C::FA::LANES;
-  hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * Wr * LNr + 127) / 128)), dim3(128), 0, stream,
-                     (const char*)d_buckets, L0, (u32)(m * Wr), (char*)ws.lvlS[0].p, (char*)ws.lvlA[0].p);
-  {
-    constexpr size_t ACCBr = AccOps<C>::ACC_BYTES;
-    const u32 rthreads = ACCBr * (256 / LNr) > 49152 ? 128 : 256;  // LDS tree within 48 KiB
-    hipLaunchKernelGGL((msm_reduce_bits_kernel<C>), dim3(nchunks, Q, Wr), dim3(rthreads), (rthreads / LNr) * ACCBr, stream,
-                       (const char*)ws.lvlS[0].p, (const char*)ws.lvlA[0].p, (u32)m, nbits, chunk, (char*)ws.lvlS[1].p);
+  if (split_reduce) {
+    reduce_windows((size_t)grp[1].w0, (size_t)grp[1].Wg, stream);
+    ARK_HIP_TRY(hipStreamWaitEvent(stream, ws.grp_ev[1], 0));   // group 0's sums
+  } else {
+    reduce_windows(0, (size_t)Wr, stream);
   }
-  const char* d_sums = (const char*)ws.lvlS[1].p;
-  if (nchunks > 1) {
-    hipLaunchKernelGGL((msm_sum_chunks_kernel<C>), dim3((u32)npairs), dim3(64), (64 / LNr) * AccOps<C>::ACC_BYTES, stream,
-                       (const char*)ws.lvlS[1].p, (u32)npairs, nchunks, (char*)ws.lvlA[1].p);
-    d_sums = (const char*)ws.lvlA[1].p;
-  }
+  const char* d_sums = two_level ? (const char*)ws.lvlA[1].p : (const char*)ws.lvlS[1].p;
   ARK_HIP_TRY(hipGetLastError());
   ARK_HIP_TRY(hipMemcpyAsync(job.pinned, d_sums, npairs * Pt::BYTES, hipMemcpyDeviceToHost, stream));
   ARK_HIP_TRY(hipMemcpyAsync((char*)job.pinned + npairs * Pt::BYTES, (const u32*)ws.hctr.p + 3, 4, hipMemcpyDeviceToHost, stream));

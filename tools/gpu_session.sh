@@ -61,7 +61,7 @@ for step in "$@"; do
       for b in algebra_amd/csrc/ubench/mulbench_*.bin; do (echo "== $b"; timeout 120 $b) >> $O/mulbench.txt 2>> $O/mulbench.err; done ;;
     msm)
       for lz in 1 0; do
-        (echo "== ARK_HIP_MSM_LAZY=$lz"; ARK_HIP_MSM_LAZY=$lz timeout 600 python tools/msm_bench.py ${a[1]} ${a[2]} ${a[4]:-3} ${a[3]:-plain}) >> $O/msm.txt 2>> $O/msm.err
+        (echo "== ARK_HIP_MSM_LAZY=$lz ARK_HIP_MSM_GROUPS=$ARK_HIP_MSM_GROUPS"; ARK_HIP_MSM_LAZY=$lz timeout 600 python tools/msm_bench.py ${a[1]} ${a[2]} ${a[4]:-3} ${a[3]:-plain}) >> $O/msm.txt 2>> $O/msm.err
       done ;;
     fft)
       for lz in 1 0; do
