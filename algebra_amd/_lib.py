@@ -144,7 +144,12 @@ def lib():
             pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(l, name)  # AttributeError if the library does not export it
+            try:
+                fn = getattr(l, name)  # AttributeError if the library does not export it
+            except AttributeError:
+                if os.environ.get("ARK_HIP_LIB"):   # an A/B build of an older revision (tools/): its entries only
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = l

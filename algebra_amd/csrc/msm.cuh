@@ -624,7 +624,15 @@ __global__ void __launch_bounds__(128) msm_table_step_kernel(const char* __restr
 // many equal scalars) would pin one lane for its whole length.  Buckets above `thresh` are skipped by
 // the lane-per-bucket kernel, cut into chunks of HEAVY_CHUNK entries, each chunk summed by one
 // wave (64 lanes striding + LDS tree), and the chunk partials combined per bucket.
-static constexpr u32 HEAVY_CHUNK = 2048;
+#ifndef ARK_HEAVY_CHUNK
+#define ARK_HEAVY_CHUNK 1024          // entries per wave of msm_heavy_partial_kernel: 16 serial additions per lane + the wave's
+                                      // LDS tree (2048 / 64 lanes before: bool 1.85 -> 1.71 ms, u8 1.42 -> 1.21, msm_u8 1.20 -> 0.96
+                                      // at 2^20 with the 128-lane combine below; 512 / 256 measured between the two -- profiles/r4_heavy_geometry_ab.txt)
+#endif
+#ifndef ARK_HEAVY_COMBINE_THREADS
+#define ARK_HEAVY_COMBINE_THREADS 128 // workgroup of msm_heavy_combine_kernel: one per heavy run
+#endif
+static constexpr u32 HEAVY_CHUNK = ARK_HEAVY_CHUNK;
 struct HeavyEntry { u32 bucket, first_item, items; };
 
 // A run is "heavy" when one lane walking it (~28 us per entry) would outlast the whole accumulate kernel, whose
@@ -786,14 +794,14 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
 // SHARED (prepared base set): the result goes to hfinal[slot] and its index into sorted[run start], where the lane
 // that owns the bucket picks it up (msm_apply_heavy_kernel); else straight into the (window, bucket) cell.
 template <class C, bool SHARED>
-__global__ void __launch_bounds__(64) msm_heavy_combine_kernel(const u32* __restrict__ ctr,
+__global__ void __launch_bounds__(ARK_HEAVY_COMBINE_THREADS) msm_heavy_combine_kernel(const u32* __restrict__ ctr,
                                                                const HeavyEntry* __restrict__ list,
                                                                const char* __restrict__ partials, int HB, int LB,
                                                                const u32* __restrict__ offsets, u32* __restrict__ sorted,
                                                                int accum, char* __restrict__ buckets) {
   typedef AccOps<C> Ops;
   typedef typename Ops::Pt Pt;
-  constexpr u32 NS = 64 / Ops::LANES;
+  constexpr u32 NS = ARK_HEAVY_COMBINE_THREADS / Ops::LANES;
   extern __shared__ uint4 heavy_lds[];
   char* sh = (char*)heavy_lds;
   const u32 slot = threadIdx.x / Ops::LANES;
@@ -1472,10 +1480,10 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                        (const char*)d_points, G.sorted, G.offsets, G.hctr, (const uint2*)G.hitems, wstride, Bbits, G.hpart);
     const u32 combine_grid = G.max_heavy < 16384 ? (u32)G.max_heavy : 16384u;  // grid-stride over the heavy runs
     if (pl.shared)
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, st, G.hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(ARK_HEAVY_COMBINE_THREADS), (ARK_HEAVY_COMBINE_THREADS / LN) * ACCB, st, G.hctr,
                          (const HeavyEntry*)G.hlist, (const char*)G.hpart, HB, LB, G.offsets, G.sorted, 0, (char*)ws.hfinal.p);
     else
-      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(64), (64 / LN) * ACCB, st, G.hctr,
+      hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(ARK_HEAVY_COMBINE_THREADS), (ARK_HEAVY_COMBINE_THREADS / LN) * ACCB, st, G.hctr,
                          (const HeavyEntry*)G.hlist, (const char*)G.hpart, HB, LB, G.offsets, G.sorted, accum, G.buckets);
     if (pl.shared) {
       if constexpr (C::LAZY_A) {

@@ -67,6 +67,10 @@ for step in "$@"; do
       for lz in 1 0; do
         (echo "== ARK_HIP_FFT_LAZY=$lz"; ARK_HIP_FFT_LAZY=$lz timeout 600 python tools/fft_shapes.py ${a[1]:-16} ${a[2]:-24}) >> $O/fft.txt 2>> $O/fft.err
       done ;;
+    pyv)   # pyv:SCRIPT[:ARGS]: python tools/SCRIPT on the shipped library and on every algebra_amd/variants/*.so
+      for v in algebra_amd/libark_hip.so $(ls algebra_amd/variants/*.so); do
+        (echo "== $v ${a[@]:1}"; ARK_HIP_LIB=$PWD/$v timeout 900 python tools/${a[1]} ${a[@]:2}) >> $O/pyv_${a[1]%.py}.txt 2>> $O/pyv_${a[1]%.py}.err
+      done ;;
     fftv)
       for v in algebra_amd/libark_hip.so $(ls algebra_amd/variants/*.so); do
         (echo "== $v"; ARK_HIP_LIB=$PWD/$v timeout 600 python tools/fft_shapes.py ${a[1]:-20} ${a[2]:-24}) >> $O/fftv.txt 2>> $O/fftv.err
