@@ -225,6 +225,8 @@ struct Context {
   hipEvent_t comm_ev[2][COMM_MAX_SLICES] = {};
   DevBuf comm_tmp, comm_small;         // receive side of the FFT exchange; MSM partials
   void* comm_pinned = nullptr;         // host mirror of comm_small
+  DevBuf comm_sums;                    // sharded MSM: [send block | world receive blocks | summed parts] (msm_sharded_sums)
+  void* comm_sums_pinned = nullptr;    // host side: [my header | world headers | summed parts]
   bool msm_timing = false, fft_timing = false;
   MsmTimings msm_tm;
   FftTimings fft_tm;
@@ -339,6 +341,16 @@ int msm_enqueue_dispatch(int curve, MsmWorkspace& ws, const void* pts, size_t ws
 }
 int msm_finish_dispatch(int curve, MsmWorkspace& ws, int slot, uint64_t* out, MsmTimings* tm) {
 #define X(NAME) msm_finish_##NAME(ws, slot, out, tm)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int msm_sum_ranks_dispatch(int curve, const void* d_blocks, int world, size_t block_bytes, uint32_t npairs, void* d_out, hipStream_t st) {
+#define X(NAME) msm_sum_ranks_##NAME(d_blocks, world, block_bytes, npairs, d_out, st)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+int msm_fold_sums_dispatch(int curve, const MsmSumsHeader& h, const void* h_sums, uint64_t* out_xyz) {
+#define X(NAME) msm_fold_sums_##NAME(h, h_sums, out_xyz)
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
@@ -1127,6 +1139,71 @@ size_t msm_stream_step(size_t n) {
   return (n + pieces - 1) / pieces;
 }
 
+
+// ---- sharded MSM: the ranks' PART SUMS are exchanged and added on the device, one host tail for the whole job ----------------
+// (msm.cuh, "one process per GPU: the part sums of all ranks").  A rank's block = 64-byte header + its part sums, padded to
+// a size that depends on the curve only, so that every rank posts the same byte count whatever its plan.  Ranks whose plans
+// differ (unequal shard sizes), an empty shard or more than SUMS_MAX_PARTS parts are seen by EVERY rank in the gathered
+// headers: all of them then take the fallback together -- finished partial results through msm_sharded_combine.
+constexpr uint32_t SUMS_MAX_PARTS = 1024;
+size_t sums_block_bytes(int curve) { return sizeof(MsmSumsHeader) + (size_t)SUMS_MAX_PARTS * CURVES[curve].fe_words * 32; }
+int sums_buffers(Context* c, int curve, int world) {
+  const size_t bb = sums_block_bytes(curve);
+  if (c->comm_sums.cap < bb * (size_t)(world + 2)) {
+    if (int rc = sync_compute(c)) return rc;
+    if (c->comm_sums.ensure(bb * (size_t)(world + 2))) return ARK_HIP_ERR_NOMEM;
+  }
+  // pinned: [MAX_DEV staging headers | MAX_DEV gathered headers | summed parts]
+  if (!c->comm_sums_pinned) ARK_HIP_TRY(hipHostMalloc(&c->comm_sums_pinned, sizeof(MsmSumsHeader) * 2 * MAX_DEV + (size_t)SUMS_MAX_PARTS * 12 * 32));
+  return 0;
+}
+// the enqueued job `slot_full`'s block -> d_block (device), stream-ordered behind the job on lane 0's stream
+int sums_write_block(Context* c, int curve, int slot_full, char* d_block, MsmSumsHeader* h_out, int stage_slot = 0) {
+  MsmWorkspace& ws = c->msm[slot_full / MSM_JOBS];
+  MsmSumsInfo info;
+  const int rc = msm_job_sums(ws, slot_full % MSM_JOBS, &info);
+  if (rc < 0) return ARK_HIP_ERR_ARG;
+  const size_t pb = (size_t)CURVES[curve].fe_words * 32;
+  MsmSumsHeader* hp = (MsmSumsHeader*)c->comm_sums_pinned + stage_slot;   // staging of this block's header (one slot per block
+                                                                          // written in one call: the copies are asynchronous)
+  if (rc == 1 || info.h.npairs == 0 || info.h.npairs > SUMS_MAX_PARTS) {
+    memset(&info.h, 0, sizeof(info.h));   // no usable sums: every rank sees npairs == 0 and falls back
+    info.d_sums = nullptr;
+  }
+  *hp = info.h;
+  *h_out = info.h;
+  ARK_HIP_TRY(hipMemcpyAsync(d_block, hp, sizeof(MsmSumsHeader), hipMemcpyHostToDevice, c->stream));
+  if (info.d_sums) {
+    ARK_HIP_TRY(hipMemcpyAsync(d_block + sizeof(MsmSumsHeader), info.d_sums, (size_t)info.h.npairs * pb, hipMemcpyDeviceToDevice, c->stream));
+    ARK_HIP_TRY(hipMemcpyAsync(d_block + offsetof(MsmSumsHeader, err), (const u32*)ws.hctr.p + 3, 4, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return 0;
+}
+// all `world` blocks sit in d_blocks: add them, bring the sums and the headers to the host, decide.  *agree = the ranks
+// share one plan and out_xyz holds the whole job's result; otherwise the caller takes the fallback.  A scalar-range error on
+// ANY rank is every rank's error.
+int sums_reduce(Context* c, int curve, const MsmSumsHeader& mine, const char* d_blocks, int world, uint64_t* out_xyz, bool* agree) {
+  const size_t bb = sums_block_bytes(curve), pb = (size_t)CURVES[curve].fe_words * 32;
+  char* d_out = (char*)c->comm_sums.p + bb * (size_t)(world + 1);
+  MsmSumsHeader* hh = (MsmSumsHeader*)c->comm_sums_pinned + MAX_DEV;   // the gathered headers
+  char* h_sums = (char*)((MsmSumsHeader*)c->comm_sums_pinned + 2 * MAX_DEV);
+  if (mine.npairs)
+    if (int rc = msm_sum_ranks_dispatch(curve, d_blocks, world, bb, mine.npairs, d_out, c->stream)) return rc;
+  ARK_HIP_TRY(hipMemcpy2DAsync(hh, sizeof(MsmSumsHeader), d_blocks, bb, sizeof(MsmSumsHeader), (size_t)world, hipMemcpyDeviceToHost, c->stream));
+  if (mine.npairs) ARK_HIP_TRY(hipMemcpyAsync(h_sums, d_out, (size_t)mine.npairs * pb, hipMemcpyDeviceToHost, c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  bool same = mine.npairs != 0, err = false;
+  for (int r = 0; r < world; r++) {
+    const MsmSumsHeader& o = hh[r];
+    err |= o.err != 0;
+    same &= o.c == mine.c && o.W == mine.W && o.narrow == mine.narrow && o.shared == mine.shared && o.nbits == mine.nbits &&
+            o.log2L0 == mine.log2L0 && o.Q == mine.Q && o.npairs == mine.npairs;
+  }
+  *agree = same;
+  if (err) return ARK_HIP_ERR_SCALAR_RANGE;
+  if (!same) return 0;
+  return msm_fold_sums_dispatch(curve, mine, h_sums, out_xyz);
+}
 
 // ---- RCCL, opened at run time ------------------------------------------------------------------------------
 // librccl.so.1 by SONAME: a process that already carries a copy (PyTorch ships its own) gets that one, so two RCCL
@@ -2251,25 +2328,84 @@ int ark_hip_comm_destroy(void) {
   return 0;
 }
 
+// local MSM -> exchange of the part sums -> one host tail (all ranks equal plans), or the fallback on finished partials
+static int msm_sharded_finish(Context* c, int curve, int slot_full, uint64_t* out_xyz) {
+  if (!c->comm || c->comm_world == 1) return msm_finish_ctx(c, curve, slot_full, out_xyz);
+  const RcclApi* api = rccl_api();
+  if (!api) {
+    msm_discard_ctx(c, curve, slot_full);
+    return ARK_HIP_ERR_COMM;
+  }
+  const int world = c->comm_world;
+  int rc = sums_buffers(c, curve, world);
+  const size_t bb = sums_block_bytes(curve);
+  char* d_send = (char*)c->comm_sums.p;
+  char* d_recv = d_send + bb;
+  MsmSumsHeader mine{};
+  if (rc == 0) rc = sums_write_block(c, curve, slot_full, d_send, &mine);
+  if (rc) {   // (a local failure before the collective is the caller's to broadcast, as for every sharded entry)
+    msm_discard_ctx(c, curve, slot_full);
+    return rc;
+  }
+  // only the header and the parts a plan can have travel: SUMS_MAX_PARTS bounds the block, the count is what every rank posts
+  ARK_RCCL_TRY(api, api->AllGather(d_send, d_recv, bb, ncclUint8, c->comm, c->stream));
+  bool agree = false;
+  rc = sums_reduce(c, curve, mine, d_recv, world, out_xyz, &agree);
+  if (rc || agree) {
+    msm_discard_ctx(c, curve, slot_full);   // the job's own host tail is not needed
+    return rc;
+  }
+  uint64_t part[36];
+  if (int rc2 = msm_finish_ctx(c, curve, slot_full, part)) return rc2;
+  return msm_sharded_combine(c, curve, part, out_xyz);
+}
 int ark_hip_msm_sw_device_sharded(int curve, const void* d_bases, const void* d_scalars, size_t n_local, int mont,
                                   uint64_t* out_xyz) {
   if (curve < 0 || curve > 4 || !out_xyz || (n_local && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
-  uint64_t part[36];
   int slot = msm_enqueue_ctx(sc.c, curve, d_bases, 0, nullptr, d_scalars, n_local, mont);
   if (slot < 0) return slot;
-  if (int rc = msm_finish_ctx(sc.c, curve, slot, part)) return rc;   // every rank reaches the collective or none: a
-  return msm_sharded_combine(sc.c, curve, part, out_xyz);            // local failure is the caller's to broadcast
+  return msm_sharded_finish(sc.c, curve, slot, out_xyz);   // every rank reaches the collective or none
 }
 int ark_hip_msm_prepared_device_sharded(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n_local, int mont,
                                         uint64_t* out_xyz) {
   if (!bases || !out_xyz) return ARK_HIP_ERR_ARG;
   const PreparedBases* pb = (const PreparedBases*)bases;
-  uint64_t part[36];
-  if (int rc = ark_hip_msm_prepared_device(bases, d_scalars, n_local, mont, part)) return rc;
+  if (n_local > pb->n) return ARK_HIP_ERR_ARG;
   Scope sc;
   if (int rc = sc.enter(pb->logical)) return rc;
-  return msm_sharded_combine(sc.c, pb->curve, part, out_xyz);
+  int slot = msm_enqueue_ctx(sc.c, pb->curve, pb->table.p, pb->n, &pb->plan, d_scalars, n_local, mont);
+  if (slot < 0) return slot;
+  return msm_sharded_finish(sc.c, pb->curve, slot, out_xyz);
+}
+// Test hook: the exchange of msm_sharded_finish with the ranks EMULATED in one process (one GPU): `world` local MSMs run one
+// after the other, each block lands where the all-gather would put it, then the same sum kernel / header check / host tail --
+// or, when the plans differ, the same fallback (partials summed on the host).  *path: 1 = part sums added on the device,
+// 2 = fallback.  Everything but the RCCL call itself.
+int ark_hip_test_msm_sharded_emulated(int curve, int world, const void* const* d_bases, const void* const* d_scalars,
+                                      const size_t* n_local, int mont, uint64_t* out_xyz, int* path) {
+  if (curve < 0 || curve > 4 || world < 1 || world > MAX_DEV || !d_bases || !d_scalars || !n_local || !out_xyz) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  if (int rc = sums_buffers(c, curve, world)) return rc;
+  const size_t bb = sums_block_bytes(curve), pw = (size_t)CURVES[curve].fe_words * 3;
+  char* d_recv = (char*)c->comm_sums.p + bb;
+  std::vector<uint64_t> partials((size_t)world * pw);
+  MsmSumsHeader h0{};
+  for (int r = 0; r < world; r++) {
+    int slot = msm_enqueue_ctx(c, curve, d_bases[r], 0, nullptr, d_scalars[r], n_local[r], mont);
+    if (slot < 0) return slot;
+    MsmSumsHeader h{};
+    int rc = sums_write_block(c, curve, slot, d_recv + (size_t)r * bb, &h, r);
+    if (r == 0) h0 = h;
+    const int rc2 = msm_finish_ctx(c, curve, slot, &partials[(size_t)r * pw]);   // (the fallback's input; also frees the slot)
+    if (rc || rc2) return rc ? rc : rc2;
+  }
+  bool agree = false;
+  if (int rc = sums_reduce(c, curve, h0, d_recv, world, out_xyz, &agree)) return rc;
+  if (path) *path = agree ? 1 : 2;
+  if (agree) return 0;
+  return ark_hip_sw_sum(curve, partials.data(), (size_t)world, out_xyz);
 }
 
 int ark_hip_fft_shard_local_device(int field, const ark_hip_radix2_domain* dom, int rank, int world, void* d_local,

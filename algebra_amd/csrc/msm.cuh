@@ -1154,6 +1154,7 @@ struct MsmJob {
   int nbits = 0, log2L0 = 0;
   u32 Q = 0;
   size_t npairs = 0;
+  const char* d_sums = nullptr;   // the job's part sums in device memory (npairs XYZZ points): read by the sharded combine
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -1592,6 +1593,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   job.log2L0 = log2L0;
   job.Q = Q;
   job.npairs = npairs;
+  job.d_sums = d_sums;
   job.timing = timing;
   job.busy = true;
   return slot;
@@ -1670,7 +1672,7 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     }
   } release{ws, job};
   if (job.empty) {
-    Jac<F>::zero().store(out_xyz);
+    if (out_xyz) Jac<F>::zero().store(out_xyz);
     return 0;
   }
   ARK_HIP_TRY(msm_wait_event(job.done));
@@ -1688,11 +1690,13 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     return 0;
   }
 
-  std::vector<int> off((size_t)Wr + 1);
-  off[0] = 0;
-  for (int w = 0; w < Wr; w++) off[w + 1] = off[w] + msm_window_width(w, c, W, pl.narrow);
-  const Pt total = msm_host_fold<C>((const char*)job.pinned, Q, Wr, nbits, job.log2L0, off.data());
-  xyzz_to_jac<F>(total).store(out_xyz);
+  if (out_xyz) {   // (nullptr: the caller folds sums of its own -- the sharded combine, over all ranks' sums)
+    std::vector<int> off((size_t)Wr + 1);
+    off[0] = 0;
+    for (int w = 0; w < Wr; w++) off[w + 1] = off[w] + msm_window_width(w, c, W, pl.narrow);
+    const Pt total = msm_host_fold<C>((const char*)job.pinned, Q, Wr, nbits, job.log2L0, off.data());
+    xyzz_to_jac<F>(total).store(out_xyz);
+  }
 
   if (tm && job.timing) {
     (void)hipEventElapsedTime(&tm->digits, job.ev[0], job.ev[1]);
@@ -1709,6 +1713,82 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
 
 // Build the table of per-window multiples for a fixed base set: table[w][i] = 2^(offset_w) * bases[i], affine,
 // w < pl.W, row stride n.  `table` must hold pl.W * n affine points.  Asynchronous on `stream`.
+// ---- one process per GPU: the part sums of all ranks, added on the device --------------------------------------------------
+// Every rank's MSM ends in the same array of part sums (per window: the bit-sliced sums U_b and the plain sum A) when the
+// ranks share one plan -- equal shard sizes.  The sharded entries all-gather THOSE (npairs XYZZ points, ~40 KB for 2^24
+// pairs) behind a 64-byte header instead of finished partial results: no rank runs a host tail before the collective, one
+// kernel adds the G copies of every part, and the single host tail runs on the sums of the whole job
+// (variable_base/mod.rs:542-557: the chunk sum, moved in front of the window combine -- elliptic-curve addition commutes).
+struct MsmSumsHeader {   // 64 bytes in front of a rank's part sums; all ranks must agree on every field but `err`
+  int c, W, narrow, shared, nbits, log2L0;
+  u32 Q, npairs;
+  u32 err;               // this rank's scalar-range flag (msm_digits_kernel)
+  u32 pad[7];
+};
+static_assert(sizeof(MsmSumsHeader) == 64, "header layout");
+struct MsmSumsInfo {
+  MsmSumsHeader h;
+  const char* d_sums;
+};
+template <class C>
+__global__ void __launch_bounds__(128) msm_sum_ranks_kernel(const char* __restrict__ blocks, int world, size_t block_bytes,
+                                                            u32 npairs, char* __restrict__ out) {
+  typedef AccOps<C> Ops;
+  typedef typename Ops::Pt Pt;
+  const u32 t = (blockIdx.x * blockDim.x + threadIdx.x) / Ops::LANES;
+  if (t >= npairs) return;
+  typename Ops::Acc acc = Ops::zero();
+  for (int r = 0; r < world; r++) {
+    const Pt x = Pt::load(blocks + (size_t)r * block_bytes + sizeof(MsmSumsHeader) + (size_t)t * Pt::BYTES);
+    Ops::add(acc, x);
+  }
+  Ops::fin(acc).store(out + (size_t)t * Pt::BYTES);
+}
+template <class C>
+int msm_sum_ranks(const void* d_blocks, int world, size_t block_bytes, u32 npairs, void* d_out, hipStream_t stream) {
+  if (npairs == 0) return 0;
+  constexpr u32 LN = C::FA::LANES;
+  hipLaunchKernelGGL((msm_sum_ranks_kernel<C>), dim3((npairs * LN + 127) / 128), dim3(128), 0, stream, (const char*)d_blocks,
+                     world, block_bytes, npairs, (char*)d_out);
+  ARK_HIP_TRY(hipGetLastError());
+  return 0;
+}
+// the host tail over part sums laid out by `h` (host memory): out_xyz = Jacobian limbs
+template <class C>
+int msm_fold_sums(const MsmSumsHeader& h, const void* h_sums, uint64_t* out_xyz) {
+  typedef typename C::F F;
+  MsmPlan pl{};
+  pl.c = h.c;
+  pl.W = h.W;
+  pl.narrow = h.narrow;
+  pl.shared = h.shared != 0;
+  const int Wr = pl.red_windows();
+  std::vector<int> off((size_t)Wr + 1);
+  off[0] = 0;
+  for (int w = 0; w < Wr; w++) off[w + 1] = off[w] + msm_window_width(w, h.c, h.W, h.narrow);
+  const XYZZ<F> total = msm_host_fold<C>((const char*)h_sums, h.Q, Wr, h.nbits, h.log2L0, off.data());
+  xyzz_to_jac<F>(total).store(out_xyz);
+  return 0;
+}
+// geometry + device pointer of an enqueued job's part sums (valid until the slot is finished)
+static inline int msm_job_sums(MsmWorkspace& ws, int slot, MsmSumsInfo* out) {
+  if (slot < 0 || slot >= MSM_JOBS) return -1;
+  const MsmJob& job = ws.jobs[slot];
+  if (!job.busy || job.no_result) return -1;
+  *out = MsmSumsInfo{};
+  if (job.empty) return 1;   // n == 0: no sums (the caller contributes the identity)
+  out->h.c = job.pl.c;
+  out->h.W = job.pl.W;
+  out->h.narrow = job.pl.narrow;
+  out->h.shared = job.pl.shared ? 1 : 0;
+  out->h.nbits = job.nbits;
+  out->h.log2L0 = job.log2L0;
+  out->h.Q = job.Q;
+  out->h.npairs = (u32)job.npairs;
+  out->d_sums = job.d_sums;
+  return 0;
+}
+
 template <class C>
 int msm_prepare_table(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream) {
   typedef typename C::F F;  // d_tmp: n * XYZZ<F>::BYTES of scratch (one unnormalised row)

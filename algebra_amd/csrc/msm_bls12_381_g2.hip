@@ -12,6 +12,10 @@ int msm_enqueue_BLS12_381_G2(MsmWorkspace& ws, const void* d_points, size_t wstr
 int msm_finish_BLS12_381_G2(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
   return msm_finish<BLS12_381_G2>(ws, slot, out_xyz, tm);
 }
+int msm_sum_ranks_BLS12_381_G2(const void* d_blocks, int world, size_t block_bytes, uint32_t npairs, void* d_out, hipStream_t stream) {
+  return msm_sum_ranks<BLS12_381_G2>(d_blocks, world, block_bytes, npairs, d_out, stream);
+}
+int msm_fold_sums_BLS12_381_G2(const MsmSumsHeader& h, const void* h_sums, uint64_t* out_xyz) { return msm_fold_sums<BLS12_381_G2>(h, h_sums, out_xyz); }
 int msm_prepare_BLS12_381_G2(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream) {
   return msm_prepare_table<BLS12_381_G2>(d_bases, n, pl, d_table, d_tmp, stream);
 }

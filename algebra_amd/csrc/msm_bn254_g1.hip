@@ -12,6 +12,10 @@ int msm_enqueue_BN254_G1(MsmWorkspace& ws, const void* d_points, size_t wstride,
 int msm_finish_BN254_G1(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
   return msm_finish<BN254_G1>(ws, slot, out_xyz, tm);
 }
+int msm_sum_ranks_BN254_G1(const void* d_blocks, int world, size_t block_bytes, uint32_t npairs, void* d_out, hipStream_t stream) {
+  return msm_sum_ranks<BN254_G1>(d_blocks, world, block_bytes, npairs, d_out, stream);
+}
+int msm_fold_sums_BN254_G1(const MsmSumsHeader& h, const void* h_sums, uint64_t* out_xyz) { return msm_fold_sums<BN254_G1>(h, h_sums, out_xyz); }
 int msm_prepare_BN254_G1(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream) {
   return msm_prepare_table<BN254_G1>(d_bases, n, pl, d_table, d_tmp, stream);
 }

@@ -178,7 +178,8 @@ def main():
                 D.comm_destroy()
             except Exception:  # noqa: BLE001
                 D._LIB_COMM["world"] = 0
-        exchange = "RCCL inside libark_hip.so (ark_hip_msm_sw_device_sharded)" if ok else \
+        exchange = "RCCL inside libark_hip.so (ark_hip_msm_sw_device_sharded: the ranks' part sums all-gathered, added on the " \
+                   "device, one host tail for the whole job)" if ok else \
             "torch.distributed all_gather (%s backend%s)" % (backend, "; library communicator unavailable: " + why if why else "")
 
     if world == 1:

@@ -356,6 +356,11 @@ int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64
 /* kind: 2 bucket += affine, 3 bucket -= affine, 4 bucket += bucket, 5 bucket double, 6 bucket -> jacobian,
  * 7 affine double_to_bucket.  acc/other/out are arrays of n elements. */
 int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64_t* other, uint64_t* out, size_t n);
+/* test hook: msm_sharded's exchange with the ranks emulated in one process on one GPU (everything but the RCCL call): world
+ * local MSMs, their part sums added on the device, one host tail -- or the fallback when the shards' plans differ.
+ * *path: 1 = device-side sum of the part sums, 2 = fallback (finished partials summed on the host). */
+int ark_hip_test_msm_sharded_emulated(int curve, int world, const void* const* d_bases, const void* const* d_scalars,
+                                      const size_t* n_local, int scalars_are_montgomery, uint64_t* out_xyz, int* path);
 /* HOST-ONLY test hook (no device needed): the serial tail of an MSM (ec/src/scalar_mul/variable_base/mod.rs:489-502, the
  * window combine) as msm_finish runs it.  parts: windows x (nbits + 1) bucket-form points (x | y | zz | zzz), row w =
  * U_(w,0) .. U_(w,nbits-1), A_w; widths: the windows' bit widths.  out = sum_w 2^(off_w) (A_w + 2^log2_l0 sum_b 2^b U_(w,b))
