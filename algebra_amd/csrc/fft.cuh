@@ -491,6 +491,9 @@ struct FftPass29Args {
 #define ARK_FFT29_FENCE
 #endif
 #endif
+#ifndef ARK_FFT29_PARK
+#define ARK_FFT29_PARK 1   // the two sums and the first difference wait in the lane's own LDS slots while the products run: 156 -> 123 VGPRs, four waves per SIMD
+#endif
 #ifndef ARK_FFT29_MIN_WAVES
 #define ARK_FFT29_MIN_WAVES 1   // waves per SIMD the register allocation must leave room for (A/B builds)
 #endif
@@ -662,12 +665,30 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT29_MIN_WAVES) fft_pass29_k
           e1 = A::template dif<4, 1>(x1, x3);
         }
         ARK_FFT29_FENCE;
+#if ARK_FFT29_PARK
+        // the two sums wait in their own LDS slots (this lane's: no barrier) while the two products run: 18 registers less
+        // across the multiply-heavy middle of the block
+        lds_put(idx[it][0], s0);
+        lds_put(idx[it][1], s1);
+        lds_put(idx[it][2], e0);
+        asm volatile("" ::: "memory");
+#endif
         const L d1 = L::mul(e1, A::limbs9(wa1[it][0], wa1[it][1], wa1t[it]));
         ARK_FFT29_FENCE;
+#if ARK_FFT29_PARK
+        asm volatile("" ::: "memory");
+        e0 = lds_get(idx[it][2]);
+#endif
         L y0, y1, y2, y3;
         if (!tail) {
           const L d0 = L::mul(e0, A::limbs9(wa0[it][0], wa0[it][1], wa0t[it]));
           ARK_FFT29_FENCE;
+#if ARK_FFT29_PARK
+          asm volatile("" ::: "memory");
+          s0 = lds_get(idx[it][0]);
+          s1 = lds_get(idx[it][1]);
+          ARK_FFT29_FENCE;
+#endif
           const L w = A::limbs9(wb[it][0], wb[it][1], wbt[it]);
           // second stage, gap lg/2: (s0, s1) and (d0, d1), one twiddle for both
           y0 = A::reduce_sweep(A::sum(s0, s1));
@@ -675,6 +696,11 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT29_MIN_WAVES) fft_pass29_k
           y2 = A::sweep(A::sum(d0, d1));
           y3 = L::mul(A::template dif<2, 1>(d0, d1), w);
         } else {
+#if ARK_FFT29_PARK
+          asm volatile("" ::: "memory");
+          s0 = lds_get(idx[it][0]);
+          s1 = lds_get(idx[it][1]);
+#endif
           const L d0 = e0;                              // value < 7.01, limbs < 3 2^29
           y0 = A::sum(s0, s1);                          // < 12.04
           y1 = A::template dif<7, 2>(s0, s1);           // < 13.02, limbs < 2.5 2^30
