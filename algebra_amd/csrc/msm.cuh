@@ -54,12 +54,11 @@ __host__ __device__ __forceinline__ int msm_window_width(int w, int c, int W, in
 }
 
 // ---- K1: signed-digit recoding -------------------------------------------------------------------
+// The magnitude the digits are taken from: v = min(s, r - s) of scalar i (canonical value; from Montgomery form first
+// when `mont`), S::N + 1 words with a zero on top; returns the sign flip (bit 31) when r - s was used.
 template <class SP>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__ scalars, u32 n, int mont, int c,
-                                                         int W, int narrow, u32* __restrict__ keys,
-                                                         u32* __restrict__ err) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ u32 msm_scalar_magnitude(const u32* __restrict__ scalars, u32 i, int mont, u32* v /*[N+1]*/,
+                                                    u32* __restrict__ err) {
   typedef Fp<SP> S;
   S s = S::load(scalars + (size_t)i * S::N);
   if (mont) s = S::from_mont(s);  // mod.rs:60-62 into_bigint
@@ -69,7 +68,7 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
   // s in [r, 2^BITS): s -= r once (2^BITS < 2r for the three scalar fields), then the fold below applies.
   if constexpr (SP::BITS < 32 * S::N) {
     if ((s.l[S::N - 1] >> (SP::BITS - 32 * (S::N - 1))) != 0) {
-      atomicOr(err, 1u);
+      if (err) atomicOr(err, 1u);
       s = S::zero();
     }
   }
@@ -103,11 +102,49 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__
   for (int k = 0; k < S::N; k++) {
     if (t[k] != s.l[k]) lt = t[k] < s.l[k];
   }
-  u32 v[S::N + 1];
 #pragma unroll
   for (int k = 0; k < S::N; k++) v[k] = lt ? t[k] : s.l[k];
   v[S::N] = 0;
-  const u32 flip = lt ? 0x80000000u : 0u;
+  return lt ? 0x80000000u : 0u;
+}
+
+// K0: width probe of an msm_bigint call.  max over the sampled scalars (every `stride`-th) of the bit length of
+// min(s, r - s) -> atomicMax into *out.  A witness of 0/1 and small values, or the reference's u8 .. u64 bench
+// distributions handed to msm_bigint, occupy the low windows only: planned for 255 bits they leave most windows empty
+// and the few live ones short of buckets for the chip's lanes (u16 at 2^20: 2.1 ms; planned for 17 bits 0.9 ms).
+template <class SP>
+__global__ void __launch_bounds__(256) msm_scalar_bits_kernel(const u32* __restrict__ scalars, u32 n, u32 stride, int mont,
+                                                              u32* __restrict__ out) {
+  typedef Fp<SP> S;
+  u32 bits = 0;
+  for (u64 t = blockIdx.x * blockDim.x + threadIdx.x; t * stride < n; t += (u64)gridDim.x * blockDim.x) {   // grid-stride
+    u32 v[S::N + 1];
+    (void)msm_scalar_magnitude<SP>(scalars, (u32)(t * stride), mont, v, nullptr);   // out of range: magnitude 0, the digits kernel reports it
+#pragma unroll
+    for (int k = 0; k < S::N; k++)
+      if (v[k]) {
+        const u32 b = 32u * (u32)k + 32u - (u32)__builtin_clz(v[k]);
+        bits = b > bits ? b : bits;
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u32 other = (u32)__shfl_xor((int)bits, o);
+    bits = other > bits ? other : bits;
+  }
+  // one same-address atomic per wave serialises (2^18 waves: 3 ms, measured); a wave that cannot raise the maximum only reads it
+  if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+}
+
+template <class SP>
+__global__ void __launch_bounds__(256) msm_digits_kernel(const u32* __restrict__ scalars, u32 n, int mont, int c,
+                                                         int W, int narrow, u32* __restrict__ keys,
+                                                         u32* __restrict__ err) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  typedef Fp<SP> S;
+  u32 v[S::N + 1];
+  const u32 flip = msm_scalar_magnitude<SP>(scalars, i, mont, v, err);
   u32 carry = 0;
   for (int w = 0; w < W; w++) {
     const int cw = msm_window_width(w, c, W, narrow);  // this window's width
@@ -634,6 +671,13 @@ __global__ void __launch_bounds__(128) msm_table_step_kernel(const char* __restr
 #endif
 static constexpr u32 HEAVY_CHUNK = ARK_HEAVY_CHUNK;
 struct HeavyEntry { u32 bucket, first_item, items; };
+// Entries per chunk for a window group with `total` sorted entries: the wave's tree (6 full additions) and the combine
+// kernel's serial walk over a run's partials are fixed costs per chunk, so large inputs take longer chunks -- a 2^23-entry
+// run (half of a 2^24 witness being ones) in 1024-entry chunks leaves 8192 partials to ONE 128-lane combine workgroup
+// (1.03 ms of 71 dependent additions) after a partial kernel that spent a third of its additions in trees.
+__host__ __device__ __forceinline__ u32 msm_heavy_chunk(u32 total) {
+  return total >= (1u << 23) ? 4u * HEAVY_CHUNK : total >= (1u << 22) ? 2u * HEAVY_CHUNK : HEAVY_CHUNK;
+}
 
 // A run is "heavy" when one lane walking it (~28 us per entry) would outlast the whole accumulate kernel, whose
 // throughput-bound duration is (non-zero entries) / 5.5e9 s: threshold = entries / 154 000, at least 64 and at least
@@ -643,8 +687,11 @@ __device__ __forceinline__ u32 msm_heavy_threshold(const u32* __restrict__ offse
   const u32 total = offsets[nslots];
   u32 t = total / 154000u;
   if (t < 64u) t = 64u;
+  // ... and at least 4 x the mean run -- where the slots can fill the chip's lanes at all.  With a few thousand slots
+  // (narrow scalars in one narrow window: msm_u8 with c = 9 has 256) every run is long, none is 4 x the mean, and 256
+  // lanes walking 4096 entries each took 39 ms at 2^20 where the chunked kernels need 0.5 ms.
   const u32 mr = 4u * (total / nslots);
-  if (t < mr) t = mr;
+  if (t < mr && nslots >= 32768u) t = mr;
   return forced ? forced : t;
 }
 
@@ -658,7 +705,8 @@ static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* _
   if (g >= nbuckets) return;
   u32 cnt = offsets[g + 1] - offsets[g];
   if (cnt <= thresh) return;
-  u32 k = (cnt + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
+  const u32 chunk = msm_heavy_chunk(offsets[nbuckets]);
+  u32 k = (cnt + chunk - 1) / chunk;
   u32 first = atomicAdd(&ctr[0], k);
   u32 slot = atomicAdd(&ctr[1], 1u);
   list[slot] = HeavyEntry{g, first, k};
@@ -754,7 +802,7 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
                                                                 const u32* __restrict__ offsets,
                                                                 const u32* __restrict__ ctr,
                                                                 const uint2* __restrict__ items, size_t wstride, int B,
-                                                                char* __restrict__ partials) {
+                                                                u32 nslots, char* __restrict__ partials) {
   typedef AccOps<C> Ops;
   typedef typename Ops::F F;           // the field as it lives in memory (Fp, or the lane-pair Fp2Half)
   typedef typename Ops::Pt Pt;
@@ -763,15 +811,16 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
   const u32 wave = threadIdx.x >> 6, slot = (threadIdx.x & 63) / Ops::LANES, wpb = blockDim.x >> 6;
   char* sh = (char*)heavy_lds + (size_t)wave * NS * Ops::ACC_BYTES;
   const u32 nitems = ctr[0];
+  const u32 chunk = msm_heavy_chunk(offsets[nslots]);   // as msm_find_heavy_kernel cut the runs
   for (u32 first = blockIdx.x * wpb; first < nitems; first += gridDim.x * wpb) {
     const u32 item = first + wave;
     const bool live = item < nitems;
     typename Ops::Acc acc = Ops::zero();
     if (live) {
       uint2 it = items[item];
-      u32 lo = offsets[it.x] + it.y * HEAVY_CHUNK;
+      u32 lo = offsets[it.x] + it.y * chunk;
       u32 hi = offsets[it.x + 1];
-      if (hi > lo + HEAVY_CHUNK) hi = lo + HEAVY_CHUNK;
+      if (hi > lo + chunk) hi = lo + chunk;
       const char* wb = bases + (size_t)(it.x >> B) * wstride * Affine<F>::BYTES;  // prepared set: the window's table
       for (u32 j = lo + slot; j < hi; j += NS) {
         u32 e = sorted[j];
@@ -1018,7 +1067,11 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
   if (env && atoi(env) >= 3 && atoi(env) <= 26) {
     best_c = atoi(env);
   } else {
-    for (int c = 3; c <= (shared ? 25 : 23); c++) {
+    // c <= bits: a window wider than the scalar only adds empty buckets to sort and reduce (msm_u16 at 2^24: the model's
+    // c = 19 took 8.2 ms, c = 17 -- one window of exactly the 2^16 buckets the digits reach -- 4.1 ms;
+    // profiles/r4_narrow_scalars.txt)
+    const int c_max = shared ? 25 : 23;
+    for (int c = 3; c <= (bits < c_max ? (bits < 3 ? 3 : bits) : c_max); c++) {
       int W, narrow;
       msm_window_layout(c, bits, &W, &narrow);
       double nbk = (double)(W - narrow) * (double)(1u << (c - 1)) + (double)narrow * (double)(1u << (c - 2));
@@ -1093,6 +1146,10 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
         // (BLS12-377 G2 2^16: c = 18 3.7 ms against 1.9 ms at c = 17; 2^24 G1: c = 21, 23)
         const int tb = (bits - 1) - (W - 1) * c;
         if (tb >= (shared ? 0 : 1) && tb <= 5) cost *= shared ? 2.0 : 1.4;
+        // narrow scalars (two to five windows): a top window that is more than two bits short of full is a large share
+        // of the work and loses more -- msm_u32 with c = 18 (18 + 15 bits) 12.5 ms at 2^24 against 8.8 ms for the exact
+        // 17 + 16 layout; only a top window that holds nothing but the carry bit (tb = 0: one heavy bucket) is cheap
+        else if (!shared && !fp2 && bits <= 129 && tb > 5 && tb < c - 3) cost *= 1.4;
       }
       if ((size_t)n * (size_t)W >= (1ull << 32)) continue;  // 32-bit sort positions
       if (cost < best) { best = cost; best_c = c; }
@@ -1162,7 +1219,7 @@ static constexpr int MSM_JOBS = 4;
 
 struct MsmWorkspace {
   DevBuf hctr, hlist, hitems, hpart, hfinal, keys, part, thist, toff, sorted, offsets, sums, buckets, lvlS[2], lvlA[2],
-      order, ohist, ooff;
+      order, ohist, ooff, probe, big;
   MsmJob jobs[MSM_JOBS];
   std::mutex mu;
   bool attr_set = false;  // dynamic-LDS opt-in done for this device
@@ -1173,7 +1230,7 @@ struct MsmWorkspace {
     hctr.release(); hlist.release(); hitems.release(); hpart.release(); hfinal.release();
     keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
     offsets.release(); sums.release();
-    order.release(); ohist.release(); ooff.release();
+    order.release(); ohist.release(); ooff.release(); probe.release(); big.release();
     buckets.release();
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; }
     for (auto& e : grp_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -1242,8 +1299,41 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (n >= (1ull << 31)) return -2;
   if (sbytes && (prepared || (sbytes != 1 && sbytes != 2 && sbytes != 4 && sbytes != 8) || sbits < 1 || sbits > 8 * sbytes))
     return -1;
+  // Full-width scalars that are all narrow (K0 above): one 4-byte read-back decides the plan, so the probe runs only
+  // where that round trip (~20 us) is small against the call (n >= 2^18) and nothing else of this workspace is in
+  // flight to wait behind (a pipelined caller keeps the 255-bit plan).  A spread sample of 4096 scalars first: uniform
+  // scalars stop there.  ARK_HIP_MSM_PROBE=0 turns it off.
+  int plan_bits = sbytes ? sbits + 1 : C::S::BITS;
+  if (!sbytes && !prepared && !piece && n >= ((size_t)1 << 18)) {
+    static const bool probe_on = [] {
+      const char* e = getenv("ARK_HIP_MSM_PROBE");
+      return !(e && atoi(e) == 0);
+    }();
+    bool idle = true;
+    for (int i = 0; i < MSM_JOBS; i++) idle = idle && !ws.jobs[i].busy;
+    if (probe_on && idle) {
+      if (ws.probe.ensure(8)) return -3;
+      auto measure = [&](u32 stride, u32* bits) -> int {
+        const u32 cnt = (u32)((n + stride - 1) / stride);
+        ARK_HIP_TRY(hipMemsetAsync(ws.probe.p, 0, 4, stream));
+        const u32 blocks = (cnt + 255) / 256;
+        hipLaunchKernelGGL((msm_scalar_bits_kernel<typename C::S>), dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, stream,
+                           (const u32*)d_scalars, (u32)n, stride, scalars_mont, (u32*)ws.probe.p);
+        ARK_HIP_TRY(hipMemcpyAsync(bits, ws.probe.p, 4, hipMemcpyDeviceToHost, stream));
+        ARK_HIP_TRY(hipStreamSynchronize(stream));
+        return 0;
+      };
+      const int slack = 8;   // fewer than 8 bits saved: not worth a second plan
+      u32 b = 0;
+      if (int rc = measure((u32)(n / 4096), &b)) return rc;
+      if ((int)b + 1 + slack <= C::S::BITS) {
+        if (int rc = measure(1u, &b)) return rc;
+        if ((int)b + 1 + slack <= C::S::BITS) plan_bits = (b ? (int)b : 1) + 1;
+      }
+    }
+  }
   const MsmPlan pl = prepared ? *prepared
-                     : (piece ? *piece->plan : msm_make_plan(n, sbytes ? sbits + 1 : C::S::BITS, msm_mul_cost(C::ID), false, C::LAZY_A));
+                     : (piece ? *piece->plan : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A));
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;                      // sort slots
   const size_t nbk = pl.nbuckets();             // accumulated buckets
@@ -1405,6 +1495,15 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                                     160 * 1024 - 64));
     ws.attr_set = true;
   }
+  // super-buckets too large for one workgroup of pass B (skewed scalars) are finished in slices; below 2^18 keys per
+  // window none can exist (PART_BIG = 2^17 and a window of uniform digits is spread over all its super-buckets anyway)
+  static const bool big_env = [] {
+    const char* e = getenv("ARK_HIP_MSM_BIG_SLICES");
+    return !(e && atoi(e) == 0);
+  }();
+  const bool big_on = big_env && n > (size_t)2 * PART_BIG;
+  const size_t big_region = PART_BIG_LIST + (size_t)nsuper + 2 * nb;   // u32 words per window group (each group's share is smaller)
+  if (big_on && ws.big.ensure(2 * big_region * 4)) return -3;
   bool lazy = false;  // Fp384 G1: the accumulate kernels on carry-free 28-bit limbs (fp28.cuh); ARK_HIP_MSM_LAZY=0: saturated
   if constexpr (C::LAZY_A) lazy = msm_lazy_enabled();
   const int W0 = ngroups == 2 ? (W + 1) / 2 : W;   // windows of group 0
@@ -1412,6 +1511,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     int w0, Wg;
     size_t slot0, nslots, nbk_g;   // first sort slot, sort slots, accumulated buckets
     u32 *keys, *sorted, *offsets, *thist, *toff, *order, *sums, *ohist, *ooff, *hctr;
+    u32* big;                      // sliced pass B (msm_sort.cuh): [count, -, list ..., counters[nslots], cursors[nslots]]
+    size_t big_words;
     uint2* part;
     HeavyEntry* hlist;
     uint2* hitems;
@@ -1437,6 +1538,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     G.ohist = (u32*)ws.ohist.p + (size_t)g * noblk0 * ORDER_BINS;
     G.ooff = (u32*)ws.ooff.p + (size_t)g * (noblk0 * ORDER_BINS + 1);
     G.hctr = (u32*)ws.hctr.p + 4 * g;
+    G.big = big_on ? (u32*)ws.big.p + (size_t)g * big_region : nullptr;
+    G.big_words = PART_BIG_LIST + ((size_t)G.Wg << HB) + 2 * G.nslots;
     const size_t ent0 = (size_t)n * W0;
     const size_t mh0 = ent0 / 64 + 1, mi0 = ent0 / HEAVY_CHUNK + mh0 + 1;   // group 0's share of the heavy-run arrays
     G.max_heavy = g == 0 ? (ngroups == 2 ? mh0 : max_heavy) : max_heavy - mh0;
@@ -1457,7 +1560,17 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, G.Wg), dim3(1024), lds_a, st, G.keys, (u32)n, HB, LB, ntiles,
                        ptile, G.toff, G.part);
     hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper_g), dim3(1024), lds_b, st, G.part, G.toff, ntiles, LB, nsuper_g,
-                       stage_cap, G.offsets, G.sorted);
+                       stage_cap, big_on ? PART_BIG : 0u, G.offsets, G.sorted);
+    if (big_on) {
+      u32* const bigcnt = G.big + PART_BIG_LIST + nsuper_g;
+      u32* const cursor = bigcnt + G.nslots;
+      ARK_HIP_TRY(hipMemsetAsync(G.big, 0, G.big_words * 4, st));
+      hipLaunchKernelGGL(msm_part_big_list_kernel, dim3((nsuper_g + 255) / 256), dim3(256), 0, st, G.toff, ntiles, nsuper_g, G.big);
+      hipLaunchKernelGGL(msm_part_big_hist_kernel, dim3(PART_BIG_SLICES, PART_BIG_GRID_Y), dim3(1024), (size_t)4 << LB, st,
+                         G.part, G.toff, ntiles, LB, G.big, bigcnt);
+      hipLaunchKernelGGL(msm_part_big_place_kernel, dim3(PART_BIG_SLICES, PART_BIG_GRID_Y), dim3(1024),
+                         ((size_t)8 << LB) + 4096, st, G.part, G.toff, ntiles, LB, G.big, bigcnt, cursor, G.offsets, G.sorted);
+    }
     int shift = 0;  // class width 2^shift so that the mean load falls around class 32..63
     while ((mean_load >> shift) >= 64) shift++;
     const u32 noblk_g = (u32)((G.nbk_g + ORDER_TILE - 1) / ORDER_TILE);
@@ -1478,7 +1591,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     constexpr size_t ACCB = AccOps<C>::ACC_BYTES;           // one parked accumulator (the form the kernels sum in)
     const u32 hthreads = ACCB * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
     hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * ACCB, st,
-                       (const char*)d_points, G.sorted, G.offsets, G.hctr, (const uint2*)G.hitems, wstride, Bbits, G.hpart);
+                       (const char*)d_points, G.sorted, G.offsets, G.hctr, (const uint2*)G.hitems, wstride, Bbits, (u32)G.nslots, G.hpart);
     const u32 combine_grid = G.max_heavy < 16384 ? (u32)G.max_heavy : 16384u;  // grid-stride over the heavy runs
     if (pl.shared)
       hipLaunchKernelGGL((msm_heavy_combine_kernel<C, true>), dim3(combine_grid), dim3(ARK_HEAVY_COMBINE_THREADS), (ARK_HEAVY_COMBINE_THREADS / LN) * ACCB, st, G.hctr,

@@ -52,6 +52,14 @@ static inline void msm_part_split(size_t n, int B, int* HB, int* LB) {
       const int v = atoi(e);
       if (v >= 0 && v <= B && B - v <= PART_LO_BITS_MAX) hb = v;
     }
+  } else {
+    // few buckets per window (narrow scalars: msm_u8 plans ONE window of 2^8): still split, or a single workgroup of
+    // pass B finishes the whole window (2^24 keys through one CU)
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    hb = lg - 15;
+    if (hb < 0) hb = 0;
+    if (hb > B) hb = B;
   }
   *HB = hb;
   *LB = B - hb;
@@ -223,12 +231,33 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
   }
 }
 
+// LDS counter increment with the lanes that share the wave's LEADING key combined into one atomic.  Uniform digits
+// put one or two lanes of a wave on the same counter and this costs a compare and a ballot; skewed scalars (a
+// witness of mostly 0/1 values, the carry bucket of unsigned 16/32-bit scalars) put a whole wave on ONE counter,
+// where 64 same-address LDS atomics serialise: the finish kernel of a 2^19-entry single-bucket super-bucket took
+// 0.88 ms that way, 1.5 M serialised atomics (profiles/r4_skewed_sort_ab.txt).  Returns the slot the lane received;
+// call with all lanes that hold a key (divergent callers are fine: the ballot only sees the active lanes).
+__device__ __forceinline__ u32 lds_inc_leading(u32* cnt, u32 key) {
+  const u32 k0 = __builtin_amdgcn_readfirstlane(key);
+  const unsigned long long same = __ballot(key == k0);
+  u32 pos;
+  if (key == k0) {
+    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(same >> 32), __builtin_amdgcn_mbcnt_lo((u32)same, 0u));
+    u32 base = 0;
+    if (rank == 0) base = atomicAdd(&cnt[k0], (u32)__popcll(same));
+    pos = __builtin_amdgcn_readfirstlane(base) + rank;   // the first active lane here is the rank-0 lane
+  } else {
+    pos = atomicAdd(&cnt[key], 1u);
+  }
+  return pos;
+}
+
 // B: one workgroup per super-bucket sb = (w << HB | low bits): bucket SLOTS sb << LB | high bits.  The sorted indices
 // of the super-bucket are assembled in LDS and written out linearly; a super-bucket larger than the
 // staging area (skewed scalars) falls back to direct placement.  Dynamic LDS: (2^LB + 1024 + stage_cap) words.
 static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint2* __restrict__ part,
                                                                       const u32* __restrict__ tile_off, u32 ntiles,
-                                                                      int LB, u32 nsuper, u32 stage_cap,
+                                                                      int LB, u32 nsuper, u32 stage_cap, u32 big_thresh,
                                                                       u32* __restrict__ offsets,
                                                                       u32* __restrict__ sorted) {
   extern __shared__ u32 part_lds[];
@@ -239,6 +268,8 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
   const u32 sb = blockIdx.x;
   const u32 start = tile_off[(size_t)sb * ntiles];
   const u32 end = tile_off[(size_t)(sb + 1) * ntiles];  // tile_off has nsuper * ntiles + 1 entries
+  if (sb == nsuper - 1 && threadIdx.x == 0) offsets[(size_t)nsuper << LB] = end;
+  if (big_thresh && end - start > big_thresh) return;   // left to the sliced kernels below
   for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
   const u32 lmask = nlow - 1u;
@@ -251,7 +282,7 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
     }
 #pragma unroll
     for (int b = 0; b < PART_MLP; b++)
-      if (kx[b] != PART_KEY_NONE) atomicAdd(&cnt[kx[b] & lmask], 1u);
+      if (kx[b] != PART_KEY_NONE) lds_inc_leading(cnt, kx[b] & lmask);
   }
   __syncthreads();
   // exclusive scan of cnt[0..nlow): lane t owns `per` consecutive bins (nlow <= 4096, blockDim = 1024)
@@ -277,7 +308,6 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
       run += c;
     }
   }
-  if (sb == nsuper - 1 && threadIdx.x == 0) offsets[(size_t)nsuper << LB] = end;
   __syncthreads();
   const u32 total = end - start;
   if (total <= stage_cap) {
@@ -291,7 +321,7 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
 #pragma unroll
       for (int b = 0; b < PART_MLP; b++) {
         if (e[b].x != PART_KEY_NONE) {
-          const u32 pos = atomicAdd(&cnt[e[b].x & lmask], 1u);
+          const u32 pos = lds_inc_leading(cnt, e[b].x & lmask);
           stage[pos] = e[b].y | (e[b].x & 0x80000000u);
         }
       }
@@ -301,10 +331,155 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
   } else {
     for (u32 j = start + threadIdx.x; j < end; j += blockDim.x) {
       uint2 e = part[j];
-      u32 pos = atomicAdd(&cnt[e.x & lmask], 1u);
+      u32 pos = lds_inc_leading(cnt, e.x & lmask);
       sorted[start + pos] = e.y | (e.x & 0x80000000u);
     }
   }
 }
+
+// ---- pass B for a super-bucket too large for one workgroup ---------------------------------------------------------
+// Skewed scalars concentrate a window's keys in a few buckets -- a witness whose values are mostly 1 sends n/2 keys to
+// bucket 1 of window 0 -- and the super-bucket that holds such a bucket would stream all of them through ONE CU twice
+// (2^23 entries: 5.0 ms at 2^24, the largest kernel of that MSM; profiles/r4_skewed_sort_ab.txt).  Super-buckets above
+// PART_BIG entries are listed, and each is finished by PART_BIG_SLICES workgroups over contiguous slices:
+//   big_hist    slice histogram in LDS -> atomicAdd into the super-bucket's global counters
+//   big_place   every slice scans the global counters (-> bucket offsets, written by slice 0), counts its slice again,
+//               reserves its share of every bucket with one global atomic per non-empty bucket, and places its entries.
+// The order inside a bucket depends on the order the slices reserve in -- unspecified already (see the header).
+static constexpr u32 PART_BIG = 1u << 17;
+static constexpr u32 PART_BIG_SLICES = 16;
+static constexpr u32 PART_BIG_GRID_Y = 32;     // listed super-buckets are walked with this stride
+static constexpr u32 PART_BIG_LIST = 16;       // word offset of the list in the `big` array ([0] = count)
+
+static __global__ void __launch_bounds__(256) msm_part_big_list_kernel(const u32* __restrict__ tile_off, u32 ntiles,
+                                                                       u32 nsuper, u32* __restrict__ big) {
+  const u32 sb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sb >= nsuper) return;
+  const u32 total = tile_off[(size_t)(sb + 1) * ntiles] - tile_off[(size_t)sb * ntiles];
+  if (total > PART_BIG) big[PART_BIG_LIST + atomicAdd(&big[0], 1u)] = sb;
+}
+
+// slice s of [start, end)
+__device__ __forceinline__ void msm_part_big_slice(u32 start, u32 end, u32* lo, u32* hi) {
+  const u32 total = end - start;
+  const u32 per = (total + PART_BIG_SLICES - 1) / PART_BIG_SLICES;
+  const u32 a = blockIdx.x * per, b = a + per;
+  *lo = start + (a < total ? a : total);
+  *hi = start + (b < total ? b : total);
+}
+
+static __global__ void __launch_bounds__(1024) msm_part_big_hist_kernel(const uint2* __restrict__ part,
+                                                                        const u32* __restrict__ tile_off, u32 ntiles, int LB,
+                                                                        const u32* __restrict__ big,
+                                                                        u32* __restrict__ bigcnt) {
+  extern __shared__ u32 part_lds[];   // [nlow]
+  const u32 nbig = big[0];
+  const u32 nlow = 1u << LB, lmask = nlow - 1u;
+  for (u32 k = blockIdx.y; k < nbig; k += gridDim.y) {
+    const u32 sb = big[PART_BIG_LIST + k];
+    u32 lo, hi;
+    msm_part_big_slice(tile_off[(size_t)sb * ntiles], tile_off[(size_t)(sb + 1) * ntiles], &lo, &hi);
+    for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) part_lds[b] = 0;
+    __syncthreads();
+    for (u32 c0 = lo; c0 < hi; c0 += blockDim.x * PART_MLP) {
+      u32 kx[PART_MLP];
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++) {
+        const u32 j = c0 + (u32)b * blockDim.x + threadIdx.x;
+        kx[b] = j < hi ? part[j].x : PART_KEY_NONE;
+      }
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++)
+        if (kx[b] != PART_KEY_NONE) lds_inc_leading(part_lds, kx[b] & lmask);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < nlow; b += blockDim.x)
+      if (part_lds[b]) atomicAdd(&bigcnt[((size_t)sb << LB) + b], part_lds[b]);
+    __syncthreads();
+  }
+}
+
+static __global__ void __launch_bounds__(1024) msm_part_big_place_kernel(const uint2* __restrict__ part,
+                                                                         const u32* __restrict__ tile_off, u32 ntiles, int LB,
+                                                                         const u32* __restrict__ big,
+                                                                         const u32* __restrict__ bigcnt,
+                                                                         u32* __restrict__ cursor, u32* __restrict__ offsets,
+                                                                         u32* __restrict__ sorted) {
+  extern __shared__ u32 part_lds[];
+  const u32 nbig = big[0];
+  const u32 nlow = 1u << LB, lmask = nlow - 1u;
+  u32* cnt = part_lds;            // [nlow]  the super-bucket's counters -> bucket starts
+  u32* wsum = part_lds + nlow;    // [1024]
+  u32* mine = wsum + 1024;        // [nlow]  this slice's counters -> its placement cursors
+  for (u32 k = blockIdx.y; k < nbig; k += gridDim.y) {
+    const u32 sb = big[PART_BIG_LIST + k];
+    const u32 start = tile_off[(size_t)sb * ntiles];
+    u32 lo, hi;
+    msm_part_big_slice(start, tile_off[(size_t)(sb + 1) * ntiles], &lo, &hi);
+    for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) {
+      cnt[b] = bigcnt[((size_t)sb << LB) + b];
+      mine[b] = 0;
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..nlow), as in msm_part_finish_kernel
+    const u32 per = nlow > blockDim.x ? nlow / blockDim.x : 1u;
+    const u32 b0 = threadIdx.x * per;
+    u32 v = 0;
+    if (b0 < nlow)
+      for (u32 q = 0; q < per; q++) v += cnt[b0 + q];
+    wsum[threadIdx.x] = v;
+    __syncthreads();
+    for (u32 o = 1; o < blockDim.x; o <<= 1) {
+      u32 y = threadIdx.x >= o ? wsum[threadIdx.x - o] : 0;
+      __syncthreads();
+      wsum[threadIdx.x] += y;
+      __syncthreads();
+    }
+    if (b0 < nlow) {
+      u32 run = wsum[threadIdx.x] - v;
+      for (u32 q = 0; q < per; q++) {
+        const u32 c = cnt[b0 + q];
+        cnt[b0 + q] = run;
+        if (blockIdx.x == 0) offsets[((size_t)sb << LB) + b0 + q] = start + run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    for (u32 c0 = lo; c0 < hi; c0 += blockDim.x * PART_MLP) {
+      u32 kx[PART_MLP];
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++) {
+        const u32 j = c0 + (u32)b * blockDim.x + threadIdx.x;
+        kx[b] = j < hi ? part[j].x : PART_KEY_NONE;
+      }
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++)
+        if (kx[b] != PART_KEY_NONE) lds_inc_leading(mine, kx[b] & lmask);
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) {
+      const u32 m = mine[b];
+      if (m) mine[b] = cnt[b] + atomicAdd(&cursor[((size_t)sb << LB) + b], m);
+    }
+    __syncthreads();
+    for (u32 c0 = lo; c0 < hi; c0 += blockDim.x * PART_MLP) {
+      uint2 e[PART_MLP];
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++) {
+        const u32 j = c0 + (u32)b * blockDim.x + threadIdx.x;
+        e[b] = j < hi ? part[j] : make_uint2(PART_KEY_NONE, 0u);
+      }
+#pragma unroll
+      for (int b = 0; b < PART_MLP; b++) {
+        if (e[b].x != PART_KEY_NONE) {
+          const u32 pos = lds_inc_leading(mine, e[b].x & lmask);
+          sorted[start + pos] = e[b].y | (e[b].x & 0x80000000u);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 
 }  // namespace arkhip

@@ -1,0 +1,160 @@
+"""Narrow and skewed scalars at sizes where the planner's narrow-scalar choices, the width probe of msm_bigint, the
+heavy-run kernels and the wave-aggregated sort counters are live (n >= 2^18): the distributions of the reference's MSM
+bench (bench-templates/src/macros/ec.rs:222-372 -- bool, u8, u16, u32, u64, their signed forms, the mixed vector) and
+witness-like vectors (mostly 0 / 1 with a few full-width values), through msm_bigint (device-resident and Montgomery
+form) and the msm_u* entries, each against k*G with k = sum s_i (a + i b) in closed form and k*G from the ORACLE."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import algebra_amd as A
+from algebra_amd import curves as cv
+import oracle_lib as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import synth as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+LOGN = 19
+
+
+@pytest.fixture(scope="module", params=["BLS12_381_G1", "BN254_G1", "BLS12_377_G2"])
+def setup(request):
+    import torch
+    name = request.param
+    cid = O.CID[name]
+    r = S.R[cv.scalar_field(cid)]
+    n = 1 << (LOGN if "G2" not in name else LOGN - 1)
+    bases = S.grow_bases(cid, n, S.A0, S.B0, r)
+    yield {"cid": cid, "r": r, "n": n, "bases": bases}
+    del bases
+    torch.cuda.empty_cache()
+
+
+def _kg(cid, sc, r):
+    k = S.dlog_of_msm(sc, S.A0, S.B0, r)
+    return O.to_affine(cid, O.scalar_mul(cid, O.generator(cid), S.limbs4(k)))
+
+
+def _limbs(vals):
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for k in range(4):
+        out[:, k] = [(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for v in vals]
+    return out
+
+
+def _unsigned(rng, n, bits):
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    sc[:, 0] = rng.integers(0, 1 << min(bits, 63), size=n, dtype=np.uint64)
+    if bits == 64:
+        sc[:, 0] |= rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63)
+    return sc
+
+
+def _wide(rng, n, bits):
+    """uniform in [0, 2^bits), bits up to 250"""
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    for k in range(4):
+        take = max(0, min(64, bits - 64 * k))
+        if take:
+            v = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) | (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63))
+            sc[:, k] = v if take == 64 else v & np.uint64((1 << take) - 1)
+    return sc
+
+
+def _run_bigint(s, sc, mont=False):
+    import torch
+    d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+    if mont:
+        return A.into_affine(s["cid"], A.msm_unchecked(s["cid"], s["bases"], d))
+    return A.into_affine(s["cid"], A.msm_bigint(s["cid"], s["bases"], d))
+
+
+@pytest.mark.parametrize("bits", [0, 1, 8, 16, 17, 32, 64, 100, 200, 246])
+def test_msm_bigint_with_scalars_of_bounded_width(setup, bits):
+    """the probe plans for the measured width (bits + 1 windows' worth): all-zero, bool, ..., and widths around the
+    slack below which the 255-bit plan is kept"""
+    s = setup
+    rng = np.random.default_rng(1000 + bits)
+    sc = np.zeros((s["n"], 4), dtype=np.uint64) if bits == 0 else (_unsigned(rng, s["n"], bits) if bits <= 64 else _wide(rng, s["n"], bits))
+    got = _run_bigint(s, sc)
+    assert np.array_equal(got, _kg(s["cid"], sc, s["r"]))
+
+
+@pytest.mark.parametrize("bits", [1, 8, 16, 32])
+def test_msm_bigint_signed_small_values(setup, bits):
+    """iN::rand as Scalar::from(negative) = r - |x| (ec.rs:252-330): folded to |x| with the point negated"""
+    s = setup
+    r = s["r"]
+    rng = np.random.default_rng(2000 + bits)
+    mag = rng.integers(0, 1 << bits, size=s["n"], dtype=np.uint64)
+    neg = rng.integers(0, 2, size=s["n"]).astype(bool)
+    sc = _limbs([(r - int(m)) % r if ng else int(m) for m, ng in zip(mag, neg)])
+    assert np.array_equal(_run_bigint(s, sc), _kg(s["cid"], sc, r))
+
+
+def test_one_wide_scalar_keeps_the_full_plan(setup):
+    """2^19 - 1 small scalars and ONE full-width one at an index the 4096-scalar sample does not visit: the full pass of
+    the probe sees it"""
+    s = setup
+    rng = np.random.default_rng(7)
+    sc = _unsigned(rng, s["n"], 8)
+    sc[12345] = S.gen_scalars(1, 99, s["r"])[0]
+    assert np.array_equal(_run_bigint(s, sc), _kg(s["cid"], sc, s["r"]))
+
+
+def test_witness_like_vector(setup):
+    """60 % zeros, 30 % ones, 5 % minus one, the rest full width: one giant bucket in window 0 (sort counters combined
+    per wave, heavy-run kernels) next to uniformly loaded ones"""
+    s = setup
+    r = s["r"]
+    rng = np.random.default_rng(11)
+    n = s["n"]
+    sc = S.gen_scalars(n, 0x77, r)
+    u = rng.random(n)
+    sc[u < 0.60] = 0
+    one = np.zeros(4, dtype=np.uint64)
+    one[0] = 1
+    sc[(u >= 0.60) & (u < 0.90)] = one
+    sc[(u >= 0.90) & (u < 0.95)] = _limbs([r - 1])[0]
+    assert np.array_equal(_run_bigint(s, sc), _kg(s["cid"], sc, r))
+
+
+def test_montgomery_form_narrow_scalars(setup):
+    """the trait path hands Fr elements in Montgomery form: the probe converts before measuring"""
+    s = setup
+    rng = np.random.default_rng(13)
+    sc = _unsigned(rng, s["n"], 16)
+    R = (1 << 256) % s["r"]
+    mont = _limbs([(int(v) * R) % s["r"] for v in sc[:, 0]])
+    assert np.array_equal(_run_bigint(s, mont, mont=True), _kg(s["cid"], sc, s["r"]))
+
+
+@pytest.mark.parametrize("name,dtype,bits", [("msm_u1", np.uint8, 1), ("msm_u8", np.uint8, 8), ("msm_u16", np.uint16, 16),
+                                             ("msm_u32", np.uint32, 32), ("msm_u64", np.uint64, 64)])
+def test_narrow_entries_at_size(setup, name, dtype, bits):
+    """msm_u1 .. msm_u64 (variable_base/mod.rs:87-117) with the narrow planner's layouts (c <= bits + 1)"""
+    import torch
+    s = setup
+    rng = np.random.default_rng(3000 + bits)
+    sc = _unsigned(rng, s["n"], bits)
+    sg = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[np.dtype(dtype).itemsize]
+    d = torch.from_numpy(np.ascontiguousarray(sc[:, 0].astype(dtype)).view(sg)).cuda()
+    got = A.into_affine(s["cid"], getattr(A, name)(s["cid"], s["bases"], d))
+    assert np.array_equal(got, _kg(s["cid"], sc, s["r"]))
+
+
+def test_probe_off_gives_the_same_point(setup, monkeypatch):
+    """ARK_HIP_MSM_PROBE is read once per process, so the comparison is against the narrow ENTRY (planned for 16 bits
+    without any probe) and the closed form"""
+    import torch
+    s = setup
+    rng = np.random.default_rng(17)
+    sc = _unsigned(rng, s["n"], 16)
+    d16 = torch.from_numpy(np.ascontiguousarray(sc[:, 0].astype(np.uint16)).view(np.int16)).cuda()
+    a = _run_bigint(s, sc)
+    b = A.into_affine(s["cid"], A.msm_u16(s["cid"], s["bases"], d16))
+    assert np.array_equal(a, b) and np.array_equal(a, _kg(s["cid"], sc, s["r"]))

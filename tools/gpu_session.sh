@@ -38,6 +38,12 @@ for step in "$@"; do
       cd $R
       python tools/rocpd_stats.py $(db p_kt) --min-us 100 > $O/kernel_stats.txt 2>> $O/post.err
       rm -rf $O/p_kt ;;
+    ktpy)   # ktpy:SCRIPT[:ARGS]: kernel trace of python tools/SCRIPT ARGS -> kernel_stats_SCRIPT_ARGS.txt
+      cd /tmp
+      timeout 600 rocprofv3 --kernel-trace -d $O/p_ktpy -o kt -- python $R/tools/${a[1]} ${a[@]:2} >> $O/ktpy.out 2>> $O/ktpy.err
+      cd $R
+      python tools/rocpd_stats.py $(db p_ktpy) --min-us 20 > $O/kernel_stats_${a[1]%.py}_$(echo ${a[@]:2} | tr ' ' '_')${suffix}.txt 2>> $O/post.err
+      rm -rf $O/p_ktpy ;;
     pmc)
       cd /tmp
       timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/p_fetch -o f -- $SHORT > $O/fetch.out 2> $O/fetch.err

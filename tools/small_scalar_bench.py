@@ -52,7 +52,7 @@ def main():
         s = n // 11
         parts = []
         for bits in (1, 8, 16, 32, 64):
-            v = rng.integers(0, 1 << min(bits, 63), size=s, dtype=np.uint64)
+            v = rng.integers(0, 1 << bits, size=s, dtype=np.uint64)
             pos = np.zeros((s, 4), dtype=np.uint64)
             pos[:, 0] = v
             parts.append(pos)
@@ -63,7 +63,7 @@ def main():
 
     cases = [("random", S.gen_scalars(n, 5, r), None), ("bool", small(1, False), A.msm_u1), ("u8", small(8, False), A.msm_u8),
              ("i8", small(8, True), None), ("u16", small(16, False), A.msm_u16), ("i16", small(16, True), None),
-             ("u32", small(32, False), A.msm_u32), ("i32", small(32, True), None), ("u64", small(63, False), A.msm_u64),
+             ("u32", small(32, False), A.msm_u32), ("i32", small(32, True), None), ("u64", small(64, False), A.msm_u64),
              ("i64", small(64, True), None), ("mixed", mixed(), None)]
     print("# %s 2^%d, device-resident inputs; ms per MSM, every result == k*G" % (curve, logn))
     for name, sc, direct in cases:
