@@ -108,32 +108,68 @@ __device__ __forceinline__ u32 msm_scalar_magnitude(const u32* __restrict__ scal
   return lt ? 0x80000000u : 0u;
 }
 
-// K0: width probe of an msm_bigint call.  max over the sampled scalars (every `stride`-th) of the bit length of
-// min(s, r - s) -> atomicMax into *out.  A witness of 0/1 and small values, or the reference's u8 .. u64 bench
-// distributions handed to msm_bigint, occupy the low windows only: planned for 255 bits they leave most windows empty
-// and the few live ones short of buckets for the chip's lanes (u16 at 2^20: 2.1 ms; planned for 17 bits 0.9 ms).
+// K0: width probe of an msm_bigint call.  Over the sampled scalars (every `stride`-th), with b = the bit length of
+// min(s, r - s):  out[0] <- max b,  out[1 + k] += number of scalars in width class k (MSM_WIDTH_TOP below).  A witness
+// of 0 / 1 and small values, or the reference's u8 .. u64 bench distributions handed to msm_bigint, occupy the low
+// windows only: planned for n full-width scalars they leave most windows empty and most of the 2^(c-1) W buckets -- whose
+// reduction does not shrink with the entries -- unused.  The reference sorts the scalars into the same classes and runs
+// one MSM per class (msm_signed, variable_base/mod.rs:251-336); here ONE pipeline runs, planned for the measured classes.
+static constexpr int MSM_WIDTH_CLASSES = 9;
+static constexpr int MSM_WIDTH_TOP[MSM_WIDTH_CLASSES] = {0, 1, 8, 16, 32, 64, 128, 192, 256};   // class k: TOP[k-1] < b <= TOP[k]
+struct MsmWidths {
+  u32 max_bits;
+  u32 count[MSM_WIDTH_CLASSES];
+};
 template <class SP>
-__global__ void __launch_bounds__(256) msm_scalar_bits_kernel(const u32* __restrict__ scalars, u32 n, u32 stride, int mont,
-                                                              u32* __restrict__ out) {
+__global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __restrict__ scalars, u32 n, u32 stride, int mont,
+                                                               u32* __restrict__ out /*[1 + MSM_WIDTH_CLASSES]*/) {
   typedef Fp<SP> S;
+  __shared__ u32 blk[1 + MSM_WIDTH_CLASSES];
+  if (threadIdx.x <= MSM_WIDTH_CLASSES) blk[threadIdx.x] = 0;
+  __syncthreads();
   u32 bits = 0;
-  for (u64 t = blockIdx.x * blockDim.x + threadIdx.x; t * stride < n; t += (u64)gridDim.x * blockDim.x) {   // grid-stride
-    u32 v[S::N + 1];
-    (void)msm_scalar_magnitude<SP>(scalars, (u32)(t * stride), mont, v, nullptr);   // out of range: magnitude 0, the digits kernel reports it
+  u32 mine[MSM_WIDTH_CLASSES] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // lane 0 of the wave: its wave's counts
+  const u64 step = (u64)gridDim.x * blockDim.x;
+  const u64 rounds = (((u64)n + stride - 1) / stride + step - 1) / step;   // the same trip count for every lane (ballots below)
+  for (u64 it = 0; it < rounds; it++) {
+    const u64 t = it * step + blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    if (t * stride < n) {
+      u32 v[S::N + 1];
+      (void)msm_scalar_magnitude<SP>(scalars, (u32)(t * stride), mont, v, nullptr);   // out of range: magnitude 0, the digits kernel reports it
+      u32 b = 0;
 #pragma unroll
-    for (int k = 0; k < S::N; k++)
-      if (v[k]) {
-        const u32 b = 32u * (u32)k + 32u - (u32)__builtin_clz(v[k]);
-        bits = b > bits ? b : bits;
-      }
+      for (int k = 0; k < S::N; k++)
+        if (v[k]) b = 32u * (u32)k + 32u - (u32)__builtin_clz(v[k]);
+      bits = b > bits ? b : bits;
+      cls = 0;
+#pragma unroll
+      for (int k = 1; k < MSM_WIDTH_CLASSES; k++) cls += b > (u32)MSM_WIDTH_TOP[k - 1] ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < MSM_WIDTH_CLASSES; k++) mine[k] += (u32)__popcll(__ballot(cls == k));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const u32 other = (u32)__shfl_xor((int)bits, o);
     bits = other > bits ? other : bits;
   }
-  // one same-address atomic per wave serialises (2^18 waves: 3 ms, measured); a wave that cannot raise the maximum only reads it
-  if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&blk[0], bits);
+#pragma unroll
+    for (int k = 0; k < MSM_WIDTH_CLASSES; k++)
+      if (mine[k]) atomicAdd(&blk[1 + k], mine[k]);
+  }
+  __syncthreads();
+  // one same-address atomic per wave serialises (2^18 waves: 3 ms, measured): one per workgroup and counter, and the
+  // maximum only where it can still rise
+  if (gridDim.x == 1) {   // the sample: one workgroup, plain stores, no zeroing beforehand
+    if (threadIdx.x <= MSM_WIDTH_CLASSES) out[threadIdx.x] = blk[threadIdx.x];
+  } else if (threadIdx.x == 0) {
+    if (blk[0] > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, blk[0]);
+  } else if (threadIdx.x <= MSM_WIDTH_CLASSES && blk[threadIdx.x]) {
+    atomicAdd(out + threadIdx.x, blk[threadIdx.x]);
+  }
 }
 
 template <class SP>
@@ -1059,7 +1095,8 @@ static inline int msm_window_offset(int w, int c, int W, int narrow) {
 // single bucket is a serial chain (~14 us per addition on a lightly loaded SIMD), the first reduction
 // level costs 2 full additions per bucket, the bit-sliced remainder ~0.5 ms.  With a prepared base set
 // (`shared`) only one bucket set is reduced, which moves the optimum to wider windows.
-static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool shared, bool lazy28 = false) {
+static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool shared, bool lazy28 = false,
+                                    const MsmWidths* widths = nullptr) {
   const double plain_k = lazy28 ? 0.79 : 1.0;   // plain path only: see the accumulate model below
   int best_c = 3;
   double best = 1e300;
@@ -1076,7 +1113,17 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       msm_window_layout(c, bits, &W, &narrow);
       double nbk = (double)(W - narrow) * (double)(1u << (c - 1)) + (double)narrow * (double)(1u << (c - 2));
       if (shared) nbk = (double)(1u << (c - 1));
-      const double entries = (double)n * W;
+      double entries = (double)n * W;
+      if (widths) {
+        // measured width classes (K0): a scalar of b bits has digits in the windows below bit b + 1 only
+        entries = 0.0;
+        for (int k = 1; k < MSM_WIDTH_CLASSES; k++) {
+          int need = (MSM_WIDTH_TOP[k] + 1 + c - 1) / c;
+          if (need > W) need = W;
+          entries += (double)widths->count[k] * need;
+        }
+        if (entries < 1.0) entries = 1.0;
+      }
       const double madd = 1.0 / 5.5e9 * mul_cost, fadd = 1.4 / 5.5e9 * mul_cost;
       const bool fp2 = mul_cost > 2.0;  // a lane PAIR per bucket
       // accumulate: throughput-bound when the buckets make several rounds over the chip's resident lanes (2 waves x 4
@@ -1137,7 +1184,7 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       // super-bucket histogram grows and so do both sort passes (2^25: c = 24 costs +2.8 ms of sort and +7 ms of
       // reduction for -4.7 ms of accumulation; BN254 2^23 / 2^24: c = 22 beats 20 by 6-7 %; profiles/r2_msm_sweeps.txt)
       const double per_bucket = (shared && n >= ((size_t)1 << 23) && c <= 22) ? 1.5e-11 : 1.0e-10;
-      const double sort = entries * 2.0e-11 + (double)W * (double)(1u << (c - 1)) * per_bucket;
+      const double sort = (double)n * W * 2.0e-11 + (double)W * (double)(1u << (c - 1)) * per_bucket;   // every key is read, live or not
       double cost = acc + red0 + bits_stage + sort;
       if (narrow == W) continue;  // every window one bit narrower: the layout of c - 1 with twice the buckets
       if (narrow == 0) {
@@ -1226,7 +1273,10 @@ struct MsmWorkspace {
   // window groups (msm_enqueue): the second group's sort runs on this stream under the first group's accumulate kernel
   hipStream_t side = nullptr;
   hipEvent_t grp_ev[2] = {nullptr, nullptr};
+  u32* probe_host = nullptr;   // pinned word the width probe reads back into (a pageable target costs a staged copy)
   void release() {
+    if (probe_host) (void)hipHostFree(probe_host);
+    probe_host = nullptr;
     hctr.release(); hlist.release(); hitems.release(); hpart.release(); hfinal.release();
     keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
     offsets.release(); sums.release();
@@ -1299,12 +1349,13 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (n >= (1ull << 31)) return -2;
   if (sbytes && (prepared || (sbytes != 1 && sbytes != 2 && sbytes != 4 && sbytes != 8) || sbits < 1 || sbits > 8 * sbytes))
     return -1;
-  // Full-width scalars that are all narrow (K0 above): one 4-byte read-back decides the plan, so the probe runs only
-  // where that round trip (~20 us) is small against the call (n >= 2^18) and nothing else of this workspace is in
-  // flight to wait behind (a pipelined caller keeps the 255-bit plan).  A spread sample of 4096 scalars first: uniform
-  // scalars stop there.  ARK_HIP_MSM_PROBE=0 turns it off.
+  // Width classes of full-width scalars (K0 above): one 40-byte read-back decides the plan, so the probe runs only where
+  // that round trip (~30 us; 2 % of a 2^18 call, measured) is small against the call (n >= 2^19) and nothing else of this workspace is in flight to wait
+  // behind (a pipelined caller keeps the plan for n uniform 255-bit scalars).  ARK_HIP_MSM_PROBE=0 turns it off.
   int plan_bits = sbytes ? sbits + 1 : C::S::BITS;
-  if (!sbytes && !prepared && !piece && n >= ((size_t)1 << 18)) {
+  MsmWidths widths{};
+  bool have_widths = false;
+  if (!sbytes && !prepared && !piece && n >= ((size_t)1 << 19)) {
     static const bool probe_on = [] {
       const char* e = getenv("ARK_HIP_MSM_PROBE");
       return !(e && atoi(e) == 0);
@@ -1312,28 +1363,40 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     bool idle = true;
     for (int i = 0; i < MSM_JOBS; i++) idle = idle && !ws.jobs[i].busy;
     if (probe_on && idle) {
-      if (ws.probe.ensure(8)) return -3;
-      auto measure = [&](u32 stride, u32* bits) -> int {
+      constexpr size_t PW = (1 + MSM_WIDTH_CLASSES) * 4;
+      if (ws.probe.ensure(PW)) return -3;
+      if (!ws.probe_host) ARK_HIP_TRY(hipHostMalloc((void**)&ws.probe_host, 64, hipHostMallocDefault));
+      auto measure = [&](u32 stride, MsmWidths* w) -> int {
         const u32 cnt = (u32)((n + stride - 1) / stride);
-        ARK_HIP_TRY(hipMemsetAsync(ws.probe.p, 0, 4, stream));
-        const u32 blocks = (cnt + 255) / 256;
-        hipLaunchKernelGGL((msm_scalar_bits_kernel<typename C::S>), dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, stream,
+        u32 blocks = cnt <= 8192 ? 1u : (cnt + 1023) / 1024;
+        if (blocks > 1024) blocks = 1024;
+        if (blocks > 1) ARK_HIP_TRY(hipMemsetAsync(ws.probe.p, 0, PW, stream));
+        hipLaunchKernelGGL((msm_scalar_bits_kernel<typename C::S>), dim3(blocks), dim3(1024), 0, stream,
                            (const u32*)d_scalars, (u32)n, stride, scalars_mont, (u32*)ws.probe.p);
-        ARK_HIP_TRY(hipMemcpyAsync(bits, ws.probe.p, 4, hipMemcpyDeviceToHost, stream));
+        ARK_HIP_TRY(hipMemcpyAsync(ws.probe_host, ws.probe.p, PW, hipMemcpyDeviceToHost, stream));
         ARK_HIP_TRY(hipStreamSynchronize(stream));
+        w->max_bits = ws.probe_host[0];
+        for (int k = 0; k < MSM_WIDTH_CLASSES; k++) w->count[k] = ws.probe_host[1 + k];
         return 0;
       };
-      const int slack = 8;   // fewer than 8 bits saved: not worth a second plan
-      u32 b = 0;
-      if (int rc = measure((u32)(n / 4096), &b)) return rc;
-      if ((int)b + 1 + slack <= C::S::BITS) {
-        if (int rc = measure(1u, &b)) return rc;
-        if ((int)b + 1 + slack <= C::S::BITS) plan_bits = (b ? (int)b : 1) + 1;
+      // a spread sample of 4096 scalars first: uniform scalars stop here (more than half of the sample wider than 128 bits)
+      MsmWidths sample{};
+      if (int rc = measure((u32)(n / 4096), &sample)) return rc;
+      u32 seen = 0, wide = 0;
+      for (int k = 0; k < MSM_WIDTH_CLASSES; k++) {
+        seen += sample.count[k];
+        if (MSM_WIDTH_TOP[k] > 128) wide += sample.count[k];
+      }
+      if (2 * wide < seen) {
+        if (int rc = measure(1u, &widths)) return rc;
+        have_widths = true;
+        const int slack = 8;   // fewer than 8 bits saved: the 255-bit layout stays
+        if ((int)widths.max_bits + 1 + slack <= C::S::BITS) plan_bits = (widths.max_bits ? (int)widths.max_bits : 1) + 1;
       }
     }
   }
   const MsmPlan pl = prepared ? *prepared
-                     : (piece ? *piece->plan : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A));
+                     : (piece ? *piece->plan : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A, have_widths ? &widths : nullptr));
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;                      // sort slots
   const size_t nbk = pl.nbuckets();             // accumulated buckets
@@ -1440,11 +1503,11 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   }
   const size_t max_heavy = total_entries / 64 + 1;  // the threshold is never below 64
   const size_t max_items = total_entries / HEAVY_CHUNK + max_heavy + 1;
-  if (ws.hctr.ensure(32) || ws.hlist.ensure((max_heavy + 1) * sizeof(HeavyEntry)) || ws.hitems.ensure((max_items + 1) * 8) ||
+  if (ws.hctr.ensure(64) || ws.hlist.ensure((max_heavy + 1) * sizeof(HeavyEntry)) || ws.hitems.ensure((max_items + 1) * 8) ||
       ws.hpart.ensure((max_items + 1) * Pt::BYTES))
     return -3;
   if (pl.shared && ws.hfinal.ensure(max_heavy * Pt::BYTES)) return -3;
-  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 32, stream));  // per window group: [chunk items, heavy runs, threshold, -]; [3]: scalar-range error flag
+  ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 64, stream));  // per window group: [chunk items, heavy runs, threshold, -]; [3]: scalar-range error flag; [8 + g]: super-buckets of group g left to the sliced pass B
   const u32 nblk = (u32)((n + 255) / 256);
   if (sbytes) {
     const u64 vmask = sbits >= 64 ? ~0ull : ((1ull << sbits) - 1ull);
@@ -1479,7 +1542,16 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     }();
     if (groups_env == 2 || (groups_env != 1 && n >= ((size_t)1 << 25))) ngroups = 2;
   }
-  if (ngroups == 2) {
+  // Heavy runs (skewed scalars) and the lane-per-bucket kernel touch disjoint buckets: with one window group and a call
+  // long enough to pay two event hops, the chunk / combine kernels -- chains of dependent additions on a few hundred
+  // waves -- run on the side stream UNDER the accumulate kernel (witness-like 2^24: 1.7 ms of heavy kernels in front of
+  // 2.1 ms of accumulation; profiles/r4_skewed_sort_ab.txt).  ARK_HIP_MSM_HEAVY_SIDE=0 keeps them in line.
+  static const bool heavy_side_env = [] {
+    const char* e = getenv("ARK_HIP_MSM_HEAVY_SIDE");
+    return !(e && atoi(e) == 0);
+  }();
+  const bool heavy_side = heavy_side_env && ngroups == 1 && !piece && n >= ((size_t)1 << 20);
+  if (ngroups == 2 || heavy_side) {
     if (!ws.side) ARK_HIP_TRY(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
     for (auto& e : ws.grp_ev)
       if (!e) ARK_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1502,7 +1574,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     return !(e && atoi(e) == 0);
   }();
   const bool big_on = big_env && n > (size_t)2 * PART_BIG;
-  const size_t big_region = PART_BIG_LIST + (size_t)nsuper + 2 * nb;   // u32 words per window group (each group's share is smaller)
+  const size_t big_region = (size_t)nsuper + 2 * nb;   // u32 words per window group (each group's share is smaller)
   if (big_on && ws.big.ensure(2 * big_region * 4)) return -3;
   bool lazy = false;  // Fp384 G1: the accumulate kernels on carry-free 28-bit limbs (fp28.cuh); ARK_HIP_MSM_LAZY=0: saturated
   if constexpr (C::LAZY_A) lazy = msm_lazy_enabled();
@@ -1511,8 +1583,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     int w0, Wg;
     size_t slot0, nslots, nbk_g;   // first sort slot, sort slots, accumulated buckets
     u32 *keys, *sorted, *offsets, *thist, *toff, *order, *sums, *ohist, *ooff, *hctr;
-    u32* big;                      // sliced pass B (msm_sort.cuh): [count, -, list ..., counters[nslots], cursors[nslots]]
-    size_t big_words;
+    u32* big;                      // sliced pass B (msm_sort.cuh): [list of super-buckets, counters[nslots], cursors[nslots]]
+    u32* big_count;                // their number (hctr[8 + g], zeroed with the other counters)
     uint2* part;
     HeavyEntry* hlist;
     uint2* hitems;
@@ -1539,7 +1611,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     G.ooff = (u32*)ws.ooff.p + (size_t)g * (noblk0 * ORDER_BINS + 1);
     G.hctr = (u32*)ws.hctr.p + 4 * g;
     G.big = big_on ? (u32*)ws.big.p + (size_t)g * big_region : nullptr;
-    G.big_words = PART_BIG_LIST + ((size_t)G.Wg << HB) + 2 * G.nslots;
+    G.big_count = (u32*)ws.hctr.p + 8 + g;
     const size_t ent0 = (size_t)n * W0;
     const size_t mh0 = ent0 / 64 + 1, mi0 = ent0 / HEAVY_CHUNK + mh0 + 1;   // group 0's share of the heavy-run arrays
     G.max_heavy = g == 0 ? (ngroups == 2 ? mh0 : max_heavy) : max_heavy - mh0;
@@ -1560,16 +1632,15 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, G.Wg), dim3(1024), lds_a, st, G.keys, (u32)n, HB, LB, ntiles,
                        ptile, G.toff, G.part);
     hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper_g), dim3(1024), lds_b, st, G.part, G.toff, ntiles, LB, nsuper_g,
-                       stage_cap, big_on ? PART_BIG : 0u, G.offsets, G.sorted);
+                       stage_cap, big_on ? PART_BIG : 0u, G.big_count, G.big, G.offsets, G.sorted);
     if (big_on) {
-      u32* const bigcnt = G.big + PART_BIG_LIST + nsuper_g;
+      u32* const bigcnt = G.big + nsuper_g;     // counters and cursors of a listed super-bucket: zeroed by the finish kernel
       u32* const cursor = bigcnt + G.nslots;
-      ARK_HIP_TRY(hipMemsetAsync(G.big, 0, G.big_words * 4, st));
-      hipLaunchKernelGGL(msm_part_big_list_kernel, dim3((nsuper_g + 255) / 256), dim3(256), 0, st, G.toff, ntiles, nsuper_g, G.big);
       hipLaunchKernelGGL(msm_part_big_hist_kernel, dim3(PART_BIG_SLICES, PART_BIG_GRID_Y), dim3(1024), (size_t)4 << LB, st,
-                         G.part, G.toff, ntiles, LB, G.big, bigcnt);
+                         G.part, G.toff, ntiles, LB, G.big_count, G.big, bigcnt);
       hipLaunchKernelGGL(msm_part_big_place_kernel, dim3(PART_BIG_SLICES, PART_BIG_GRID_Y), dim3(1024),
-                         ((size_t)8 << LB) + 4096, st, G.part, G.toff, ntiles, LB, G.big, bigcnt, cursor, G.offsets, G.sorted);
+                         ((size_t)8 << LB) + 4096, st, G.part, G.toff, ntiles, LB, G.big_count, G.big, bigcnt, cursor, G.offsets,
+                         G.sorted);
     }
     int shift = 0;  // class width 2^shift so that the mean load falls around class 32..63
     while ((mean_load >> shift) >= 64) shift++;
@@ -1583,13 +1654,19 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     return 0;
   };
   // heavy runs + the lane-per-bucket kernel of one group
-  auto accumulate_group = [&](const Group& G, hipStream_t st) -> int {
+  auto accumulate_group = [&](const Group& G, hipStream_t st) -> int {   // (st is reassigned below)
     // runs too long for one lane: chunk partials by one wave each, combined per run (empty for uniform scalars)
     hipLaunchKernelGGL(msm_find_heavy_kernel, dim3((u32)((G.nslots + 255) / 256)), dim3(256), 0, st, G.offsets, (u32)G.nslots,
                        forced_thresh, G.hctr, G.hlist, G.hitems);
     constexpr u32 LN = C::FA::LANES;                        // lanes per element of the accumulate field
     constexpr size_t ACCB = AccOps<C>::ACC_BYTES;           // one parked accumulator (the form the kernels sum in)
     const u32 hthreads = ACCB * (256 / LN) > 49152 ? 128 : 256;  // one LDS tree per wave, <= 48 KiB per workgroup
+    hipStream_t const acc_st = st;
+    if (heavy_side) {
+      ARK_HIP_TRY(hipEventRecord(ws.grp_ev[0], st));
+      ARK_HIP_TRY(hipStreamWaitEvent(ws.side, ws.grp_ev[0], 0));
+      st = ws.side;
+    }
     hipLaunchKernelGGL((msm_heavy_partial_kernel<C>), dim3(1024), dim3(hthreads), (hthreads / LN) * ACCB, st,
                        (const char*)d_points, G.sorted, G.offsets, G.hctr, (const uint2*)G.hitems, wstride, Bbits, (u32)G.nslots, G.hpart);
     const u32 combine_grid = G.max_heavy < 16384 ? (u32)G.max_heavy : 16384u;  // grid-stride over the heavy runs
@@ -1599,6 +1676,10 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     else
       hipLaunchKernelGGL((msm_heavy_combine_kernel<C, false>), dim3(combine_grid), dim3(ARK_HEAVY_COMBINE_THREADS), (ARK_HEAVY_COMBINE_THREADS / LN) * ACCB, st, G.hctr,
                          (const HeavyEntry*)G.hlist, (const char*)G.hpart, HB, LB, G.offsets, G.sorted, accum, G.buckets);
+    if (heavy_side) {
+      ARK_HIP_TRY(hipEventRecord(ws.grp_ev[1], ws.side));
+      st = acc_st;
+    }
     if (pl.shared) {
       if constexpr (C::LAZY_A) {
         if (lazy)
@@ -1610,6 +1691,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
         hipLaunchKernelGGL((msm_accumulate_shared_kernel<C>), dim3((u32)((nbk * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
                            (const char*)d_points, wstride, G.sorted, G.offsets, G.order, (u32)nbk, W, Bbits,
                            (const u32*)G.hctr + 2, HB, LB, G.buckets);
+      if (heavy_side) ARK_HIP_TRY(hipStreamWaitEvent(st, ws.grp_ev[1], 0));
       hipLaunchKernelGGL((msm_apply_heavy_kernel<C>), dim3(1024), dim3(64), 0, st, (const u32*)G.hctr,
                          (const HeavyEntry*)G.hlist, G.offsets, G.sorted, (const char*)ws.hfinal.p, W, Bbits, HB, LB, G.buckets);
     } else {
@@ -1623,6 +1705,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
         hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((G.nslots * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
                            (const char*)d_points, G.sorted, G.offsets, G.order, (u32)G.nslots, (const u32*)G.hctr + 2, HB, LB,
                            accum, G.buckets);
+      if (heavy_side) ARK_HIP_TRY(hipStreamWaitEvent(st, ws.grp_ev[1], 0));
     }
     return 0;
   };

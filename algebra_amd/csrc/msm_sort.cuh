@@ -258,6 +258,7 @@ __device__ __forceinline__ u32 lds_inc_leading(u32* cnt, u32 key) {
 static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint2* __restrict__ part,
                                                                       const u32* __restrict__ tile_off, u32 ntiles,
                                                                       int LB, u32 nsuper, u32 stage_cap, u32 big_thresh,
+                                                                      u32* __restrict__ big_count, u32* __restrict__ big,
                                                                       u32* __restrict__ offsets,
                                                                       u32* __restrict__ sorted) {
   extern __shared__ u32 part_lds[];
@@ -269,7 +270,16 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
   const u32 start = tile_off[(size_t)sb * ntiles];
   const u32 end = tile_off[(size_t)(sb + 1) * ntiles];  // tile_off has nsuper * ntiles + 1 entries
   if (sb == nsuper - 1 && threadIdx.x == 0) offsets[(size_t)nsuper << LB] = end;
-  if (big_thresh && end - start > big_thresh) return;   // left to the sliced kernels below
+  if (big_thresh && end - start > big_thresh) {   // left to the sliced kernels below: list it, zero its counters and cursors
+    if (threadIdx.x == 0) big[atomicAdd(big_count, 1u)] = sb;
+    u32* const bigcnt = big + nsuper + ((size_t)sb << LB);
+    u32* const cursor = bigcnt + ((size_t)nsuper << LB);
+    for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) {
+      bigcnt[b] = 0;
+      cursor[b] = 0;
+    }
+    return;
+  }
   for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) cnt[b] = 0;
   __syncthreads();
   const u32 lmask = nlow - 1u;
@@ -341,7 +351,8 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
 // Skewed scalars concentrate a window's keys in a few buckets -- a witness whose values are mostly 1 sends n/2 keys to
 // bucket 1 of window 0 -- and the super-bucket that holds such a bucket would stream all of them through ONE CU twice
 // (2^23 entries: 5.0 ms at 2^24, the largest kernel of that MSM; profiles/r4_skewed_sort_ab.txt).  Super-buckets above
-// PART_BIG entries are listed, and each is finished by PART_BIG_SLICES workgroups over contiguous slices:
+// PART_BIG entries are listed by the finish kernel (which also zeroes their counters), and each is finished by
+// PART_BIG_SLICES workgroups over contiguous slices:
 //   big_hist    slice histogram in LDS -> atomicAdd into the super-bucket's global counters
 //   big_place   every slice scans the global counters (-> bucket offsets, written by slice 0), counts its slice again,
 //               reserves its share of every bucket with one global atomic per non-empty bucket, and places its entries.
@@ -349,15 +360,6 @@ static __global__ void __launch_bounds__(1024) msm_part_finish_kernel(const uint
 static constexpr u32 PART_BIG = 1u << 17;
 static constexpr u32 PART_BIG_SLICES = 16;
 static constexpr u32 PART_BIG_GRID_Y = 32;     // listed super-buckets are walked with this stride
-static constexpr u32 PART_BIG_LIST = 16;       // word offset of the list in the `big` array ([0] = count)
-
-static __global__ void __launch_bounds__(256) msm_part_big_list_kernel(const u32* __restrict__ tile_off, u32 ntiles,
-                                                                       u32 nsuper, u32* __restrict__ big) {
-  const u32 sb = blockIdx.x * blockDim.x + threadIdx.x;
-  if (sb >= nsuper) return;
-  const u32 total = tile_off[(size_t)(sb + 1) * ntiles] - tile_off[(size_t)sb * ntiles];
-  if (total > PART_BIG) big[PART_BIG_LIST + atomicAdd(&big[0], 1u)] = sb;
-}
 
 // slice s of [start, end)
 __device__ __forceinline__ void msm_part_big_slice(u32 start, u32 end, u32* lo, u32* hi) {
@@ -370,13 +372,14 @@ __device__ __forceinline__ void msm_part_big_slice(u32 start, u32 end, u32* lo, 
 
 static __global__ void __launch_bounds__(1024) msm_part_big_hist_kernel(const uint2* __restrict__ part,
                                                                         const u32* __restrict__ tile_off, u32 ntiles, int LB,
+                                                                        const u32* __restrict__ big_count,
                                                                         const u32* __restrict__ big,
                                                                         u32* __restrict__ bigcnt) {
   extern __shared__ u32 part_lds[];   // [nlow]
-  const u32 nbig = big[0];
+  const u32 nbig = big_count[0];
   const u32 nlow = 1u << LB, lmask = nlow - 1u;
   for (u32 k = blockIdx.y; k < nbig; k += gridDim.y) {
-    const u32 sb = big[PART_BIG_LIST + k];
+    const u32 sb = big[k];
     u32 lo, hi;
     msm_part_big_slice(tile_off[(size_t)sb * ntiles], tile_off[(size_t)(sb + 1) * ntiles], &lo, &hi);
     for (u32 b = threadIdx.x; b < nlow; b += blockDim.x) part_lds[b] = 0;
@@ -401,18 +404,19 @@ static __global__ void __launch_bounds__(1024) msm_part_big_hist_kernel(const ui
 
 static __global__ void __launch_bounds__(1024) msm_part_big_place_kernel(const uint2* __restrict__ part,
                                                                          const u32* __restrict__ tile_off, u32 ntiles, int LB,
+                                                                         const u32* __restrict__ big_count,
                                                                          const u32* __restrict__ big,
                                                                          const u32* __restrict__ bigcnt,
                                                                          u32* __restrict__ cursor, u32* __restrict__ offsets,
                                                                          u32* __restrict__ sorted) {
   extern __shared__ u32 part_lds[];
-  const u32 nbig = big[0];
+  const u32 nbig = big_count[0];
   const u32 nlow = 1u << LB, lmask = nlow - 1u;
   u32* cnt = part_lds;            // [nlow]  the super-bucket's counters -> bucket starts
   u32* wsum = part_lds + nlow;    // [1024]
   u32* mine = wsum + 1024;        // [nlow]  this slice's counters -> its placement cursors
   for (u32 k = blockIdx.y; k < nbig; k += gridDim.y) {
-    const u32 sb = big[PART_BIG_LIST + k];
+    const u32 sb = big[k];
     const u32 start = tile_off[(size_t)sb * ntiles];
     u32 lo, hi;
     msm_part_big_slice(start, tile_off[(size_t)(sb + 1) * ntiles], &lo, &hi);

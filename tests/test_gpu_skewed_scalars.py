@@ -1,5 +1,5 @@
 """Narrow and skewed scalars at sizes where the planner's narrow-scalar choices, the width probe of msm_bigint, the
-heavy-run kernels and the wave-aggregated sort counters are live (n >= 2^18): the distributions of the reference's MSM
+heavy-run kernels and the wave-aggregated sort counters are live (n = 2^19): the distributions of the reference's MSM
 bench (bench-templates/src/macros/ec.rs:222-372 -- bool, u8, u16, u32, u64, their signed forms, the mixed vector) and
 witness-like vectors (mostly 0 / 1 with a few full-width values), through msm_bigint (device-resident and Montgomery
 form) and the msm_u* entries, each against k*G with k = sum s_i (a + i b) in closed form and k*G from the ORACLE."""
@@ -27,7 +27,7 @@ def setup(request):
     name = request.param
     cid = O.CID[name]
     r = S.R[cv.scalar_field(cid)]
-    n = 1 << (LOGN if "G2" not in name else LOGN - 1)
+    n = 1 << LOGN
     bases = S.grow_bases(cid, n, S.A0, S.B0, r)
     yield {"cid": cid, "r": r, "n": n, "bases": bases}
     del bases

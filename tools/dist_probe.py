@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One scalar distribution of the reference's MSM bench through msm_bigint, a few calls -- for a kernel trace
-(rocprofv3 --kernel-trace -- python tools/dist_probe.py u16 20).  Distributions: random, bool, u8, u16, u32, u64."""
+(rocprofv3 --kernel-trace -- python tools/dist_probe.py u16 20).  Distributions: random, bool, u8, u16, u32, u64, witness."""
 import os
 import sys
 import time
@@ -23,7 +23,15 @@ n = 1 << logn
 bases = S.grow_bases(cid, n, S.A0, S.B0, r)
 rng = np.random.default_rng(1)
 bits = {"bool": 1, "u8": 8, "u16": 16, "u32": 32, "u64": 64}.get(name)
-if bits is None:
+if name == "witness":   # 60 % zeros, 30 % ones, 5 % minus one, 5 % full width
+    sc = S.gen_scalars(n, 77, r)
+    u = rng.random(n)
+    sc[u < 0.60] = 0
+    one = np.zeros(4, dtype=np.uint64)
+    one[0] = 1
+    sc[(u >= 0.60) & (u < 0.90)] = one
+    sc[(u >= 0.90) & (u < 0.95)] = np.array([((r - 1) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
+elif bits is None:
     sc = S.gen_scalars(n, 5, r)
 else:
     sc = np.zeros((n, 4), dtype=np.uint64)

@@ -42,7 +42,7 @@ for step in "$@"; do
       cd /tmp
       timeout 600 rocprofv3 --kernel-trace -d $O/p_ktpy -o kt -- python $R/tools/${a[1]} ${a[@]:2} >> $O/ktpy.out 2>> $O/ktpy.err
       cd $R
-      python tools/rocpd_stats.py $(db p_ktpy) --min-us 20 > $O/kernel_stats_${a[1]%.py}_$(echo ${a[@]:2} | tr ' ' '_')${suffix}.txt 2>> $O/post.err
+      python tools/rocpd_stats.py $(db p_ktpy) --min-us 20 --timeline ${KT_TIMELINE:-0} > $O/kernel_stats_${a[1]%.py}_$(echo ${a[@]:2} | tr ' ' '_')${suffix}.txt 2>> $O/post.err
       rm -rf $O/p_ktpy ;;
     pmc)
       cd /tmp

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Reduction-geometry sweep of one MSM (base set prepared once): level-0 chunk (ARK_HIP_MSM_L0) x bit-stage chunk
-(ARK_HIP_MSM_CHUNK); every configuration checked bit-exactly against k*G.
-    python tools/reduce_sweep.py [CURVE] [LOG_N] [plain|prepared]"""
+"""Reduction geometry sweep: level-0 run length (ARK_HIP_MSM_L0) x bit-sliced chunk (ARK_HIP_MSM_CHUNK) against the
+library's own choice, device-resident plain MSM, every result checked against k*G.
+    python tools/reduce_sweep.py CURVE LOG_N [LOG_N ...]"""
+import ctypes as C
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -14,28 +16,45 @@ import torch
 import algebra_amd as A
 import synth as S
 from algebra_amd import curves as cv
-from msm_bench import timed
+from algebra_amd._lib import check, lib
 
-curve = sys.argv[1] if len(sys.argv) > 1 else "BLS12_381_G1"
-logn = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-mode = sys.argv[3] if len(sys.argv) > 3 else "prepared"
+curve = sys.argv[1]
 cid = cv.curve_id(curve)
 r = S.R[cv.scalar_field(cid)]
-n = 1 << logn
-bases = S.grow_bases(cid, n, S.A0, S.B0, r)
-sc = S.gen_scalars(n, 5, r)
-scalars = torch.from_numpy(sc.view(np.int64)).cuda()
-kg = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
-pb = A.PreparedBases(cid, bases) if mode == "prepared" else None
-run = (lambda: pb.msm_bigint(scalars)) if pb is not None else (lambda: A.msm_bigint(cid, bases, scalars))
-for l0 in (None, 8, 16, 32, 64):
-    for chunk in (None, 1024, 2048, 4096, 8192, 16384):
-        for k, v in (("ARK_HIP_MSM_L0", l0), ("ARK_HIP_MSM_CHUNK", chunk)):
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
-        res, dt, tm = timed(run, 3)
+L = lib()
+for logn in [int(x) for x in sys.argv[2:]]:
+    n = 1 << logn
+    bases = S.grow_bases(cid, n, S.A0, S.B0, r)
+    sc = S.gen_scalars(n, 5, r)
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    kg = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
+
+    def run(steps=6):
+        A.msm_bigint(cid, bases, d)
+        check(L.ark_hip_msm_set_timing(1), "t")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = A.msm_bigint(cid, bases, d)
+        dt = (time.perf_counter() - t0) / steps
+        tm = (C.c_double * 8)()
+        L.ark_hip_msm_last_timing(tm)
+        check(L.ark_hip_msm_set_timing(0), "t")
         ok = bool(np.array_equal(A.into_affine(cid, res), kg))
-        print("%s 2^%d %s c=%d W=%d L0=%-4s chunk=%-5s  %.3f ms  [acc %.2f red %.2f]  exact=%s"
-              % (curve, logn, mode, int(tm[6]), int(tm[7]), l0, chunk, dt * 1e3, tm[3], tm[4], ok), flush=True)
+        return dt * 1e3, tm[4], ok
+
+    for k in ("ARK_HIP_MSM_L0", "ARK_HIP_MSM_CHUNK"):
+        os.environ.pop(k, None)
+    ms, red, ok = run()
+    print("%s 2^%d plan %s: library choice %.3f ms (reduce %.3f)%s" % (curve, logn, A.msm_plan(cid, n), ms, red, "" if ok else " WRONG"), flush=True)
+    for l0 in (1, 2, 4, 8, 16):
+        line = "  L0=%-2d" % l0
+        for ch in (256, 512, 1024, 2048, 4096):
+            os.environ["ARK_HIP_MSM_L0"] = str(l0)
+            os.environ["ARK_HIP_MSM_CHUNK"] = str(ch)
+            ms, red, ok = run()
+            line += "  chunk %4d: %.3f (%.3f)%s" % (ch, ms, red, "" if ok else "!")
+        print(line, flush=True)
+    for k in ("ARK_HIP_MSM_L0", "ARK_HIP_MSM_CHUNK"):
+        os.environ.pop(k, None)
+    del bases, d
+    torch.cuda.empty_cache()

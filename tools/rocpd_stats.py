@@ -41,6 +41,7 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--min-us", type=float, default=1000.0)
     ap.add_argument("--pmc", action="store_true", help="database comes from a --pmc run: print counter sums")
+    ap.add_argument("--timeline", type=int, default=0, help="also list the LAST n launches in order: start, duration, idle gap before")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     if a.pmc:
@@ -48,6 +49,15 @@ def main():
         return
     table(c, "", "all kernel launches")
     table(c, "where (end-start) >= %d" % int(a.min_us * 1000), "launches >= %.0f us (the timed full-size steps)" % a.min_us)
+    if a.timeline:
+        rows = c.execute("select name, start, end from kernels order by start desc limit %d" % a.timeline).fetchall()[::-1]
+        print("## the last %d launches in start order (us): start, duration, idle gap since the latest end so far" % len(rows))
+        t0, last_end, busy = rows[0][1], rows[0][1], 0
+        for name, st, en in rows:
+            print("%10.1f %9.1f %8.1f  %s" % ((st - t0) / 1e3, (en - st) / 1e3, max(0, st - last_end) / 1e3, name[:90]))
+            busy += en - max(st, last_end) if en > last_end else 0
+            last_end = max(last_end, en)
+        print("span %.1f us, busy %.1f us" % ((last_end - t0) / 1e3, busy / 1e3))
 
 
 if __name__ == "__main__":

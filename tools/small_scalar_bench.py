@@ -61,10 +61,21 @@ def main():
         allv = np.concatenate(parts)
         return allv[rng.permutation(allv.shape[0])]
 
+    def witness():
+        """an R1CS-witness-like vector: 60 % zeros, 30 % ones, 5 % minus one, 5 % full width"""
+        sc = S.gen_scalars(n, 77, r)
+        u = rng.random(n)
+        sc[u < 0.60] = 0
+        one = np.zeros(4, dtype=np.uint64)
+        one[0] = 1
+        sc[(u >= 0.60) & (u < 0.90)] = one
+        sc[(u >= 0.90) & (u < 0.95)] = to_limbs([r - 1])[0]
+        return sc
+
     cases = [("random", S.gen_scalars(n, 5, r), None), ("bool", small(1, False), A.msm_u1), ("u8", small(8, False), A.msm_u8),
              ("i8", small(8, True), None), ("u16", small(16, False), A.msm_u16), ("i16", small(16, True), None),
              ("u32", small(32, False), A.msm_u32), ("i32", small(32, True), None), ("u64", small(64, False), A.msm_u64),
-             ("i64", small(64, True), None), ("mixed", mixed(), None)]
+             ("i64", small(64, True), None), ("mixed", mixed(), None), ("witness", witness(), None)]
     print("# %s 2^%d, device-resident inputs; ms per MSM, every result == k*G" % (curve, logn))
     for name, sc, direct in cases:
         d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
