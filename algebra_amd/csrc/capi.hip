@@ -354,6 +354,11 @@ int msm_fold_sums_dispatch(int curve, const MsmSumsHeader& h, const void* h_sums
   ARK_CURVE_SWITCH(curve, X);
 #undef X
 }
+int msm_sample_widths_dispatch(int curve, const void* h_scalars, size_t n, int mont, MsmWidths* out) {
+#define X(NAME) (msm_sample_widths_##NAME(h_scalars, n, mont, out), 0)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
 int msm_prepare_dispatch(int curve, const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t st) {
 #define X(NAME) msm_prepare_##NAME(d_bases, n, pl, d_table, d_tmp, st)
   ARK_CURVE_SWITCH(curve, X);
@@ -1043,7 +1048,17 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
   const bool shared = allow_shared && npieces >= 2 && npieces <= 16;
   MsmPlan plan{};
   if (shared) {
-    plan = msm_make_plan(n, msm_scalar_bits(curve), msm_mul_cost(curve), false, msm_lazy28(curve));
+    // the window size from the width classes of a spread sample of the host scalars (msm.cuh K0: what the device entry
+    // measures exactly); the layout stays the full-width one -- a sample cannot bound the widest scalar
+    MsmWidths widths{};
+    bool skewed = false;
+    static const bool probe_on = [] {
+      const char* e = getenv("ARK_HIP_MSM_PROBE");
+      return !(e && atoi(e) == 0);
+    }();
+    if (probe_on && scalars && n >= ((size_t)1 << 19) && msm_sample_widths_dispatch(curve, scalars, n, mont, &widths) == 0)
+      skewed = msm_widths_skewed(widths);
+    plan = msm_make_plan(n, msm_scalar_bits(curve), msm_mul_cost(curve), false, msm_lazy28(curve), skewed ? &widths : nullptr);
     if ((size_t)step * (size_t)plan.W >= (1ull << 32)) return ARK_HIP_ERR_SIZE;
     const size_t need = plan.nbuckets() * (size_t)CURVES[curve].fe_words * 32;  // XYZZ: four field elements
     if (c->piece_buckets.cap < need) {

@@ -10,6 +10,7 @@ struct MsmTimings;
 struct MsmPlan;
 struct MsmPiece;
 struct MsmSumsHeader;
+struct MsmWidths;
 struct FftWorkspace;
 struct FftTimings;
 
@@ -21,6 +22,7 @@ struct FftTimings;
   int msm_finish_##NAME(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm);                          \
   int msm_sum_ranks_##NAME(const void* d_blocks, int world, size_t block_bytes, uint32_t npairs, void* d_out, hipStream_t stream); \
   int msm_fold_sums_##NAME(const MsmSumsHeader& h, const void* h_sums, uint64_t* out_xyz);                         \
+  void msm_sample_widths_##NAME(const void* h_scalars, size_t n, int mont, MsmWidths* out);                        \
   int msm_prepare_##NAME(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream);   \
   int batchmul_build_##NAME(const void* h_base_affine, int window, void* d_scratch, void* d_table, hipStream_t stream); \
   size_t batchmul_build_scratch_##NAME(int window);                                                               \

@@ -57,8 +57,8 @@ __host__ __device__ __forceinline__ int msm_window_width(int w, int c, int W, in
 // The magnitude the digits are taken from: v = min(s, r - s) of scalar i (canonical value; from Montgomery form first
 // when `mont`), S::N + 1 words with a zero on top; returns the sign flip (bit 31) when r - s was used.
 template <class SP>
-__device__ __forceinline__ u32 msm_scalar_magnitude(const u32* __restrict__ scalars, u32 i, int mont, u32* v /*[N+1]*/,
-                                                    u32* __restrict__ err) {
+__host__ __device__ __forceinline__ u32 msm_scalar_magnitude(const u32* __restrict__ scalars, u32 i, int mont, u32* v /*[N+1]*/,
+                                                             u32* __restrict__ err) {
   typedef Fp<SP> S;
   S s = S::load(scalars + (size_t)i * S::N);
   if (mont) s = S::from_mont(s);  // mod.rs:60-62 into_bigint
@@ -68,7 +68,11 @@ __device__ __forceinline__ u32 msm_scalar_magnitude(const u32* __restrict__ scal
   // s in [r, 2^BITS): s -= r once (2^BITS < 2r for the three scalar fields), then the fold below applies.
   if constexpr (SP::BITS < 32 * S::N) {
     if ((s.l[S::N - 1] >> (SP::BITS - 32 * (S::N - 1))) != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
       if (err) atomicOr(err, 1u);
+#else
+      (void)err;   // (host callers only measure widths)
+#endif
       s = S::zero();
     }
   }
@@ -170,6 +174,41 @@ __global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __rest
   } else if (threadIdx.x <= MSM_WIDTH_CLASSES && blk[threadIdx.x]) {
     atomicAdd(out + threadIdx.x, blk[threadIdx.x]);
   }
+}
+
+// The same classes for HOST scalars, estimated from a spread sample of at most 4096 of them (the streamed entries plan
+// before the first piece is uploaded and cannot wait for a device pass over all scalars): counts scaled to n, max_bits
+// = the field's -- an estimate may choose the window size, never the number of windows.
+template <class SP>
+void msm_sample_widths_host(const void* h_scalars, size_t n, int mont, MsmWidths* out) {
+  typedef Fp<SP> S;
+  *out = MsmWidths{};
+  out->max_bits = (u32)SP::BITS;
+  if (n == 0) return;
+  const size_t stride = n > 4096 ? n / 4096 : 1;
+  size_t seen = 0;
+  u32 cnt[MSM_WIDTH_CLASSES] = {0};
+  for (size_t i = 0; i < n; i += stride) {
+    u32 v[S::N + 1];
+    (void)msm_scalar_magnitude<SP>((const u32*)h_scalars, (u32)i, mont, v, nullptr);
+    u32 b = 0;
+    for (int k = 0; k < S::N; k++)
+      if (v[k]) b = 32u * (u32)k + 32u - (u32)__builtin_clz(v[k]);
+    int cls = 0;
+    for (int k = 1; k < MSM_WIDTH_CLASSES; k++) cls += b > (u32)MSM_WIDTH_TOP[k - 1] ? 1 : 0;
+    cnt[cls]++;
+    seen++;
+  }
+  for (int k = 0; k < MSM_WIDTH_CLASSES; k++) out->count[k] = (u32)((double)cnt[k] * (double)n / (double)seen);
+}
+// true when the classes say "not n uniform full-width scalars": fewer than half wider than 128 bits
+static inline bool msm_widths_skewed(const MsmWidths& w) {
+  u64 seen = 0, wide = 0;
+  for (int k = 0; k < MSM_WIDTH_CLASSES; k++) {
+    seen += w.count[k];
+    if (MSM_WIDTH_TOP[k] > 128) wide += w.count[k];
+  }
+  return 2 * wide < seen;
 }
 
 template <class SP>
@@ -1382,12 +1421,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
       // a spread sample of 4096 scalars first: uniform scalars stop here (more than half of the sample wider than 128 bits)
       MsmWidths sample{};
       if (int rc = measure((u32)(n / 4096), &sample)) return rc;
-      u32 seen = 0, wide = 0;
-      for (int k = 0; k < MSM_WIDTH_CLASSES; k++) {
-        seen += sample.count[k];
-        if (MSM_WIDTH_TOP[k] > 128) wide += sample.count[k];
-      }
-      if (2 * wide < seen) {
+      if (msm_widths_skewed(sample)) {
         if (int rc = measure(1u, &widths)) return rc;
         have_widths = true;
         const int slack = 8;   // fewer than 8 bits saved: the 255-bit layout stays

@@ -16,6 +16,9 @@ int msm_sum_ranks_BLS12_381_G1(const void* d_blocks, int world, size_t block_byt
   return msm_sum_ranks<BLS12_381_G1>(d_blocks, world, block_bytes, npairs, d_out, stream);
 }
 int msm_fold_sums_BLS12_381_G1(const MsmSumsHeader& h, const void* h_sums, uint64_t* out_xyz) { return msm_fold_sums<BLS12_381_G1>(h, h_sums, out_xyz); }
+void msm_sample_widths_BLS12_381_G1(const void* h_scalars, size_t n, int mont, MsmWidths* out) {
+  msm_sample_widths_host<typename BLS12_381_G1::S>(h_scalars, n, mont, out);
+}
 int msm_prepare_BLS12_381_G1(const void* d_bases, size_t n, const MsmPlan& pl, void* d_table, void* d_tmp, hipStream_t stream) {
   return msm_prepare_table<BLS12_381_G1>(d_bases, n, pl, d_table, d_tmp, stream);
 }

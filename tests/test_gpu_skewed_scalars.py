@@ -158,3 +158,26 @@ def test_probe_off_gives_the_same_point(setup, monkeypatch):
     a = _run_bigint(s, sc)
     b = A.into_affine(s["cid"], A.msm_u16(s["cid"], s["bases"], d16))
     assert np.array_equal(a, b) and np.array_equal(a, _kg(s["cid"], sc, s["r"]))
+
+
+def test_host_pointer_entry_plans_from_a_sample(setup):
+    """ark_hip_msm_sw with host arrays (what the Rust hooks call): the streamed path estimates the width classes from a
+    sample of the host scalars, canonical and Montgomery form; a vector whose SAMPLE is all ones but which holds full-width
+    scalars elsewhere must still come out right (the estimate picks the window size only)"""
+    s = setup
+    r = s["r"]
+    n = s["n"]
+    hb = s["bases"].cpu().numpy().view(np.uint64).reshape(n, -1)
+    rng = np.random.default_rng(23)
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    sc[:, 0] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    stride = n // 4096
+    wide = S.gen_scalars(n, 0x99, r)
+    off = np.arange(n) % stride != 0                 # every index the sampler does not visit
+    pick = off & (rng.random(n) < 0.03)
+    sc[pick] = wide[pick]
+    kg = _kg(s["cid"], sc, r)
+    assert np.array_equal(A.into_affine(s["cid"], A.msm_bigint(s["cid"], hb, sc)), kg)
+    R = (1 << 256) % r
+    mont = _limbs([(S.scalar_int(row) * R) % r for row in sc])
+    assert np.array_equal(A.into_affine(s["cid"], A.msm_unchecked(s["cid"], hb, mont)), kg)

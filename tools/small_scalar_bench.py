@@ -76,6 +76,8 @@ def main():
              ("i8", small(8, True), None), ("u16", small(16, False), A.msm_u16), ("i16", small(16, True), None),
              ("u32", small(32, False), A.msm_u32), ("i32", small(32, True), None), ("u64", small(64, False), A.msm_u64),
              ("i64", small(64, True), None), ("mixed", mixed(), None), ("witness", witness(), None)]
+    host = len(sys.argv) > 2 and sys.argv[2] == "host"   # + the host-pointer entry (ark_hip_msm_sw, default settings) for three rows
+    hb = bases.cpu().numpy().view(np.uint64).reshape(n, -1) if host else None
     print("# %s 2^%d, device-resident inputs; ms per MSM, every result == k*G" % (curve, logn))
     for name, sc, direct in cases:
         d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
@@ -88,6 +90,14 @@ def main():
                 res = fn()
             dt = (time.perf_counter() - t0) / 3
             line += "  %s %6.2f ms (exact=%s)" % (label, dt * 1e3, bool(np.array_equal(A.into_affine(cid, res), kg)))
+        if host and name in ("random", "mixed", "witness"):
+            hs = np.ascontiguousarray(sc)
+            A.msm_bigint(cid, hb, hs)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                res = A.msm_bigint(cid, hb, hs)
+            dt = (time.perf_counter() - t0) / 3
+            line += "  host-pointer %6.2f ms (exact=%s)" % (dt * 1e3, bool(np.array_equal(A.into_affine(cid, res), kg)))
         if direct is not None:
             # the narrow entries (ark_hip_msm_sw_small_device): scalars in the reference's own integer type
             dt_np = {"bool": np.uint8, "u8": np.uint8, "u16": np.uint16, "u32": np.uint32, "u64": np.uint64}[name]
