@@ -421,6 +421,55 @@ def main():
             except Exception as e:  # noqa: BLE001 -- side measurements never cost the headline line
                 others["%s MSM 2^%d" % (cname, lg)] = {"error": repr(e)[:200]}
 
+    # ---- the reference bench's non-uniform scalars (bench-templates/src/macros/ec.rs:244-372) at the headline size, plus a
+    # witness-like vector: msm_bigint on device-resident inputs, each against k*G.  Not the headline (uniform scalars are).
+    if others is not None:
+        try:
+            rng = np.random.default_rng(0x5CA1A)
+            nsk = n
+            bsk = bases if bases is not None else S.grow_bases(cid, nsk, A0, B0, R_MOD)   # (config 4 may have released them)
+            skew = {}
+
+            def limb_rows(v):
+                a = np.zeros((nsk, 4), dtype=np.uint64)
+                a[:, 0] = v
+                return a
+
+            def witness():   # 60 % zeros, 30 % ones, 5 % minus one, 5 % full width
+                a = S.gen_scalars(nsk, 0x717, R_MOD)
+                u = rng.random(nsk)
+                a[u < 0.60] = 0
+                one = np.zeros(4, dtype=np.uint64)
+                one[0] = 1
+                a[(u >= 0.60) & (u < 0.90)] = one
+                a[(u >= 0.90) & (u < 0.95)] = np.array(S.limbs4(R_MOD - 1), dtype=np.uint64)
+                return a
+
+            for label, make in (("bool", lambda: limb_rows(rng.integers(0, 2, size=nsk, dtype=np.uint64))),
+                                ("u8", lambda: limb_rows(rng.integers(0, 1 << 8, size=nsk, dtype=np.uint64))),
+                                ("u16", lambda: limb_rows(rng.integers(0, 1 << 16, size=nsk, dtype=np.uint64))),
+                                ("u32", lambda: limb_rows(rng.integers(0, 1 << 32, size=nsk, dtype=np.uint64))),
+                                ("u64", lambda: limb_rows(rng.integers(0, 1 << 64, size=nsk, dtype=np.uint64))),
+                                ("witness_60_30_5_5", witness)):
+                sk_h = make()
+                sk = torch.from_numpy(sk_h.view(np.int64)).cuda()
+                torch.cuda.synchronize()
+                want = S.mul_gen(cid, S.dlog_of_msm(sk_h, A0, B0, R_MOD), R_MOD)
+                res_sk = A.msm_bigint(cid, bsk, sk)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    res_sk = A.msm_bigint(cid, bsk, sk)
+                dt_sk = (time.perf_counter() - t1) / 3
+                skew[label] = {"ms_per_step": dt_sk * 1e3, "value": nsk / dt_sk,
+                               "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_sk), want))}
+                del sk
+            others["BLS12_381_G1 MSM 2^%d, non-uniform scalars through msm_bigint" % log_local] = skew
+            if bsk is not bases:
+                del bsk
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            others["non-uniform scalars"] = {"error": repr(e)[:200]}
+
     # ---- FFT leg (rank 0's GPU; the FFT config is single-GPU) ---------------------------------------
     # the reference's bench shapes (poly/benches/fft.rs:71-152): in-place FFT, IFFT and their coset variants on Vec<Fr>
     fft = None
