@@ -518,6 +518,7 @@ def main():
         npass = int(ft[1])
         # the same transform as a batch of 8 polynomials (three in flight: ark_hip_fft_batch_in_place_device)
         ys = [x.clone() for _ in range(8)]
+        torch.cuda.synchronize()       # (as above: torch's stream is not the library's)
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in ys])
         check(L.ark_hip_fft_batch_in_place_device(dom.field, sref, ptrs, 8, 0), "fft batch")
         check(L.ark_hip_synchronize(), "sync")
@@ -574,6 +575,7 @@ def main():
                 ref_out = O.fft(fid, x_h, kf, None, False, cores)
             cpu_s = (time.perf_counter() - t1) / creps
             z = x.clone()
+            torch.cuda.synchronize()   # the clone runs on torch's stream, the transform on the library's
             check(fwd(dom.field, sref, z.data_ptr()), "fft")
             check(L.ark_hip_synchronize(), "sync")
             same = bool(np.array_equal(z.cpu().numpy().view(np.uint64).reshape(-1), ref_out))

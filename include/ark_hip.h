@@ -136,7 +136,14 @@ int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, 
                          uint64_t* out_xyz);
 int ark_hip_msm_sw_small_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalar_bytes,
                                 int max_bits, uint64_t* out_xyz);
-/* Same with bases/scalars already in this GPU's memory (device pointers); out_xyz is a host pointer. */
+/* Same with bases/scalars already in this GPU's memory (device pointers); out_xyz is a host pointer.
+ * Scalar widths: msm_signed (variable_base/mod.rs:242-347) sorts the scalars into width classes (+-u1, +-u8, +-u16,
+ * +-u32, +-u64, the rest) and runs one MSM per class.  This entry runs ONE pipeline and plans it from the same classes:
+ * from 2^19 pairs, with nothing else of the context in flight, a probe measures the bit length of min(s, r - s) over a
+ * sample of 4096 scalars and -- unless they look uniform -- over all of them (one 40-byte read-back), and the window size and
+ * the number of windows follow the digits the scalars really have.  The result is the same group element either way;
+ * ARK_HIP_MSM_PROBE=0 plans every call for n uniform full-width scalars.  The host-pointer entry above estimates the
+ * classes from 4096 of the host scalars and takes only the window size from them. */
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalars_are_montgomery,
                           uint64_t* out_xyz);
 /* Asynchronous form: the device work is enqueued and the call returns; ark_hip_msm_wait blocks until the result is
