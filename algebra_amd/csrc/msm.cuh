@@ -553,6 +553,81 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_lazy_k
   }
   K::to_bucket(acc).store(cell);
 }
+// The same walk with every run cut into `parts` equal pieces, one lane each (narrow scalars at large n: msm_u16's ONE
+// window has 2^16 runs of n / 2^16 entries -- half a wave per SIMD walking 1024 entries each at 2^26; i16 half of that).
+// Lane (part, t) sums piece `part` of run order[t] into parts[part][bucket]; msm_sum_parts_kernel adds a run's pieces into
+// its bucket.  Heavy runs are skipped by both, as in the kernel above.  Parts are chosen on the host (msm_enqueue) only
+// where the slots cannot fill the chip's lanes and the runs are long; uniform 255-bit scalars never come here.
+template <class C>
+__global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_parts_kernel(const char* __restrict__ bases,
+                                                                  const u32* __restrict__ sorted,
+                                                                  const u32* __restrict__ offsets,
+                                                                  const u32* __restrict__ order, u32 nbuckets,
+                                                                  const u32* __restrict__ d_thresh, int HB, int LB,
+                                                                  u32 nparts, char* __restrict__ parts) {
+  typedef LazyK<C> K;
+  typedef typename K::FM F;
+  const u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) / K::LANES;
+  const u32 part = gid / nbuckets, t = gid - part * nbuckets;
+  if (part >= nparts) return;
+  const u32 g = order ? order[t] : t;
+  const u32 start = offsets[g], stop = offsets[g + 1];
+  const u32 len = stop - start;
+  if (len > *d_thresh) return;  // left to the heavy-bucket kernels
+  const u32 per = (len + nparts - 1) / nparts;
+  const u32 a = part * per, b = a + per;
+  u32 j = start + (a < len ? a : len);
+  const u32 end = start + (b < len ? b : len);
+  char* cell = parts + ((size_t)part * nbuckets + msm_slot_to_bucket(g, HB, LB)) * XYZZ<F>::BYTES;
+  typename K::Acc acc = K::inf();
+  if (j < end) {
+    u32 e = sorted[j];
+    u32 e1 = j + 1 < end ? sorted[j + 1] : 0;
+    Affine<F> p = Affine<F>::load(bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
+    for (;;) {
+      u32 e2 = 0;
+      Affine<F> p_next = p;
+      const bool more = j + 1 < end;
+      if (more) {
+        p_next = Affine<F>::load(bases + (size_t)(e1 & 0x7fffffffu) * Affine<F>::BYTES);
+        if (j + 2 < end) e2 = sorted[j + 2];
+      }
+      if (!p.is_zero()) {
+        if (K::madd(acc, p, (e >> 31) != 0)) {
+          typename K::Acc dbl;
+          K::mdbl(dbl, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
+          acc = dbl;
+        }
+      }
+      if (!more) break;
+      e = e1;
+      e1 = e2;
+      p = p_next;
+      j++;
+    }
+  }
+  K::to_bucket(acc).store(cell);
+}
+template <class C>
+__global__ void __launch_bounds__(256) msm_sum_parts_kernel(const u32* __restrict__ offsets, u32 nbuckets,
+                                                            const u32* __restrict__ d_thresh, int HB, int LB, u32 nparts,
+                                                            const char* __restrict__ parts, int accum,
+                                                            char* __restrict__ buckets) {
+  typedef LazyK<C> K;
+  typedef typename K::FM F;
+  const u32 g = (blockIdx.x * blockDim.x + threadIdx.x) / K::LANES;
+  if (g >= nbuckets) return;
+  const u32 len = offsets[g + 1] - offsets[g];
+  if (len > *d_thresh) return;
+  if (accum && len == 0) return;
+  const size_t bkt = msm_slot_to_bucket(g, HB, LB);
+  char* cell = buckets + bkt * XYZZ<F>::BYTES;
+  typename K::Acc acc = K::inf();
+  if (accum) acc = K::from_bucket(XYZZ<F>::load(cell));
+  for (u32 q = 0; q < nparts; q++) K::add(acc, XYZZ<F>::load(parts + ((size_t)q * nbuckets + bkt) * XYZZ<F>::BYTES));
+  K::to_bucket(acc).store(cell);
+}
+
 
 template <class C>
 __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_shared_lazy_kernel(
@@ -1305,7 +1380,7 @@ static constexpr int MSM_JOBS = 4;
 
 struct MsmWorkspace {
   DevBuf hctr, hlist, hitems, hpart, hfinal, keys, part, thist, toff, sorted, offsets, sums, buckets, lvlS[2], lvlA[2],
-      order, ohist, ooff, probe, big;
+      order, ohist, ooff, probe, big, parts;
   MsmJob jobs[MSM_JOBS];
   std::mutex mu;
   bool attr_set = false;  // dynamic-LDS opt-in done for this device
@@ -1319,7 +1394,7 @@ struct MsmWorkspace {
     hctr.release(); hlist.release(); hitems.release(); hpart.release(); hfinal.release();
     keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
     offsets.release(); sums.release();
-    order.release(); ohist.release(); ooff.release(); probe.release(); big.release();
+    order.release(); ohist.release(); ooff.release(); probe.release(); big.release(); parts.release();
     buckets.release();
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; }
     for (auto& e : grp_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -1612,6 +1687,31 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   if (big_on && ws.big.ensure(2 * big_region * 4)) return -3;
   bool lazy = false;  // Fp384 G1: the accumulate kernels on carry-free 28-bit limbs (fp28.cuh); ARK_HIP_MSM_LAZY=0: saturated
   if constexpr (C::LAZY_A) lazy = msm_lazy_enabled();
+  // Few slots with long runs (narrow scalars in one or two windows at large n): each run is walked by `run_parts` lanes
+  // (msm_accumulate_parts_kernel) until the lanes make two rounds over the chip's resident ones (2 waves x 4 SIMDs x 256 CUs x 64)
+  u32 run_parts = 1;
+  size_t parts_region = 0;
+  if (lazy && !pl.shared && !piece) {
+    static const size_t lanes_target = [] {
+      const char* e = getenv("ARK_HIP_MSM_PARTS_LANES");   // 0: never split runs
+      return e ? (size_t)atol(e) : (size_t)262144;   // two rounds of the resident lanes: measured better than one (u16 2^24 4.24 -> 3.82 ms,
+                                                     // u32 8.85 -> 6.88), four / eight rounds no better (profiles/r4_narrow_scalars.txt)
+    }();
+    double expect = (double)n * W;   // sorted entries: from the width classes where they were measured
+    if (have_widths) {
+      expect = 0.0;
+      for (int k = 1; k < MSM_WIDTH_CLASSES; k++) {
+        int need = (MSM_WIDTH_TOP[k] + 1 + c - 1) / c;
+        expect += (double)widths.count[k] * (need > W ? W : need);
+      }
+    }
+    const double mean_run = expect / (double)nb;
+    while (run_parts < 8 && nb * (size_t)(2 * run_parts) <= lanes_target && mean_run >= 32.0 * (2 * run_parts)) run_parts *= 2;
+    if (run_parts > 1) {
+      parts_region = (size_t)run_parts * nb * Pt::BYTES;
+      if (ws.parts.ensure(2 * parts_region)) return -3;
+    }
+  }
   const int W0 = ngroups == 2 ? (W + 1) / 2 : W;   // windows of group 0
   struct Group {
     int w0, Wg;
@@ -1730,10 +1830,19 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                          (const HeavyEntry*)G.hlist, G.offsets, G.sorted, (const char*)ws.hfinal.p, W, Bbits, HB, LB, G.buckets);
     } else {
       if constexpr (C::LAZY_A) {
-        if (lazy)
+        if (lazy && run_parts > 1) {
+          char* const pbuf = (char*)ws.parts.p + (size_t)(&G - grp) * parts_region;
+          hipLaunchKernelGGL((msm_accumulate_parts_kernel<C>), dim3((u32)((G.nslots * run_parts * C::FA::LANES + 255) / 256)),
+                             dim3(256), 0, st, (const char*)d_points, G.sorted, G.offsets, G.order, (u32)G.nslots,
+                             (const u32*)G.hctr + 2, HB, LB, run_parts, pbuf);
+          hipLaunchKernelGGL((msm_sum_parts_kernel<C>), dim3((u32)((G.nslots * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
+                             G.offsets, (u32)G.nslots, (const u32*)G.hctr + 2, HB, LB, run_parts, (const char*)pbuf, accum,
+                             G.buckets);
+        } else if (lazy) {
           hipLaunchKernelGGL((msm_accumulate_lazy_kernel<C>), dim3((u32)((G.nslots * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
                              (const char*)d_points, G.sorted, G.offsets, G.order, (u32)G.nslots, (const u32*)G.hctr + 2, HB, LB,
                              accum, G.buckets);
+        }
       }
       if (!lazy)
         hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3((u32)((G.nslots * C::FA::LANES + 255) / 256)), dim3(256), 0, st,
