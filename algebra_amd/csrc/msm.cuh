@@ -1707,6 +1707,10 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     }
     const double mean_run = expect / (double)nb;
     while (run_parts < 8 && nb * (size_t)(2 * run_parts) <= lanes_target && mean_run >= 32.0 * (2 * run_parts)) run_parts *= 2;
+    if (const char* e = getenv("ARK_HIP_MSM_RUN_PARTS")) {   // test / tuning knob: force 1, 2, 4 or 8 lanes per run
+      const int v = atoi(e);
+      if (v == 1 || v == 2 || v == 4 || v == 8) run_parts = (u32)v;
+    }
     if (run_parts > 1) {
       parts_region = (size_t)run_parts * nb * Pt::BYTES;
       if (ws.parts.ensure(2 * parts_region)) return -3;

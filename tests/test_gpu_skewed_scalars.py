@@ -181,3 +181,29 @@ def test_host_pointer_entry_plans_from_a_sample(setup):
     R = (1 << 256) % r
     mont = _limbs([(S.scalar_int(row) * R) % r for row in sc])
     assert np.array_equal(A.into_affine(s["cid"], A.msm_unchecked(s["cid"], hb, mont)), kg)
+
+
+@pytest.mark.parametrize("parts", [2, 4, 8])
+def test_runs_walked_by_several_lanes(setup, parts, monkeypatch):
+    """msm_accumulate_parts_kernel + msm_sum_parts_kernel (chosen by the library for few slots with long runs, from 2^22
+    narrow scalars on): forced here at 2^19 for uniform full-width scalars, a u16 vector and a witness-like one -- runs
+    shorter than the number of lanes (empty pieces), heavy runs next to split ones, G2 as lane pairs"""
+    s = setup
+    r = s["r"]
+    n = s["n"]
+    rng = np.random.default_rng(4000 + parts)
+    monkeypatch.setenv("ARK_HIP_MSM_RUN_PARTS", str(parts))
+    full = S.gen_scalars(n, 0x4242 + parts, r)
+    u16 = _unsigned(rng, n, 16)
+    wit = full.copy()
+    u = rng.random(n)
+    wit[u < 0.5] = 0
+    one = np.zeros(4, dtype=np.uint64)
+    one[0] = 1
+    wit[(u >= 0.5) & (u < 0.9)] = one
+    for sc in (full, u16, wit):
+        assert np.array_equal(_run_bigint(s, sc), _kg(s["cid"], sc, r))
+    d16 = u16[:, 0].astype(np.uint16)
+    import torch
+    t16 = torch.from_numpy(np.ascontiguousarray(d16).view(np.int16)).cuda()
+    assert np.array_equal(A.into_affine(s["cid"], A.msm_u16(s["cid"], s["bases"], t16)), _kg(s["cid"], u16, r))
