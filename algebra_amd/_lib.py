@@ -86,6 +86,8 @@ SYMBOLS = {
     "ark_hip_msm_cache_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
     "ark_hip_msm_sw_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ark_hip_msm_plan": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ark_hip_msm_plan_widths": (C.c_int, [C.c_int, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int)]),
     "ark_hip_msm_set_timing": (C.c_int, [C.c_int]),
     "ark_hip_msm_last_timing": (C.c_int, [C.POINTER(C.c_double)]),
     "ark_hip_sw_sum": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -1768,6 +1768,19 @@ int ark_hip_msm_plan(int curve, size_t n, int prepared, int* window_bits, int* w
   return 0;
 }
 
+// the plan of a plain MSM whose scalars have the given width classes (what ark_hip_msm_sw_device does after its probe)
+int ark_hip_msm_plan_widths(int curve, size_t n, uint32_t max_bits, const uint32_t counts[9], int* window_bits, int* windows) {
+  if (curve < 0 || curve > 4 || !counts) return ARK_HIP_ERR_ARG;
+  static_assert(MSM_WIDTH_CLASSES == 9, "the header documents nine classes");
+  MsmWidths w{};
+  w.max_bits = max_bits;
+  for (int k = 0; k < MSM_WIDTH_CLASSES; k++) w.count[k] = counts[k];
+  const MsmPlan pl = msm_plan_for_widths(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve), msm_lazy28(curve), w);
+  if (window_bits) *window_bits = pl.c;
+  if (windows) *windows = pl.W;
+  return 0;
+}
+
 int ark_hip_msm_set_timing(int enable) {
   ARK_SCOPE(sc);
   sc.c->msm_timing = enable != 0;

@@ -201,6 +201,9 @@ void msm_sample_widths_host(const void* h_scalars, size_t n, int mont, MsmWidths
   }
   for (int k = 0; k < MSM_WIDTH_CLASSES; k++) out->count[k] = (u32)((double)cnt[k] * (double)n / (double)seen);
 }
+// plan of a plain MSM whose width classes were MEASURED over all n scalars (msm_enqueue after K0; ark_hip_msm_plan_widths):
+// windows for the widest scalar unless fewer than 8 bits would be saved, window size from the digits the classes have
+static inline struct MsmPlan msm_plan_for_widths(size_t n, int field_bits, double mul_cost, bool lazy28, const MsmWidths& w);
 // true when the classes say "not n uniform full-width scalars": fewer than half wider than 128 bits
 static inline bool msm_widths_skewed(const MsmWidths& w) {
   u64 seen = 0, wide = 0;
@@ -1328,6 +1331,13 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
   return p;
 }
 
+static inline MsmPlan msm_plan_for_widths(size_t n, int field_bits, double mul_cost, bool lazy28, const MsmWidths& w) {
+  const int slack = 8;
+  int bits = field_bits;
+  if ((int)w.max_bits + 1 + slack <= field_bits) bits = (w.max_bits ? (int)w.max_bits : 1) + 1;
+  return msm_make_plan(n, bits, mul_cost, false, lazy28, &w);
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -1499,13 +1509,13 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
       if (msm_widths_skewed(sample)) {
         if (int rc = measure(1u, &widths)) return rc;
         have_widths = true;
-        const int slack = 8;   // fewer than 8 bits saved: the 255-bit layout stays
-        if ((int)widths.max_bits + 1 + slack <= C::S::BITS) plan_bits = (widths.max_bits ? (int)widths.max_bits : 1) + 1;
       }
     }
   }
   const MsmPlan pl = prepared ? *prepared
-                     : (piece ? *piece->plan : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A, have_widths ? &widths : nullptr));
+                     : piece  ? *piece->plan
+                     : have_widths ? msm_plan_for_widths(n, C::S::BITS, msm_mul_cost(C::ID), C::LAZY_A, widths)
+                                   : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A);
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;                      // sort slots
   const size_t nbk = pl.nbuckets();             // accumulated buckets

@@ -86,6 +86,20 @@ def msm_plan(curve, n, prepared=False):
     return c.value, w.value
 
 
+MSM_WIDTH_TOP = (0, 1, 8, 16, 32, 64, 128, 192, 256)
+
+
+def msm_plan_widths(curve, n, max_bits, counts):
+    """(window bits, windows) of a plain msm_bigint whose scalars fall into the width classes `counts` (nine entries:
+    scalars with MSM_WIDTH_TOP[k-1] < bits(min(s, r - s)) <= MSM_WIDTH_TOP[k]) -- ark_hip_msm_plan_widths: the plan the
+    device entry uses after its width probe (msm_signed's partition, variable_base/mod.rs:251-336)."""
+    arr = (C.c_uint32 * 9)(*[int(x) for x in counts])
+    c, w = C.c_int(), C.c_int()
+    check(lib().ark_hip_msm_plan_widths(cv.curve_id(curve), int(n), int(max_bits), arr, C.byref(c), C.byref(w)),
+          "ark_hip_msm_plan_widths")
+    return c.value, w.value
+
+
 class ResidentBases:
     """A base array pinned on the GPU (ark_hip_msm_bases_pin): while the pin lives the caller does NOT modify the
     array, and every host-array msm / msm_bigint / msm_u* whose bases are this array -- or a row range of it -- runs

@@ -207,6 +207,11 @@ int ark_hip_msm_prepared_multi(int n_gpus, const ark_hip_msm_bases* const* shard
 /* The window plan (widest window in bits, number of windows) the library picks for an MSM of n pairs on `curve`, plain
  * (prepared = 0) or over a prepared base set; pure host arithmetic. */
 int ark_hip_msm_plan(int curve, size_t n, int prepared, int* window_bits, int* windows);
+/* The plan of a plain msm_bigint whose n scalars fall into the given width classes of b = bits(min(s, r - s)) -- counts[k]
+ * scalars with TOP[k-1] < b <= TOP[k], TOP = {0, 1, 8, 16, 32, 64, 128, 192, 256} (msm_signed's partition, mod.rs:251-285,
+ * with two classes above u64) -- and whose widest has max_bits: what ark_hip_msm_sw_device does after its probe.  Host
+ * arithmetic only. */
+int ark_hip_msm_plan_widths(int curve, size_t n, uint32_t max_bits, const uint32_t counts[9], int* window_bits, int* windows);
 /* Per-phase device times of the last MSM finished on this device with timing enabled (ms):
  * [digits, partition histogram + scan, partition scatter + finish + bucket order, accumulate (incl. heavy
  *  buckets), reduce, total, window_bits, windows] */

@@ -176,6 +176,66 @@ def test_msm_plan_is_host_only_and_sane():
         assert (c.value, w.value) == want, (curve, logn, prepared, c.value, w.value)
 
 
+def test_msm_plan_follows_the_width_classes():
+    # ark_hip_msm_plan_widths: the plan msm_bigint uses after its width probe (the GPU form of msm_signed's partition,
+    # variable_base/mod.rs:251-336).  Host arithmetic only.
+    import ctypes as C
+    import numpy as np
+    from algebra_amd._lib import lib
+    L = lib()
+    TOP = (0, 1, 8, 16, 32, 64, 128, 192, 256)
+    fbits = {0: 254, 1: 255, 2: 253, 3: 253, 4: 255}
+
+    def plan(curve, n, max_bits, counts):
+        arr = (C.c_uint32 * 9)(*[int(x) for x in counts])
+        c, w = C.c_int(), C.c_int()
+        assert L.ark_hip_msm_plan_widths(curve, n, max_bits, arr, C.byref(c), C.byref(w)) == 0
+        return c.value, w.value
+
+    def uniform(curve, n):
+        c, w = C.c_int(), C.c_int()
+        assert L.ark_hip_msm_plan(curve, n, 0, C.byref(c), C.byref(w)) == 0
+        return c.value, w.value
+
+    for curve in range(5):
+        for logn in (19, 22, 24, 26):
+            n = 1 << logn
+            # every scalar full width: the plan of ark_hip_msm_plan
+            assert plan(curve, n, fbits[curve], [0] * 8 + [n]) == uniform(curve, n)
+            # one class only: a single window of exactly the buckets its digits reach where that fits, never c > bits + 1
+            for k, top in enumerate(TOP[1:6], start=1):
+                cnt = [0] * 9
+                cnt[k] = n
+                c, w = plan(curve, n, top, cnt)
+                assert c <= max(3, top + 1) and c * w >= top + 1 and (w - 1) * c < top + 1 + w, (curve, logn, top, c, w)
+            assert plan(curve, n, 16, [0, 0, 0, n, 0, 0, 0, 0, 0]) == (17, 1)
+            # a witness: few full-width scalars among zeros and ones -> the window size of a much smaller MSM, same coverage
+            wit = [n * 6 // 10, n * 35 // 100, 0, 0, 0, 0, 0, 0, n - n * 6 // 10 - n * 35 // 100]
+            c, w = plan(curve, n, fbits[curve], wit)
+            cu, wu = uniform(curve, n)
+            assert c <= cu and c * w >= fbits[curve] and (c < cu or logn < 22), (curve, logn, c, w, cu, wu)
+            # all zero: still a valid (tiny) plan
+            c, w = plan(curve, n, 0, [n] + [0] * 8)
+            assert c >= 3 and w == 1
+    # random histograms: the windows always cover the widest scalar, a wider maximum never plans fewer total bits
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        curve = int(rng.integers(0, 5))
+        n = 1 << int(rng.integers(19, 27))
+        wts = rng.random(9) * (rng.random(9) < 0.5)
+        if wts.sum() == 0:
+            wts[int(rng.integers(0, 9))] = 1.0
+        cnt = np.floor(wts / wts.sum() * n).astype(np.int64)
+        top_class = max(k for k in range(9) if cnt[k] > 0)
+        lo = TOP[top_class - 1] + 1 if top_class else 0
+        hi = min(TOP[top_class], fbits[curve] - 1) if top_class else 0   # folded magnitudes are below r/2
+        max_bits = int(rng.integers(lo, max(lo, hi) + 1))
+        c, w = plan(curve, n, max_bits, cnt)
+        assert 3 <= c <= 26 and w >= 1 and c * w >= min(max_bits + 1, fbits[curve]), (curve, n, max_bits, cnt.tolist(), c, w)
+    assert L.ark_hip_msm_plan_widths(9, 1, 0, (C.c_uint32 * 9)(), None, None) == -1
+    assert L.ark_hip_msm_plan_widths(1, 1, 0, None, None, None) == -1
+
+
 def test_synth_discrete_log_identity_is_exact_for_large_indices():
     # tools/synth.py::dlog_of_msm backs every at-size parity check (k*G identity): its chunked uint64 sums must stay exact
     # for the largest index ranges used (a 2^28-pair job overflowed the first version's chunks of 32)

@@ -63,6 +63,7 @@ for step in "$@"; do
     n2gloo)
       (ARK_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 3 --warmup 1 --log-n 21 --fft-log-n 20 --fft-steps 4 > $O/bench_n2_gloo.json) 2> $O/bench_n2_gloo.err ;;
     soak) (timeout 1200 python tools/soak.py ${a[1]:-200} 2>&1 | tail -4) > $O/soak.log ;;
+    skewsoak) (timeout 1500 python tools/skew_soak.py ${a[1]:-100} ${a[2]:-2024} 2>&1 | grep -v "^it " | tail -8) > $O/skew_soak.log ;;
     mulbench)
       for b in algebra_amd/csrc/ubench/mulbench_*.bin; do (echo "== $b"; timeout 120 $b) >> $O/mulbench.txt 2>> $O/mulbench.err; done ;;
     msm)
