@@ -1479,7 +1479,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   int plan_bits = sbytes ? sbits + 1 : C::S::BITS;
   MsmWidths widths{};
   bool have_widths = false;
-  if (!sbytes && !prepared && !piece && n >= ((size_t)1 << 19)) {
+  if (!sbytes && !piece && n >= ((size_t)1 << 19)) {
     static const bool probe_on = [] {
       const char* e = getenv("ARK_HIP_MSM_PROBE");
       return !(e && atoi(e) == 0);
@@ -1508,7 +1508,16 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
       if (int rc = measure((u32)(n / 4096), &sample)) return rc;
       if (msm_widths_skewed(sample)) {
         if (int rc = measure(1u, &widths)) return rc;
-        have_widths = true;
+        if (!prepared) {
+          have_widths = true;
+        } else if (widths.max_bits <= 48) {   // (u32: 8.9 ms prepared, 6.8 plain; u64: 11.0 prepared, 12.4 plain -- at 2^24)
+          // A prepared set shares ONE bucket set of 2^(c-1) buckets (c = 22 at 2^24) between all windows: right for
+          // n x 12 digits, wrong for scalars that have one to four -- u16 at 2^24: 12.8 ms against the plain path's 3.8.
+          // Row 0 of the table is the base set itself (2^0 P_i): scalars no wider than 48 bits take the plain pipeline on it.
+          prepared = nullptr;
+          wstride = 0;
+          have_widths = true;
+        }
       }
     }
   }

@@ -207,3 +207,23 @@ def test_runs_walked_by_several_lanes(setup, parts, monkeypatch):
     import torch
     t16 = torch.from_numpy(np.ascontiguousarray(d16).view(np.int16)).cuda()
     assert np.array_equal(A.into_affine(s["cid"], A.msm_u16(s["cid"], s["bases"], t16)), _kg(s["cid"], u16, r))
+
+
+def test_prepared_set_with_narrow_and_mixed_scalars(setup):
+    """a prepared base set asked for scalars no wider than 48 bits runs the plain pipeline on row 0 of its table (= the
+    bases); anything with wider scalars keeps the prepared plan; then a uniform call on the same handle"""
+    import torch
+    s = setup
+    r, n = s["r"], s["n"]
+    rng = np.random.default_rng(31)
+    pb = A.PreparedBases(s["cid"], s["bases"])
+    try:
+        cases = [np.zeros((n, 4), dtype=np.uint64), _unsigned(rng, n, 1), _unsigned(rng, n, 16), _unsigned(rng, n, 64)]
+        mixed = _unsigned(rng, n, 8)
+        mixed[::9] = S.gen_scalars((n + 8) // 9, 0x51, r)
+        cases += [mixed, S.gen_scalars(n, 0x52, r)]
+        for sc in cases:
+            d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+            assert np.array_equal(A.into_affine(s["cid"], pb.msm_bigint(d)), _kg(s["cid"], sc, r))
+    finally:
+        pb.free()
