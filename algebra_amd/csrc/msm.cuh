@@ -855,15 +855,27 @@ static __global__ void __launch_bounds__(256) msm_find_heavy_kernel(const u32* _
   u32 g = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 thresh = msm_heavy_threshold(offsets, nbuckets, forced);  // the same value in every lane
   if (g == 0) ctr[2] = thresh;                                        // for the kernels that follow
-  if (g >= nbuckets) return;
-  u32 cnt = offsets[g + 1] - offsets[g];
-  if (cnt <= thresh) return;
   const u32 chunk = msm_heavy_chunk(offsets[nbuckets]);
-  u32 k = (cnt + chunk - 1) / chunk;
-  u32 first = atomicAdd(&ctr[0], k);
-  u32 slot = atomicAdd(&ctr[1], 1u);
-  list[slot] = HeavyEntry{g, first, k};
-  for (u32 q = 0; q < k; q++) items[first + q] = make_uint2(g, q);
+  u32 k = 0, first = 0;
+  if (g < nbuckets) {
+    const u32 cnt = offsets[g + 1] - offsets[g];
+    if (cnt > thresh) {
+      k = (cnt + chunk - 1) / chunk;
+      first = atomicAdd(&ctr[0], k);
+      const u32 slot = atomicAdd(&ctr[1], 1u);
+      list[slot] = HeavyEntry{g, first, k};
+    }
+  }
+  // the chunk items of a run: a few by its own lane, many (one bucket holding half of a 2^24 witness: 2048 chunks) by the wave
+  if (k && k <= 16)
+    for (u32 q = 0; q < k; q++) items[first + q] = make_uint2(g, q);
+  unsigned long long big = __ballot(k > 16);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const u32 kk = (u32)__shfl((int)k, src), ff = (u32)__shfl((int)first, src), gg = (u32)__shfl((int)g, src);
+    for (u32 q = threadIdx.x & 63u; q < kk; q += 64u) items[ff + q] = make_uint2(gg, q);
+  }
 }
 
 // Point additions of the reduction / heavy-run kernels.  `Pt` is a point as it lives in memory (canonical XYZZ over the

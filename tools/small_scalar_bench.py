@@ -28,7 +28,7 @@ def to_limbs(vals):
 
 def main():
     logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    curve = "BLS12_381_G1"
+    curve = os.environ.get("SKEW_CURVE", "BLS12_381_G1")
     cid = cv.curve_id(curve)
     r = S.R[cv.scalar_field(cid)]
     n = 1 << logn
