@@ -7,10 +7,15 @@
 #   bench[:ARGS]         python bench.py ARGS                                 -> bench.json / bench.err
 #   kt                   rocprofv3 --kernel-trace of a short bench            -> kernel_stats.txt
 #   pmc                  FETCH_SIZE / WRITE_SIZE passes + gather calibration  -> pmc_traffic.json, pmc_*.txt
+#                        (needs csrc/ubench/ubench.bin: hipcc --offload-arch=gfx950 -O3 -o ubench.bin ubench.hip)
 #   sq                   SQ counters (VALU / wait / busy) of a short bench    -> pmc_sq.txt
 #   env:VAR=VAL          export VAR=VAL for the steps that follow (A/B switches: ARK_HIP_FFT_LAZY=0, ARK_HIP_MSM_LAZY=0)
 #   n2gloo               bench.py --gpus 2 over gloo, ranks sharing the GPU   -> bench_n2_gloo.json
 #   soak:N               tools/soak.py N                                      -> soak.log
+#   skewsoak:N[:SEED]    tools/skew_soak.py N SEED (random width-class mixtures, five curves) -> skew_soak.log
+#   ktpy:SCRIPT[:ARGS]   rocprofv3 --kernel-trace of python tools/SCRIPT ARGS; KT_TIMELINE=N also lists the last N launches
+#                        in start order with the idle gaps between them        -> kernel_stats_SCRIPT_ARGS.txt
+#   pyv:SCRIPT[:ARGS]    python tools/SCRIPT on the shipped library and on every algebra_amd/variants/*.so -> pyv_SCRIPT.txt
 #   mulbench             csrc/ubench/mulbench_*.bin (prebuilt, travel as .bin)-> mulbench.txt
 #   msm:CURVE:LOGN[:MODE[:REPS]]   tools/msm_bench.py, ARK_HIP_MSM_LAZY=1 and 0 -> msm.txt
 #   fft[:LO:HI]          tools/fft_shapes.py (the reference's five bench shapes), ARK_HIP_FFT_LAZY=1 and 0 -> fft.txt
