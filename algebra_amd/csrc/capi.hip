@@ -1048,7 +1048,7 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
   const bool shared = allow_shared && npieces >= 2 && npieces <= 16;
   MsmPlan plan{};
   if (shared) {
-    // the window size from the width classes of a spread sample of the host scalars (msm.cuh K0: what the device entry
+    // the window size from the width classes of a spread sample (~1024) of the host scalars (msm.cuh K0: what the device entry
     // measures exactly); the layout stays the full-width one -- a sample cannot bound the widest scalar
     MsmWidths widths{};
     bool skewed = false;

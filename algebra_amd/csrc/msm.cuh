@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __rest
   }
 }
 
-// The same classes for HOST scalars, estimated from a spread sample of at most 4096 of them (the streamed entries plan
+// The same classes for HOST scalars, estimated from a spread sample of about 1024 of them (the streamed entries plan
 // before the first piece is uploaded and cannot wait for a device pass over all scalars): counts scaled to n, max_bits
 // = the field's -- an estimate may choose the window size, never the number of windows.
 template <class SP>
@@ -185,7 +185,7 @@ void msm_sample_widths_host(const void* h_scalars, size_t n, int mont, MsmWidths
   *out = MsmWidths{};
   out->max_bits = (u32)SP::BITS;
   if (n == 0) return;
-  const size_t stride = n > 4096 ? n / 4096 : 1;
+  const size_t stride = n > 1024 ? n / 1024 : 1;   // (1024: a Montgomery -> canonical product per sample costs ~30 ns of host time)
   size_t seen = 0;
   u32 cnt[MSM_WIDTH_CLASSES] = {0};
   for (size_t i = 0; i < n; i += stride) {

@@ -144,7 +144,7 @@ int ark_hip_msm_sw_small_device(int curve, const void* d_bases, const void* d_sc
  * the number of windows follow the digits the scalars really have.  The result is the same group element either way;
  * ARK_HIP_MSM_PROBE=0 plans every call for n uniform full-width scalars.  A prepared base set whose scalars turn out no wider
  * than 48 bits runs this plain pipeline on row 0 of its table (the bases themselves).  The host-pointer entry above estimates the
- * classes from 4096 of the host scalars and takes only the window size from them. */
+ * classes from about 1024 of the host scalars and takes only the window size from them. */
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalars_are_montgomery,
                           uint64_t* out_xyz);
 /* Asynchronous form: the device work is enqueued and the call returns; ark_hip_msm_wait blocks until the result is

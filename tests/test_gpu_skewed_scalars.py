@@ -171,7 +171,7 @@ def test_host_pointer_entry_plans_from_a_sample(setup):
     rng = np.random.default_rng(23)
     sc = np.zeros((n, 4), dtype=np.uint64)
     sc[:, 0] = rng.integers(0, 2, size=n, dtype=np.uint64)
-    stride = n // 4096
+    stride = n // 1024                              # the host sampler visits every (n / 1024)-th scalar
     wide = S.gen_scalars(n, 0x99, r)
     off = np.arange(n) % stride != 0                 # every index the sampler does not visit
     pick = off & (rng.random(n) < 0.03)
