@@ -227,3 +227,36 @@ def test_prepared_set_with_narrow_and_mixed_scalars(setup):
             assert np.array_equal(A.into_affine(s["cid"], pb.msm_bigint(d)), _kg(s["cid"], sc, r))
     finally:
         pb.free()
+
+
+def test_switches_off_give_the_same_points():
+    """the A/B switches (read once per process) in a fresh process: probe, sliced pass B, side stream and run parts all
+    off -- the round-3 pipeline with this round's sort counters -- against k*G on a witness-like vector and a u16 one"""
+    import subprocess
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tools")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch
+import algebra_amd as A
+import oracle_lib as O
+import synth as S
+from algebra_amd import curves as cv
+cid = O.CID["BLS12_381_G1"]; r = S.R[cv.scalar_field(cid)]; n = 1 << 19
+bases = S.grow_bases(cid, n, S.A0, S.B0, r)
+rng = np.random.default_rng(5)
+wit = S.gen_scalars(n, 9, r); u = rng.random(n); wit[u < 0.6] = 0
+one = np.zeros(4, dtype=np.uint64); one[0] = 1; wit[(u >= 0.6) & (u < 0.95)] = one
+u16 = np.zeros((n, 4), dtype=np.uint64); u16[:, 0] = rng.integers(0, 1 << 16, size=n, dtype=np.uint64)
+for sc in (wit, u16):
+    d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+    k = S.dlog_of_msm(sc, S.A0, S.B0, r)
+    want = O.to_affine(cid, O.scalar_mul(cid, O.generator(cid), S.limbs4(k)))
+    assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, bases, d)), want)
+print("switches-off ok")
+'''
+    env = dict(os.environ, ARK_HIP_MSM_PROBE="0", ARK_HIP_MSM_BIG_SLICES="0", ARK_HIP_MSM_HEAVY_SIDE="0",
+               ARK_HIP_MSM_PARTS_LANES="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "switches-off ok" in out.stdout, out.stderr[-2000:]
