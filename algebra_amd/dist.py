@@ -2,11 +2,15 @@
 it, on torch.distributed.
 
 The reference itself splits an MSM by base range and sums the chunk results
-(ec/src/scalar_mul/variable_base/mod.rs:521-557); across GPUs the same split needs exactly one exchange:
-every rank contributes one Projective point (3 field elements: 144 B for BLS12-381 G1).  The reduction
-operator is elliptic-curve addition, which RCCL does not offer as a reduce op, so the collective is an
-all-gather (latency-bound, a few microseconds over xGMI) followed by world_size-1 point additions on
-the host.  No other data-path collective exists: bases and scalars never leave their GPU.
+(ec/src/scalar_mul/variable_base/mod.rs:521-557); across GPUs the same split needs exactly one exchange.  The
+reduction operator is elliptic-curve addition, which RCCL does not offer as a reduce op, so the collective is an
+all-gather (latency-bound, a few microseconds over xGMI):
+  * inside the library (comm_init done, device-resident shards): every rank contributes its per-window PART SUMS
+    (a 64-byte header + at most 1024 XYZZ points, ~40 KB) straight from device memory, one kernel adds the copies of
+    every part and ONE host tail runs on the sums of the whole job (capi.hip: ark_hip_msm_sw_device_sharded);
+  * on torch.distributed (gloo on CPU, or no library communicator): every rank contributes one finished Projective point
+    (3 field elements: 144 B for BLS12-381 G1) and world_size - 1 point additions follow on the host.
+No other data-path collective exists: bases and scalars never leave their GPU.
 """
 import numpy as np
 
