@@ -1690,7 +1690,11 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     const char* e = getenv("ARK_HIP_MSM_HEAVY_SIDE");
     return !(e && atoi(e) == 0);
   }();
-  const bool heavy_side = heavy_side_env && ngroups == 1 && !piece && n >= ((size_t)1 << 20);
+  static const int heavy_side_min_log = [] {
+    const char* e = getenv("ARK_HIP_MSM_HEAVY_SIDE_MIN_LOG");   // tuning knob: smallest log2 n that takes the side stream
+    return e ? atoi(e) : 20;
+  }();
+  const bool heavy_side = heavy_side_env && ngroups == 1 && !piece && n >= ((size_t)1 << heavy_side_min_log);
   if (ngroups == 2 || heavy_side) {
     if (!ws.side) ARK_HIP_TRY(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
     for (auto& e : ws.grp_ev)
