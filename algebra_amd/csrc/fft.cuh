@@ -72,7 +72,9 @@ struct FftPassArgs {
   int zskip;   // first executed pass of a degree-aware transform (fft.rs:29-71): the input holds only the first
                // n >> zskip coefficients, the first zskip stages are not run -- their effect on a zero-padded input,
                // x'[pos] = x[pos mod d] * w^((pos mod d) * bitrev_z(pos / d)), d = n >> zskip, is applied by the loads
-  const u32* roots;    // w^j, j < n/2
+  const u32* roots;    // w^j, j < n/2; compact: followed by the table of every later stage (below)
+  int compact;         // 1: roots holds T_0 | T_1 | ... with T_s[i] = w^(i << s), i < n >> (s + 1) -- T_s starts at entry
+                       // n - (n >> s): a stage-s twiddle is T_s[index], not roots[index << s] (round 5)
   const u32* pre_lo;   // first pass: x[pos] *= pre_hi[pos >> 10] * pre_lo[pos & 1023]   (nullable)
   const u32* pre_hi;
   const u32* post_lo;  // last pass: out[pos] *= post_hi[pos >> 10] * post_lo[pos & 1023]  (nullable)
@@ -181,6 +183,10 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
   for (; ls + 1 < kp; ls += 2) {
     const u32 lg = 1u << (kp - 1 - ls), qt = lg >> 1;
     const int s = a.s0 + ls;
+    // where stage s and stage s + 1 find their twiddles: the stage's own compact table, or the full table strided
+    const size_t nn = (size_t)1 << k;
+    const size_t sbase0 = a.compact ? nn - (nn >> s) : 0, sbase1 = a.compact ? nn - (nn >> (s + 1)) : 0;
+    const int ssh0 = a.compact ? 0 : s, ssh1 = a.compact ? 0 : s + 1;
     u32 idx[FFT_MAX_EPT / 4][4];
     uint4 wa0[FFT_MAX_EPT / 4][2], wa1[FFT_MAX_EPT / 4][2], wb[FFT_MAX_EPT / 4][2];
     bool ha0[FFT_MAX_EPT / 4], hb[FFT_MAX_EPT / 4];
@@ -194,32 +200,32 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
         else { gq = g & ((1u << (kp - 2)) - 1u); r = g >> (kp - 2); }
         const u32 j0 = gq & (qt - 1u);
         const u32 q0 = ((gq & ~(qt - 1u)) << 2) | j0;
-        size_t ta0, ta1, tb;
+        size_t ta0, ta1, tb;   // twiddle exponents >> stage: entries of the stage's compact table
         if (!a.last) {
           const size_t col = ((size_t)mid << t) | r;
 #pragma unroll
           for (int m = 0; m < 4; m++) idx[it][m] = ((q0 + m * qt) << t) | r;
-          ta0 = ((((size_t)j0) << lo_shift) | col) << s;
-          ta1 = ((((size_t)(j0 + qt)) << lo_shift) | col) << s;
-          tb = ((((size_t)j0) << lo_shift) | col) << (s + 1);
+          ta0 = (((size_t)j0) << lo_shift) | col;
+          ta1 = (((size_t)(j0 + qt)) << lo_shift) | col;
+          tb = ta0;
         } else {
 #pragma unroll
           for (int m = 0; m < 4; m++) idx[it][m] = (r << kp) | (q0 + m * qt);
-          ta0 = (size_t)j0 << s;
-          ta1 = (size_t)(j0 + qt) << s;
-          tb = (size_t)j0 << (s + 1);
+          ta0 = (size_t)j0;
+          ta1 = (size_t)(j0 + qt);
+          tb = ta0;
         }
-        const uint4* g1 = (const uint4*)(a.roots + ta1 * F::N);  // never the trivial twiddle: j0 + lg/2 > 0
+        const uint4* g1 = (const uint4*)(a.roots + (sbase0 + (ta1 << ssh0)) * F::N);  // never the trivial twiddle: j0 + lg/2 > 0
         wa1[it][0] = g1[0];
         wa1[it][1] = g1[1];
         if (ta0 != 0) {
-          const uint4* g0 = (const uint4*)(a.roots + ta0 * F::N);
+          const uint4* g0 = (const uint4*)(a.roots + (sbase0 + (ta0 << ssh0)) * F::N);
           wa0[it][0] = g0[0];
           wa0[it][1] = g0[1];
           ha0[it] = true;
         }
         if (tb != 0) {
-          const uint4* g2 = (const uint4*)(a.roots + tb * F::N);
+          const uint4* g2 = (const uint4*)(a.roots + (sbase1 + (tb << ssh1)) * F::N);
           wb[it][0] = g2[0];
           wb[it][1] = g2[1];
           hb[it] = true;
@@ -260,6 +266,8 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
   for (; ls < kp; ls++) {
     const u32 lg = 1u << (kp - 1 - ls);
     const int s = a.s0 + ls;
+    const size_t sbase = a.compact ? ((size_t)1 << k) - (((size_t)1 << k) >> s) : 0;
+    const int ssh = a.compact ? 0 : s;
     u32 i0s[FFT_MAX_EPT / 2], i1s[FFT_MAX_EPT / 2];
     uint4 w0[FFT_MAX_EPT / 2], w1[FFT_MAX_EPT / 2];
     bool hasw[FFT_MAX_EPT / 2];
@@ -275,18 +283,18 @@ __global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __rest
           u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
           i0 = (q << t) | r;
           i1 = i0 + (lg << t);
-          tw = ((((size_t)(q & (lg - 1))) << lo_shift) | ((size_t)mid << t) | r) << s;
+          tw = (((size_t)(q & (lg - 1))) << lo_shift) | ((size_t)mid << t) | r;
         } else {
           u32 qq = b & ((1u << (kp - 1)) - 1u), r = b >> (kp - 1);
           u32 q = ((qq & ~(lg - 1)) << 1) | (qq & (lg - 1));
           i0 = (r << kp) | q;
           i1 = i0 + lg;
-          tw = ((size_t)(q & (lg - 1))) << s;
+          tw = (size_t)(q & (lg - 1));
         }
         i0s[it] = i0;
         i1s[it] = i1;
         if (tw != 0) {  // twiddle loads of the whole stage go out before any butterfly waits on one
-          const uint4* g = (const uint4*)(a.roots + tw * F::N);
+          const uint4* g = (const uint4*)(a.roots + (sbase + (tw << ssh)) * F::N);
           w0[it] = g[0];
           w1[it] = g[1];
           hasw[it] = true;
@@ -856,8 +864,25 @@ __global__ void __launch_bounds__(256) fft_axis_kernel(const u32* src, u32* dst,
 }
 
 // ---- host side: cached twiddle tables + pass plan ------------------------------------------------
+// T_s[i] = T_0[i << s] for every stage s >= 1, packed behind T_0 (entry n - (n >> s) onwards): one thread per entry of
+// the tail [n/2, n - 1)
+template <class FP>
+__global__ void __launch_bounds__(256) fft_compact_tables_kernel(u32* __restrict__ tab, int k) {
+  const size_t n = (size_t)1 << k;
+  const size_t e = n / 2 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // destination entry
+  if (e >= n - 1) return;
+  // stage of entry e: the s with n - (n >> s) <= e < n - (n >> (s + 1)), i.e. s = number of leading ones of e in k bits
+  const size_t gap = n - e;                      // in (n >> (s + 1), n >> s]
+  const int s = k - (64 - __clzll((unsigned long long)(gap - 1)));   // gap - 1 in [n >> (s+1), n >> s): top bit k - s - 1
+  const size_t i = e - (n - (n >> s));
+  const uint4* src = (const uint4*)(tab + (i << s) * 8);
+  uint4* dst = (uint4*)(tab + e * 8);
+  const uint4 a = src[0], b = src[1];
+  dst[0] = a;
+  dst[1] = b;
+}
 struct FftTables {
-  DevBuf roots;   // n/2 entries (form 1: limbs 0..7 of the unpacked 9 x 29-bit entries)
+  DevBuf roots;   // n/2 entries (form 1: limbs 0..7 of the unpacked 9 x 29-bit entries); form 0: n - 1 entries, compact per stage
   DevBuf roots9;  // form 1: limb 8 of every entry
   DevBuf small;   // scratch for the two-level build + generator copy
 };
@@ -922,6 +947,11 @@ struct FftWorkspace {
 };
 static inline bool fft_lazy_env() {
   static const bool v = getenv("ARK_HIP_FFT_LAZY") && getenv("ARK_HIP_FFT_LAZY")[0] == '1';
+  return v;
+}
+// ARK_HIP_FFT_COMPACT=0: every stage reads the size-n table strided (the round-4 access pattern; A/B only)
+static inline bool fft_compact_env() {
+  static const bool v = [] { const char* e = getenv("ARK_HIP_FFT_COMPACT"); return !(e && e[0] == '0'); }();
   return v;
 }
 struct FftTimings { float total = 0; float pass[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int npass = 0; };
@@ -996,7 +1026,9 @@ int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
     ~Guard() { if (t) { t->roots.release(); t->roots9.release(); t->small.release(); } }
   } guard{&tb};
   size_t half = k >= 1 ? ((size_t)1 << (k - 1)) : 1;
-  if (tb.roots.ensure(half * F::BYTES)) return -3;
+  // the saturated kernel's table carries every stage's twiddles compactly: T_0 (n/2) | T_1 (n/4) | ... = n - 1 entries
+  const bool compact = !form29 && k >= 2;
+  if (tb.roots.ensure((compact ? 2 * half : half) * F::BYTES)) return -3;
   if (form29 && ARK_FFT29_UNPACKED_TW && tb.roots9.ensure(half * 4)) return -3;
   const int LB = 11;
   size_t nlo = half < ((size_t)1 << LB) ? half : ((size_t)1 << LB);
@@ -1020,6 +1052,9 @@ int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
     hipLaunchKernelGGL((fft_expand_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, d_lo, d_hi,
                        LB, half, (u32*)tb.roots.p);
   }
+  if (compact)
+    hipLaunchKernelGGL((fft_compact_tables_kernel<FP>), dim3((u32)((half - 1 + 255) / 256)), dim3(256), 0, stream,
+                       (u32*)tb.roots.p, k);
   if (form29 && ARK_FFT29_UNPACKED_TW)
     hipLaunchKernelGGL((fft_unpack_table_kernel<FP>), dim3((u32)((half + 255) / 256)), dim3(256), 0, stream, (u32*)tb.roots.p,
                        half, (u32*)tb.roots9.p);
@@ -1212,6 +1247,7 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     a.k = k; a.s0 = s0; a.kp = kps[i]; a.t = ti; a.last = (i == P - 1) ? 1 : 0;
     a.zskip = (i == 0) ? zlog : 0;
     a.roots = roots;
+    a.compact = (!lazy29 && k >= 2 && fft_compact_env()) ? 1 : 0;
     a.pre_lo = (i == 0) ? pre_lo : nullptr;
     a.pre_hi = (i == 0) ? pre_hi : nullptr;
     a.post_lo = a.last ? post_lo : nullptr;

@@ -8,6 +8,7 @@
 #   kt                   rocprofv3 --kernel-trace of a short bench            -> kernel_stats.txt
 #   pmc                  FETCH_SIZE / WRITE_SIZE passes + gather calibration  -> pmc_traffic.json, pmc_*.txt
 #                        (needs csrc/ubench/ubench.bin: hipcc --offload-arch=gfx950 -O3 -o ubench.bin ubench.hip)
+#   pmcpy:SCRIPT[:ARGS]  FETCH_SIZE / WRITE_SIZE passes of python tools/SCRIPT ARGS   -> pmcpy_SCRIPT.txt
 #   sq                   SQ counters (VALU / wait / busy) of a short bench    -> pmc_sq.txt
 #   env:VAR=VAL          export VAR=VAL for the steps that follow (A/B switches: ARK_HIP_FFT_LAZY=0, ARK_HIP_MSM_LAZY=0)
 #   n2gloo               bench.py --gpus 2 over gloo, ranks sharing the GPU   -> bench_n2_gloo.json
@@ -59,6 +60,14 @@ for step in "$@"; do
       python tools/rocpd_stats.py $(db p_write) --pmc --min-us 100 > $O/pmc_write.txt 2>> $O/post.err
       python tools/pmc_traffic.py $(db p_fetch) $(db p_write) 24 22 $(db p_cal) 33554432 > $O/pmc_traffic.json 2>> $O/post.err
       rm -rf $O/p_fetch $O/p_write $O/p_cal ;;
+    pmcpy)   # pmcpy:SCRIPT[:ARGS]: FETCH_SIZE and WRITE_SIZE passes (separate runs) of python tools/SCRIPT ARGS -> pmcpy_SCRIPT<suffix>.txt
+      cd /tmp
+      timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/p_pf -o f -- python $R/tools/${a[1]} ${a[@]:2} > $O/pmcpy.out 2> $O/pmcpy.err
+      timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/p_pw -o w -- python $R/tools/${a[1]} ${a[@]:2} >> $O/pmcpy.out 2>> $O/pmcpy.err
+      cd $R
+      (echo "== ${a[@]:1} $suffix (raw counters, KiB; FETCH_SIZE counts half of a wide streaming read on gfx950)"
+       python tools/rocpd_stats.py $(db p_pf) --pmc --min-us 50; python tools/rocpd_stats.py $(db p_pw) --pmc --min-us 50) >> $O/pmcpy_${a[1]%.py}$suffix.txt 2>> $O/post.err
+      rm -rf $O/p_pf $O/p_pw ;;
     sq)
       cd /tmp
       timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/p_sq -o s -- $SHORT > $O/sq.out 2> $O/sq.err
