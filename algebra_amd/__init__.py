@@ -16,4 +16,4 @@ from .msm import (BatchMulPreprocessing, batch_mul, ChunkedPippenger, HashMapPip
                   msm_u64, msm_unchecked, normalize_batch, sum_projective, base_cache_config, base_cache_clear,
                   base_cache_stats, ResidentBases, pin_bases, msm_plan, msm_plan_widths, MSM_WIDTH_TOP)
 from .domain import Radix2EvaluationDomain  # noqa: F401
-from .poly import poly_mul, poly_mul_host  # noqa: F401
+from .poly import DeviceVec, poly_mul, poly_mul_host  # noqa: F401

@@ -116,6 +116,12 @@ SYMBOLS = {
     "ark_hip_fft_sharded_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_void_p, C.c_int]),
     "ark_hip_fft_shard_local_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "ark_hip_fft_shard_cross_device": (C.c_int, [C.c_int, C.POINTER(Radix2DomainStruct), C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "ark_hip_fr_add_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_fr_sub_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_fr_neg_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_fr_scale_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_memset_device": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
     "ark_hip_fft_set_kernel": (C.c_int, [C.c_int]),
     "ark_hip_fft_set_timing": (C.c_int, [C.c_int]),
     "ark_hip_fft_last_timing": (C.c_int, [C.POINTER(C.c_double)]),

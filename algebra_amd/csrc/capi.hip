@@ -401,6 +401,16 @@ int fr_mul_dispatch(int field, const void* a, const void* b, void* r, size_t n, 
   ARK_FIELD_SWITCH(field, X);
 #undef X
 }
+int fr_scale_dispatch(int field, const void* a, const uint64_t* k4, void* r, size_t n, hipStream_t st) {
+#define X(NAME) fr_scale_##NAME(a, k4, r, n, st)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+int fr_op_dispatch(int field, int op, const void* a, const void* b, void* r, size_t n, hipStream_t st) {
+#define X(NAME) test_field_op_##NAME(op, a, b, r, n, st)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
 int fft_axis_dispatch(int field, FftWorkspace& ws, const void* src, void* dst, unsigned G, size_t cols, const uint64_t* root,
                       hipStream_t st) {
 #define X(NAME) fft_axis_##NAME(ws, src, dst, G, cols, root, st)
@@ -2283,6 +2293,51 @@ int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, co
   if (!d_data || !root) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
   if (int rc = fft_axis_dispatch(field, sc.c->fft, d_data, d_data, G, cols, root, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+
+// The rest of the pointwise algebra on device-resident vectors of Fr (Evaluations +=, -=, negation; a polynomial or an
+// evaluation vector times a field element -- poly/src/evaluations/univariate/mod.rs:104-180, polynomial/univariate/
+// dense.rs:343-371, :604-622): what a chain evaluate_over_domain -> pointwise -> interpolate needs besides the transforms
+// and ark_hip_fr_mul_device to stay on the device between ONE upload and ONE download.  Asynchronous on the context
+// stream; r may alias a or b.
+int ark_hip_fr_add_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n) {
+  if (n && (!d_a || !d_b || !d_r)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (int rc = fr_op_dispatch(field, 0, d_a, d_b, d_r, n, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+int ark_hip_fr_sub_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n) {
+  if (n && (!d_a || !d_b || !d_r)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (int rc = fr_op_dispatch(field, 1, d_a, d_b, d_r, n, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+int ark_hip_fr_neg_device(int field, const void* d_a, void* d_r, size_t n) {
+  if (n && (!d_a || !d_r)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (int rc = fr_op_dispatch(field, 4, d_a, nullptr, d_r, n, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+// r[i] = a[i] * k; k: one Montgomery element in HOST memory, read before the call returns
+int ark_hip_fr_scale_device(int field, const void* d_a, const uint64_t* k, void* d_r, size_t n) {
+  if (!k || (n && (!d_a || !d_r))) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (int rc = fr_scale_dispatch(field, d_a, k, d_r, n, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+// device-to-device copy / byte fill on the context stream (a device vector's clone() and its zero-extension), ordered with
+// the transforms and the pointwise kernels like every other *_device entry
+int ark_hip_memcpy_d2d(void* dst_dptr, const void* src_dptr, size_t bytes) {
+  if (bytes && (!dst_dptr || !src_dptr)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (bytes) ARK_HIP_TRY(hipMemcpyAsync(dst_dptr, src_dptr, bytes, hipMemcpyDeviceToDevice, sc.c->stream));
+  return mark_producer(sc.c);
+}
+int ark_hip_memset_device(void* dptr, int value, size_t bytes) {
+  if (bytes && !dptr) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (bytes) ARK_HIP_TRY(hipMemsetAsync(dptr, value, bytes, sc.c->stream));
   return mark_producer(sc.c);
 }
 

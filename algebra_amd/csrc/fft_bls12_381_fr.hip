@@ -10,6 +10,9 @@ int fft_run_BLS12_381_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* 
 int test_field_op_BLS12_381_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<Fp<BLS12_381_FR>, true>(op, a, b, r, n, s);
 }
+int fr_scale_BLS12_381_FR(const void* a, const uint64_t* k4, void* r, size_t n, hipStream_t s) {
+  return fr_scale_launch<Fp<BLS12_381_FR>>(a, k4, r, n, s);
+}
 int fft_axis_BLS12_381_FR(FftWorkspace& ws, const void* d_src, void* d_dst, unsigned G, size_t cols, const uint64_t* root4, hipStream_t s) {
   return fft_axis_run<BLS12_381_FR>(ws, d_src, d_dst, G, cols, root4, s);
 }

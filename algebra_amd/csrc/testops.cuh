@@ -62,6 +62,28 @@ int test_field_op_launch(int op, const void* a, const void* b, void* r, size_t n
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// r[i] = a[i] * k for a constant k passed by value (DensePolynomial * F, Evaluations scaled by a field element): the
+// constant travels in the kernel arguments, so a caller's stack value needs no device copy and no lifetime rule
+struct FrConst { u32 l[8]; };
+template <class F>
+__global__ void __launch_bounds__(256) fr_scale_kernel(const char* a, FrConst k, char* r, size_t n) {  // r may alias a
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F kk;
+#pragma unroll
+  for (int j = 0; j < F::N; j++) kk.l[j] = k.l[j];
+  F::mul(F::load(a + i * F::BYTES), kk).store(r + i * F::BYTES);
+}
+template <class F>
+int fr_scale_launch(const void* a, const uint64_t* k4, void* r, size_t n, hipStream_t s) {
+  static_assert(F::N == 8, "the scalar fields served are 256-bit");
+  if (n == 0) return 0;
+  FrConst k;
+  for (int j = 0; j < 4; j++) { k.l[2 * j] = (u32)k4[j]; k.l[2 * j + 1] = (u32)(k4[j] >> 32); }
+  hipLaunchKernelGGL((fr_scale_kernel<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const char*)a, k, (char*)r, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 // acc: XYZZ (kinds 2..6) or affine (kind 7); other: affine (2,3) or XYZZ (4); out: XYZZ, or Jacobian for kind 6
 template <class C>
 __global__ void __launch_bounds__(128) test_point_op_kernel(int kind, const char* __restrict__ acc_in,

@@ -58,3 +58,115 @@ def poly_mul(field, a, b):
     # which is how the reference's interpolate() result looks when a product vanishes at the top
     nz = np.nonzero(out.any(axis=1))[0]
     return out[: (nz[-1] + 1) if nz.size else 0]
+
+
+class DeviceVec:
+    """Fr vector owned by the library's allocator on the current GPU -- the Python mirror of `ark_hip::DeviceVec` (Rust:
+    rust/ark-hip/src/device.rs, C++: include/ark_hip.hpp).  numpy in (`from_host`), numpy out (`to_host`), everything in
+    between stays in HBM: `evaluate_over_domain` -> `+=`, `-=`, `*=`, `scale`, `negate` -> `interpolate`
+    (polynomial/univariate/mod.rs:305-360, evaluations/univariate/mod.rs:40-50, :104-180) with ONE upload per input and
+    ONE download.  Asynchronous on the library's stream; `to_host` waits."""
+
+    def __init__(self, field, length, _zero=True):
+        self.field = cv.field_id(field)
+        self.len = int(length)
+        self.cap = self.len
+        self.ptr = C.c_void_p(0)
+        if self.len:
+            check(lib().ark_hip_malloc(self.len * 32, C.byref(self.ptr)), "ark_hip_malloc")
+            if _zero:
+                check(lib().ark_hip_memset_device(self.ptr, 0, self.len * 32), "ark_hip_memset_device")
+
+    @classmethod
+    def from_host(cls, field, x):
+        a = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+        v = cls(field, a.shape[0], _zero=False)
+        check(lib().ark_hip_memcpy_h2d(v.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes), "ark_hip_memcpy_h2d")
+        return v
+
+    def to_host(self):
+        out = np.empty((self.len, 4), dtype=np.uint64)
+        check(lib().ark_hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes), "ark_hip_memcpy_d2h")
+        return out
+
+    def clone(self):
+        v = DeviceVec(self.field, self.len, _zero=False)
+        check(lib().ark_hip_memcpy_d2d(v.ptr, self.ptr, self.len * 32), "ark_hip_memcpy_d2d")
+        return v
+
+    def free(self):
+        if self.ptr and self.ptr.value:
+            check(lib().ark_hip_free(self.ptr), "ark_hip_free")
+            self.ptr = C.c_void_p(0)
+            self.len = self.cap = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def __len__(self):
+        return self.len
+
+    def resize_zeroed(self, new_len):
+        """Vec::resize(new_len, F::zero()) (also truncates)"""
+        L = lib()
+        if new_len > self.cap:
+            v = DeviceVec(self.field, new_len, _zero=False)
+            check(L.ark_hip_memcpy_d2d(v.ptr, self.ptr, self.len * 32), "ark_hip_memcpy_d2d")
+            old_ptr = self.ptr
+            self.ptr, self.cap = v.ptr, new_len
+            v.ptr = old_ptr   # freed with v
+            v.free()
+        old = self.len
+        self.len = new_len
+        if new_len > old:
+            check(L.ark_hip_memset_device(C.c_void_p(self.ptr.value + old * 32), 0, (new_len - old) * 32), "ark_hip_memset_device")
+
+    def _same(self, other):
+        if other.len != self.len or other.field != self.field:
+            raise ValueError("domains are unequal")   # the reference's assertion
+
+    def __iadd__(self, other):
+        self._same(other)
+        check(lib().ark_hip_fr_add_device(self.field, self.ptr, other.ptr, self.ptr, self.len), "ark_hip_fr_add_device")
+        return self
+
+    def __isub__(self, other):
+        self._same(other)
+        check(lib().ark_hip_fr_sub_device(self.field, self.ptr, other.ptr, self.ptr, self.len), "ark_hip_fr_sub_device")
+        return self
+
+    def __imul__(self, other):
+        self._same(other)
+        check(lib().ark_hip_fr_mul_device(self.field, self.ptr, other.ptr, self.ptr, self.len), "ark_hip_fr_mul_device")
+        return self
+
+    def scale(self, k):
+        k = np.ascontiguousarray(k, dtype=np.uint64).reshape(4)
+        check(lib().ark_hip_fr_scale_device(self.field, self.ptr, k.ctypes.data_as(C.c_void_p), self.ptr, self.len),
+              "ark_hip_fr_scale_device")
+        return self
+
+    def negate(self):
+        check(lib().ark_hip_fr_neg_device(self.field, self.ptr, self.ptr, self.len), "ark_hip_fr_neg_device")
+        return self
+
+    def evaluate_over_domain(self, domain):
+        """coefficients -> evaluations over `domain`, in place (zero-extended; at most size/4 coefficients take the
+        degree-aware path).  Returns self (now the evaluations)."""
+        have = self.len
+        if have > domain.size():
+            raise ValueError("more coefficients than the domain size")
+        self.resize_zeroed(domain.size())
+        check(lib().ark_hip_fft_in_place_degree_aware_device(self.field, C.byref(domain._s), self.ptr, have),
+              "ark_hip_fft_in_place_degree_aware_device")
+        return self
+
+    def interpolate(self, domain):
+        """evaluations over `domain` -> coefficients, in place (Evaluations::interpolate).  Returns self."""
+        if self.len != domain.size():
+            raise ValueError("domains are unequal")
+        check(lib().ark_hip_ifft_in_place_device(self.field, C.byref(domain._s), self.ptr), "ark_hip_ifft_in_place_device")
+        return self

@@ -6,10 +6,16 @@
 
 Metric (BASELINE.json): G1 scalar-muls/sec of a BLS12-381 G1 MSM, inputs resident in HBM.
   value   ONE MSM per step through the PLAIN entry -- ark_hip_msm_sw_device on raw bases, nothing precomputed: what
-          VariableBaseMSM::msm / msm_bigint compute (variable_base/mod.rs:59-85).  N = 1: 2^24 pairs (the configuration
-          the metric is quoted on).  N > 1: weak scaling, 2^24 pairs per GPU -- one 2^(24 + log2 N) MSM whose base-range
-          shard [r*2^24, (r+1)*2^24) lives on rank r; the 144-byte partials are all-gathered over RCCL and summed
-          (elliptic-curve addition, so not an RCCL reduction op).  No other collective exists on the path.
+          VariableBaseMSM::msm / msm_bigint compute (variable_base/mod.rs:59-85).
+          N = 1: 2^24 pairs (the configuration the metric is quoted on), `"scaling": "weak"` by the contract's convention
+          for a one-GPU line.
+          N > 1: BASELINE config 4 -- ONE 2^26 MSM split over the N ranks by base range (STRONG scaling: total work fixed,
+          2^26 / N pairs per GPU; shard [r*2^26/N, (r+1)*2^26/N) lives on rank r; the ranks' part sums are all-gathered
+          over RCCL and added on the device -- elliptic-curve addition, so not an RCCL reduction op; no other collective
+          exists on the path).  `"scaling": "strong"`; its one-GPU reference is the N = 1 line's
+          `config4_strong_2_26.value` (the same 2^26 job on one GPU), NOT that line's `value` (a 2^24 job).  Two more
+          legs ride along at N > 1, each labelled: `weak_2_24_per_gpu` (2^24 pairs on every GPU: one 2^(24+log2 N) job)
+          and `strong_2_24` (the 2^24 job itself split N ways: 2^24 / N pairs per GPU).
   extras  (never `value`)  `prepared`: the same job against a PREPARED base set (ark_hip_msm_bases_prepare: per-window
           multiples built once, outside the step, for a fixed SRS); `pipelined`: two asynchronous jobs in flight;
           `trait_surface`: the same job through ark_hip_msm_sw from HOST pointers -- what SWCurveConfig::msm and the
@@ -48,6 +54,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # quoted against a loop the kernel beats.
 MAD_U64_U32_PER_S = 34.96e12
 MAD_U64_U32_PER_S_TWO_WAVES = 26.6e12
+SIMPLE_VALU_PER_S = 55.04e12   # v_add_u32, the same file: the plain vector instruction's issue rate
 # Fr products: the carry-free 9 x 29-bit product back to back in a loop, best measured rate (eight waves per SIMD) and the
 # rate at two waves (profiles/r4_ubench_product_rate_29bit.txt, BLS12-381 Fr)
 FR_PRODUCTS_PER_S = {"carry-free": 177.2e9, "saturated": 135.7e9}
@@ -65,6 +72,33 @@ limbs4 = S.limbs4
 
 def gen_scalars(n, seed):
     return S.gen_scalars(n, seed, R_MOD)
+
+
+def fft_issue_bound(kf, nf, dev_ms):
+    """The vector-issue bound of the saturated pass kernel (VERDICT r4 next #1d): instructions per 4-point group of a
+    two-stage round counted in the shipped ISA (hipcc -S of fft_bls12_381_fr.hip: 512 v_mad_u64_u32 + 512 v_addc_co_u32 of
+    the four Comba products, 380 others -- additions / subtractions with their conditional corrections, LDS traffic, index
+    arithmetic), priced at the issue rates measured on this chip (profiles/r3_issue_rates.txt, eight waves per SIMD:
+    v_mad_u64_u32 34.96e12 lane-ops/s, v_add_u32 55.04e12)."""
+    P = (kf + 7) // 8
+    base, rem = kf // P, kf % P
+    kps = [base + (1 if i < rem else 0) for i in range(P)]
+    for i in range(P):
+        for j in range(P - 1, i, -1):
+            if kps[i] % 2 and kps[j] % 2 and kps[i] < 8 and kps[j] > 2:
+                kps[i] += 1
+                kps[j] -= 1
+                break
+    rounds2 = sum(kp // 2 for kp in kps)          # two-stage rounds: nf / 4 groups of four points each
+    rounds1 = sum(kp % 2 for kp in kps)           # single-stage rounds: nf / 2 butterflies, half a group's work each
+    groups = nf / 4.0 * (rounds2 + 0.5 * rounds1)
+    mads, others = 512.0, 512.0 + 380.0
+    t = groups * (mads / MAD_U64_U32_PER_S + others / SIMPLE_VALU_PER_S)
+    return {"what": "time the transform's vector instructions need at the chip's measured issue rates: %d two-stage rounds "
+                    "(+ %d single) x 2^%d 4-point groups x (512 v_mad_u64_u32 at 34.96e12 lane-ops/s + 892 plain vector "
+                    "instructions at 55.04e12)" % (rounds2, rounds1, kf - 2),
+            "bound_ms": t * 1e3, "achieved_ms": dev_ms, "frac": t * 1e3 / dev_ms, "pass_plan": kps,
+            "source": "profiles/r3_issue_rates.txt; instruction counts: the kernel's ISA, see DESIGN.md section 5"}
 
 
 def usable_cores():
@@ -91,7 +125,7 @@ def pmc_traffic(kernel, log_n):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json,
     produced by tools/pmc_traffic.py on this same command; FETCH_SIZE / WRITE_SIZE collected in separate passes,
     corrected as MI355X_MICROARCH.md prescribes).  None when no matching measurement is committed."""
-    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -109,8 +143,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=None,
-                    help="log2 of the pairs PER GPU of the headline MSM (default 24: BASELINE config 2; the job is one "
-                         "MSM of 2^(log-n) * N pairs)")
+                    help="N = 1: log2 of the pairs of the headline MSM (default 24: BASELINE config 2).  N > 1: log2 of the "
+                         "pairs PER GPU of the weak-scaling leg, and of the job the strong_2_24 leg splits")
+    ap.add_argument("--log-total", type=int, default=None,
+                    help="N > 1: log2 of the pairs of the ONE job split over all ranks -- the headline value (default 26: "
+                         "BASELINE config 4)")
     ap.add_argument("--fft-log-n", type=int, default=22)
     ap.add_argument("--fft-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,8 +230,15 @@ def main():
         except Exception:  # noqa: BLE001
             nv = "unknown"
         exchange += "; library communicator rank %d of %d; RCCL %s" % (cr.value, cw.value, nv)
-    log_local = args.log_n if args.log_n is not None else LOG_PER_GPU
-    n = 1 << log_local                      # pairs on this GPU
+    log_weak = args.log_n if args.log_n is not None else LOG_PER_GPU
+    if world == 1:
+        n = 1 << log_weak                   # pairs on this GPU
+        headline_scaling = "weak"
+    else:
+        log_total = args.log_total if args.log_total is not None else LOG_CONFIG4
+        n = (1 << log_total) // world       # BASELINE config 4: ONE 2^26 job, strong scaling
+        headline_scaling = "strong"
+    log_local = int(np.log2(n)) if n & (n - 1) == 0 else float(np.log2(n))
     n_total = n * world                     # pairs of the one MSM
     ab = cv.affine_bytes(cid)
 
@@ -258,6 +302,37 @@ def main():
     want = expected_affine(scalars_h, first)
     exact = bool(np.array_equal(A.into_affine(cid, result), want)) if rank == 0 else None
     extras = not args.no_extras
+
+    # ---- N > 1: the two other scalings of the same path, each labelled (never `value`) ---------------------------
+    side_legs = {}
+    if world > 1 and extras:
+        for key, n_leg, scal, what in (
+                ("weak_2_%d_per_gpu" % log_weak, 1 << log_weak, "weak",
+                 "2^%d pairs on every GPU: one 2^%d * %d job" % (log_weak, log_weak, world)),
+                ("strong_2_%d" % log_weak, (1 << log_weak) // world, "strong",
+                 "the 2^%d job (BASELINE config 2) split %d ways; its one-GPU reference is the N = 1 line's `value`"
+                 % (log_weak, world))):
+            try:
+                if n_leg == n:
+                    lb, lsh, ls = bases, scalars_h, scalars
+                else:
+                    lb, lsh, ls = make_inputs(n_leg, rank * n_leg, 0x1E6 + rank)
+                st = min(args.steps, 5)
+                res_l, el_l, ph_l = run_timed(lambda sc: A.msm_bigint(cid, lb, sc), ls, 1, st,
+                                              sharded=lambda sc: D.msm_bigint_sharded(cid, lb, sc))
+                kl = expected_affine(lsh, rank * n_leg)
+                if rank == 0:
+                    side_legs[key] = {"what": what, "scaling": scal, "pairs_per_gpu": n_leg,
+                                      "value": n_leg * world * st / el_l, "unit": "scalar-muls/s",
+                                      "ms_per_step": el_l * 1e3 / st, "steps": st,
+                                      "window_bits": int(ph_l[6]), "windows": int(ph_l[7]), "accumulate_ms": ph_l[3],
+                                      "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_l), kl))}
+                if n_leg != n:
+                    del lb, ls
+                    torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001 -- a side measurement must never cost the headline line
+                if rank == 0:
+                    side_legs[key] = {"error": repr(e)[:200]}
 
     # ---- extension: the same job against a PREPARED base set (fixed SRS; the table is built outside the step) ----
     prepared = None
@@ -352,7 +427,7 @@ def main():
 
     # ---- BASELINE config 4: ONE 2^26 MSM split over the ranks (strong scaling; N = 1: the whole job on one GPU) ----
     config4 = None
-    if extras and (world > 1 or log_local == LOG_PER_GPU):
+    if extras and world == 1 and log_local == LOG_PER_GPU:
         try:
             nb_ = (1 << LOG_CONFIG4) // world
             if nb_ == n:
@@ -508,14 +583,24 @@ def main():
         ifft_ms = timed_dev(inv, sref)
         cfft_ms = timed_dev(fwd, cref)
         cifft_ms = timed_dev(inv, cref)
-        # per-pass device times of one transform (HIP events on the library stream)
+        # per-pass device times (HIP events on the library stream), averaged over as many transforms as `ms_per_step`: the
+        # chip's clocks drift by +-8 % over milliseconds under this kernel (profiles/r5_fft_schedule_ab.txt), so ONE
+        # event-timed transform and the mean of twenty are different statistics -- round 4's "76 us per call that is not
+        # kernel time" was that, not launch overhead (the trace shows 0 us between passes, 6 us between transforms)
         check(L.ark_hip_fft_set_timing(1), "fft timing")
-        check(fwd(dom.field, sref, y.data_ptr()), "fft")
         ft = (C.c_double * 10)()
-        L.ark_hip_fft_last_timing(ft)
+        dev_all, pass_sum = [], None
+        for _ in range(max(1, args.fft_steps)):
+            check(fwd(dom.field, sref, y.data_ptr()), "fft")
+            L.ark_hip_fft_last_timing(ft)
+            dev_all.append(ft[0])
+            npass = int(ft[1])
+            cur = np.array([ft[2 + i] for i in range(npass)])
+            pass_sum = cur if pass_sum is None else pass_sum + cur
         check(L.ark_hip_fft_set_timing(0), "fft timing")
-        dev_ms = ft[0]
-        npass = int(ft[1])
+        dev_ms = float(np.mean(dev_all))
+        dev_min = float(np.min(dev_all))
+        pass_ms = [float(v) for v in pass_sum / len(dev_all)]
         # the same transform as a batch of 8 polynomials (three in flight: ark_hip_fft_batch_in_place_device)
         ys = [x.clone() for _ in range(8)]
         torch.cuda.synchronize()       # (as above: torch's stream is not the library's)
@@ -587,7 +672,7 @@ def main():
         fft = {
             "metric": "BLS12-381 Fr radix-2 FFT elements/sec (2^%d, in place, device resident)" % kf,
             "value": nf / (fft_ms * 1e-3), "unit": "elements/s", "ms_per_step": fft_ms,
-            "device_ms": dev_ms, "passes": [ft[2 + i] for i in range(npass)],
+            "device_ms": dev_ms, "device_ms_fastest_of_%d" % len(dev_all): dev_min, "passes": pass_ms,
             "shapes_ms": {"fft": fft_ms, "ifft": ifft_ms, "coset_fft": cfft_ms, "coset_ifft": cifft_ms},
             "ifft_fft_roundtrip_exact": roundtrip_ok,
             "arithmetic": "exact integers on v_mad_u64_u32: %s" % ("carry-free 9 x 29-bit limbs" if lazy_fft else "saturated 32-bit limbs"),
@@ -613,7 +698,8 @@ def main():
                                            "frac": products / (dev_ms * 1e-3)
                                            / FR_PRODUCTS_PER_S_TWO_WAVES["carry-free" if lazy_fft else "saturated"]},
                              "peak_source": "profiles/r4_ubench_product_rate_29bit.txt (BLS12-381 Fr): saturated product 135.7 G/s "
-                                            "at eight waves per SIMD / 121.5 at two; carry-free 177.2 / 154.5"}},
+                                            "at eight waves per SIMD / 121.5 at two; carry-free 177.2 / 154.5"},
+                         "valu_issue": None if lazy_fft or kf <= 10 else fft_issue_bound(kf, nf, dev_ms)},
         }
 
     # ---- sharded FFT leg (N > 1): 2^fft_log_n coefficients per GPU, all-to-all exchanges over RCCL ----------
@@ -691,7 +777,8 @@ def main():
         mads_per_s = madds * mads_per_add / (acc_ms * 1e-3)
         traffic, traffic_src = pmc_traffic(ACC_KERNEL, log_local)
         out = {
-            "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (int(np.log2(n_total)), "" if world == 1 else " over %d GPUs" % world),
+            "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (int(round(np.log2(n_total))), "" if world == 1 else
+                                                             ", ONE job split over %d GPUs" % world),
             "value": n_total * args.steps / elapsed,
             "unit": "scalar-muls/s",
             "n_gpus": world,
@@ -699,12 +786,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": headline_scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "BLS12-381 G1 MSM, one job of 2^%d random bases/scalars, device resident, plain entry "
-                                   "(raw bases, nothing precomputed: VariableBaseMSM::msm_bigint)" % int(np.log2(n_total)),
+                                   "(raw bases, nothing precomputed: VariableBaseMSM::msm_bigint)%s"
+                                   % (int(round(np.log2(n_total))), "" if world == 1 else
+                                      " -- BASELINE config 4, split by base range over %d GPUs (strong scaling: the total is "
+                                      "fixed; one-GPU reference = `config4_strong_2_26.value` of the --gpus 1 line)" % world),
                        "arithmetic": "exact integers on v_mad_u64_u32: Montgomery Fp384, bucket accumulation on %s, "
                                      "everything else on saturated 32-bit limbs" %
                                      ("carry-free 28-bit limbs" if LAZY else "saturated 32-bit limbs"),
@@ -737,7 +827,8 @@ def main():
             "trait_surface": trait,
             "prepared": prepared,
             "pipelined": pipelined,
-            "config4_strong_2_26": config4,
+            "config4_strong_2_26": config4 if world == 1 else "this line's `value` (N > 1: the headline IS config 4)",
+            "other_scalings": side_legs if world > 1 else None,
             "other_configs": others,
             "fft": fft,
             "fft_sharded": fft_sharded,

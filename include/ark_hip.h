@@ -70,6 +70,9 @@ int ark_hip_malloc(size_t bytes, void** out_dptr);
 int ark_hip_free(void* dptr);
 int ark_hip_memcpy_h2d(void* dst_dptr, const void* src_host, size_t bytes);
 int ark_hip_memcpy_d2h(void* dst_host, const void* src_dptr, size_t bytes);
+/* device-to-device copy and byte fill, asynchronous on the context stream (ordered with every *_device entry) */
+int ark_hip_memcpy_d2d(void* dst_dptr, const void* src_dptr, size_t bytes);
+int ark_hip_memset_device(void* dptr, int value, size_t bytes);
 /* Page-locked host memory: scalar vectors produced into it upload at full PCIe rate and truly asynchronously
  * (ark_hip_msm_prepared_async). */
 int ark_hip_host_alloc(size_t bytes, void** out_ptr);
@@ -299,6 +302,15 @@ int ark_hip_fft_batch_in_place_device(int field, const ark_hip_radix2_domain* do
  * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
  * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */
 int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
+/* The rest of the pointwise algebra of device-resident Fr vectors (round 5): Evaluations += / -= / negation
+ * (poly/src/evaluations/univariate/mod.rs:104-180) and a vector times ONE field element (dense.rs:604-622; k is a host
+ * pointer to one Montgomery element, read before the call returns).  With the transforms above, a chain
+ * evaluate_over_domain -> pointwise -> interpolate (polynomial/univariate/mod.rs:305-360, evaluations/univariate/
+ * mod.rs:40-50) runs between ONE upload and ONE download.  Asynchronous on the context stream; r may alias a or b. */
+int ark_hip_fr_add_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
+int ark_hip_fr_sub_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
+int ark_hip_fr_neg_device(int field, const void* d_a, void* d_r, size_t n);
+int ark_hip_fr_scale_device(int field, const void* d_a, const uint64_t* k, void* d_r, size_t n);
 /* `&DensePolynomial * &DensePolynomial` (poly/src/polynomial/univariate/dense.rs:641-656: evaluate both factors over the
  * radix-2 domain of size >= na + nb - 1, multiply pointwise, interpolate) from HOST coefficient vectors: ONE upload of a and
  * b, both forward transforms in flight together (short factors on the degree-aware path), the pointwise product and the

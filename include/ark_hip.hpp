@@ -16,6 +16,10 @@
 //        new_(num_coeffs) -> optional (None when log2(size) > TWO_ADICITY)         (poly/src/domain/radix2/mod.rs:55-83)
 //        get_coset, size, log_size_of_group, size_inv, group_gen, group_gen_inv, coset_offset, coset_offset_inv,
 //        coset_offset_pow_size, fft, fft_in_place, ifft, ifft_in_place             (radix2/mod.rs:85-153, domain/mod.rs:92-112)
+//   ark_hip::DeviceVec<F>, ark_hip::DeviceEvaluations<F>, ark_hip::evaluate_over_domain   (round 5)
+//        coefficient / evaluation vectors that stay in HBM: evaluate_over_domain -> pointwise +, -, * -> interpolate
+//        (polynomial/univariate/mod.rs:305-360, evaluations/univariate/mod.rs:40-50, :104-180) with ONE upload and ONE
+//        download instead of two PCIe crossings per transform
 //
 // Element types are plain limb arrays in the reference's in-memory layout (Montgomery, little-endian u64 limbs).
 #pragma once
@@ -428,5 +432,122 @@ class Radix2EvaluationDomain {
     v.resize(size());
   }
 };
+
+// ---- device-resident vectors of Fr: DensePolynomial coefficients / Evaluations that stay in HBM -----------------------
+// The reference's callers chain transforms: DensePolynomial::evaluate_over_domain (polynomial/univariate/mod.rs:305-360:
+// zero-extend + fft_in_place -> Evaluations), the pointwise +, -, * of Evaluations over one domain
+// (evaluations/univariate/mod.rs:104-180) and Evaluations::interpolate (mod.rs:40-50: ifft_in_place -> coefficients).
+// Through the host-pointer entries every link of such a chain crosses PCIe twice (2 x 128 MiB at 2^22: 5.3 ms around a
+// 0.5 ms transform).  DeviceVec owns ark_hip_malloc memory; the chain below costs ONE upload and ONE download.
+// All operations are asynchronous on the library's stream of the current device and ordered with each other; to_vec()
+// waits.  A DeviceVec belongs to the device that was current when it was made.
+template <int FIELD_ID>
+class DeviceVec {
+ public:
+  DeviceVec() = default;
+  explicit DeviceVec(size_t len) { alloc(len); zero_from(0); }                       // vec![F::zero(); len]
+  static DeviceVec from_slice(const Fr* x, size_t len) {
+    DeviceVec v;
+    v.alloc(len);
+    check(ark_hip_memcpy_h2d(v.p_, x, len * 32), "ark_hip_memcpy_h2d");
+    return v;
+  }
+  static DeviceVec from_vec(const std::vector<Fr>& x) { return from_slice(x.data(), x.size()); }
+  DeviceVec(DeviceVec&& o) noexcept : p_(o.p_), len_(o.len_), cap_(o.cap_), dev_(o.dev_) { o.p_ = nullptr; o.len_ = o.cap_ = 0; }
+  DeviceVec& operator=(DeviceVec&& o) noexcept {
+    if (this != &o) { release(); p_ = o.p_; len_ = o.len_; cap_ = o.cap_; dev_ = o.dev_; o.p_ = nullptr; o.len_ = o.cap_ = 0; }
+    return *this;
+  }
+  DeviceVec(const DeviceVec&) = delete;
+  DeviceVec& operator=(const DeviceVec&) = delete;
+  ~DeviceVec() { release(); }
+  DeviceVec clone() const {
+    DeviceVec v;
+    v.alloc(len_);
+    check(ark_hip_memcpy_d2d(v.p_, p_, len_ * 32), "ark_hip_memcpy_d2d");
+    return v;
+  }
+  std::vector<Fr> to_vec() const {
+    std::vector<Fr> out(len_);
+    check(ark_hip_memcpy_d2h(out.data(), p_, len_ * 32), "ark_hip_memcpy_d2h");
+    return out;
+  }
+  size_t len() const { return len_; }
+  bool is_empty() const { return len_ == 0; }
+  void* device_ptr() { return p_; }
+  const void* device_ptr() const { return p_; }
+  // Vec::resize(new_len, F::zero()) / Vec::truncate
+  void resize_zeroed(size_t new_len) {
+    if (new_len > cap_) {
+      DeviceVec v;
+      v.alloc(new_len);
+      check(ark_hip_memcpy_d2d(v.p_, p_, len_ * 32), "ark_hip_memcpy_d2d");
+      const size_t keep = len_;
+      *this = std::move(v);
+      len_ = keep;
+    }
+    const size_t old = len_;
+    len_ = new_len;
+    if (new_len > old) zero_from(old);
+  }
+  // pointwise: self = self (op) other, element by element (lengths must agree, as Evaluations over one domain do)
+  DeviceVec& operator+=(const DeviceVec& o) { same(o); check(ark_hip_fr_add_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_add_device"); return *this; }
+  DeviceVec& operator-=(const DeviceVec& o) { same(o); check(ark_hip_fr_sub_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_sub_device"); return *this; }
+  DeviceVec& operator*=(const DeviceVec& o) { same(o); check(ark_hip_fr_mul_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_mul_device"); return *this; }
+  DeviceVec& operator*=(const Fr& k) { check(ark_hip_fr_scale_device(FIELD_ID, p_, k.limbs.data(), p_, len_), "ark_hip_fr_scale_device"); return *this; }
+  void negate() { check(ark_hip_fr_neg_device(FIELD_ID, p_, p_, len_), "ark_hip_fr_neg_device"); }
+
+ private:
+  void* p_ = nullptr;
+  size_t len_ = 0, cap_ = 0;
+  int dev_ = -1;
+  void alloc(size_t len) {
+    dev_ = ark_hip_get_device();
+    len_ = cap_ = len;
+    if (len) check(ark_hip_malloc(len * 32, &p_), "ark_hip_malloc");
+  }
+  void zero_from(size_t from) {
+    if (len_ > from) check(ark_hip_memset_device((char*)p_ + from * 32, 0, (len_ - from) * 32), "ark_hip_memset_device");
+  }
+  void same(const DeviceVec& o) const {
+    if (o.len_ != len_) throw Error(ARK_HIP_ERR_ARG, "domains are unequal");   // the reference's assert_eq!(self.domain, other.domain)
+  }
+  void release() {
+    if (!p_) return;
+    const int cur = ark_hip_get_device();
+    if (dev_ >= 0 && cur != dev_) (void)ark_hip_set_device(dev_);   // freed on the device that owns it
+    (void)ark_hip_free(p_);
+    if (dev_ >= 0 && cur != dev_ && cur >= 0) (void)ark_hip_set_device(cur);
+    p_ = nullptr;
+  }
+};
+
+// Evaluations<F, Radix2EvaluationDomain<F>> resident on the device (evaluations/univariate/mod.rs:18-29)
+template <int FIELD_ID>
+struct DeviceEvaluations {
+  DeviceVec<FIELD_ID> evals;
+  Radix2EvaluationDomain<FIELD_ID> domain;
+  // Evaluations::interpolate (mod.rs:47-50): the coefficients, still on the device (size() of them; the reference's
+  // from_coefficients_vec drops leading zeros on the host -- do that after to_vec() if a DensePolynomial is wanted)
+  DeviceVec<FIELD_ID> interpolate() && {
+    check(ark_hip_ifft_in_place_device(FIELD_ID, &domain.raw(), evals.device_ptr()), "ark_hip_ifft_in_place_device");
+    return std::move(evals);
+  }
+  DeviceEvaluations& operator+=(const DeviceEvaluations& o) { evals += o.evals; return *this; }
+  DeviceEvaluations& operator-=(const DeviceEvaluations& o) { evals -= o.evals; return *this; }
+  DeviceEvaluations& operator*=(const DeviceEvaluations& o) { evals *= o.evals; return *this; }
+};
+// DensePolynomial::evaluate_over_domain (polynomial/univariate/mod.rs:305-360) for coefficients already on the device:
+// zero-extension and transform in place; at most size/4 coefficients take the degree-aware path (radix2/mod.rs:141).
+// More coefficients than the domain holds is the reference's folding case (mod.rs:330-352): not served here.
+template <int FIELD_ID>
+DeviceEvaluations<FIELD_ID> evaluate_over_domain(DeviceVec<FIELD_ID>&& coeffs, const Radix2EvaluationDomain<FIELD_ID>& domain) {
+  const size_t have = coeffs.len();
+  if (have > domain.size()) throw Error(ARK_HIP_ERR_ARG, "more coefficients than the domain size");
+  coeffs.resize_zeroed(domain.size());
+  check(ark_hip_fft_in_place_degree_aware_device(FIELD_ID, &domain.raw(), coeffs.device_ptr(), have),
+        "ark_hip_fft_in_place_degree_aware_device");
+  return DeviceEvaluations<FIELD_ID>{std::move(coeffs), domain};
+}
 
 }  // namespace ark_hip

@@ -61,6 +61,8 @@ extern "C" {
     pub fn ark_hip_free(dptr: *mut c_void) -> c_int;
     pub fn ark_hip_memcpy_h2d(dst_dptr: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
     pub fn ark_hip_memcpy_d2h(dst_host: *mut c_void, src_dptr: *const c_void, bytes: usize) -> c_int;
+    pub fn ark_hip_memcpy_d2d(dst_dptr: *mut c_void, src_dptr: *const c_void, bytes: usize) -> c_int;
+    pub fn ark_hip_memset_device(dptr: *mut c_void, value: c_int, bytes: usize) -> c_int;
     pub fn ark_hip_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
     pub fn ark_hip_host_free(ptr: *mut c_void) -> c_int;
     pub fn ark_hip_msm_sw(curve: c_int, bases: *const u64, scalars: *const u64, n: usize,
@@ -124,6 +126,13 @@ extern "C" {
     pub fn ark_hip_fft_batch_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *const *mut c_void,
                                              count: usize, inverse: c_int) -> c_int;
     pub fn ark_hip_fr_mul_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    pub fn ark_hip_fr_add_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    pub fn ark_hip_fr_sub_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    pub fn ark_hip_fr_neg_device(field: c_int, d_a: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    /// `r[i] = a[i] * k`, `k`: one Montgomery element in host memory (read before the call returns).
+    pub fn ark_hip_fr_scale_device(field: c_int, d_a: *const c_void, k: *const u64, d_r: *mut c_void, n: usize) -> c_int;
+    pub fn ark_hip_fft_in_place_degree_aware_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void,
+                                                    num_coeffs: usize) -> c_int;
     /// `&DensePolynomial * &DensePolynomial` from host coefficient vectors: one upload, three transforms and the pointwise
     /// product on the device, one download; `out_len` = coefficients with leading zeros dropped.
     pub fn ark_hip_poly_mul(field: c_int, a: *const u64, na: usize, b: *const u64, nb: usize, out: *mut u64,
@@ -177,7 +186,7 @@ pub fn fr_field_id<F: Field>() -> Option<c_int> {
 
 /// The Montgomery limbs of a 4-limb prime-field element.  `Fp` is `(BigInt<4>, PhantomData)`
 /// (ff/src/fields/models/fp/mod.rs:109-115): not `#[repr(C)]`, so the size is checked by every caller.
-fn limbs<F>(x: &F) -> [u64; 4] {
+pub fn limbs<F>(x: &F) -> [u64; 4] {
     debug_assert_eq!(core::mem::size_of::<F>(), 32);
     unsafe { *(x as *const F as *const [u64; 4]) }
 }

@@ -10,15 +10,21 @@
 //! * **unmodified arkworks**: [`hip_sw_config!`] declares a wrapper `SWCurveConfig` (every item of the trait
 //!   delegated, `msm` on the GPU) and [`domain::HipRadix2EvaluationDomain`] wraps the evaluation domain.
 //!
+//! * **chains of transforms**: [`device::DeviceVec`] / [`device::DeviceEvaluations`] keep coefficient and evaluation
+//!   vectors in HBM -- `evaluate_over_domain` -> pointwise `+=`, `-=`, `*=` -> `interpolate` with one upload per input
+//!   and one download, instead of two PCIe crossings per transform through the `EvaluationDomain` hook.
+//!
 //! Beyond the reference's surface: [`msm::PreparedBases`] (a fixed SRS resident on the GPU with its per-window
 //! multiples), [`msm::MsmJob`] (asynchronous MSMs), [`msm::msm_multi`] (one MSM over all GPUs of the node).
 //!
 //! SOURCE ONLY: the image this repository is built in has no Rust toolchain; the identical C ABI is exercised by
 //! tests/ through ctypes and through the compiled C++ mirror (include/ark_hip.hpp).
+pub mod device;
 pub mod domain;
 pub mod msm;
 pub use ark_hip_sys as sys;
 pub use ark_hip_sys::{BLS12_377_G1, BLS12_377_G2, BLS12_381_G1, BLS12_381_G2, BN254_G1};
+pub use device::{DeviceError, DeviceEvaluations, DeviceVec};
 pub use msm::{sw_msm, sw_msm_bigint};
 #[cfg(feature = "ec-hook")]
 pub use msm::{sw_batch_mul, sw_msm_small, sw_normalize_batch};

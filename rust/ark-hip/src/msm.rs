@@ -11,7 +11,7 @@ use ark_hip_sys as sys;
 use ark_std::vec::Vec;
 use core::ffi::{c_int, c_void};
 use core::marker::PhantomData;
-use core::mem::{size_of, MaybeUninit};
+use core::mem::{offset_of, size_of, MaybeUninit};
 
 type BigIntOf<P> = <<P as ark_ec::CurveConfig>::ScalarField as PrimeField>::BigInt;
 
@@ -28,9 +28,22 @@ pub const fn fe_words(curve: c_int) -> usize {
 /// `Affine { x, y, infinity: () }` and `Projective { x, y, z }` are contiguous in declaration order, which is what the
 /// C ABI assumes.  A curve whose `ZeroFlag` is `bool` (an extra byte in `Affine`) or any other surprise fails the check:
 /// the call then takes the CPU path and says so once -- never silently.
+///
+/// Sizes alone would let a reordering of equally sized members through (rustc is free to reorder the fields of a
+/// `repr(Rust)` struct), so the OFFSETS of the public coordinates are checked as well (SURVEY 8b "Memory layout"):
+/// `x` at 0, `y` one field element in, `z` two (affine.rs:30-37, group.rs:34-41; `core::mem::offset_of!`, Rust 1.77).
+/// `Affine::infinity` is `pub(super)`: it cannot be named here, and with `x`, `y` pinned and the total size equal to
+/// two field elements it has no bytes left to occupy (`ZeroFlag = ()`).
 fn layout_ok<P: SWCurveConfig, S>(curve: c_int) -> bool {
-    let ok = size_of::<Affine<P>>() == 2 * fe_words(curve) * 8
-        && size_of::<Projective<P>>() == 3 * fe_words(curve) * 8
+    let fe = fe_words(curve) * 8;
+    let ok = size_of::<Affine<P>>() == 2 * fe
+        && size_of::<Projective<P>>() == 3 * fe
+        && size_of::<P::BaseField>() == fe
+        && offset_of!(Affine<P>, x) == 0
+        && offset_of!(Affine<P>, y) == fe
+        && offset_of!(Projective<P>, x) == 0
+        && offset_of!(Projective<P>, y) == fe
+        && offset_of!(Projective<P>, z) == 2 * fe
         && size_of::<S>() == 32;
     if !ok {
         #[cfg(feature = "std")]
@@ -158,16 +171,19 @@ pub fn sw_msm_chunks<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalar
 /// Sub-slices (`&srs[..n]`, the steps of `msm_chunks`) hit the resident copy too.
 pub struct ResidentBases<'a, P: SWCurveConfig> {
     curve: c_int,
+    device: c_int,
     bases: &'a [Affine<P>],
 }
 impl<'a, P: SWCurveConfig> ResidentBases<'a, P> {
     /// `None` if the layout check fails, no device is present or the copy does not fit (callers then simply run unpinned).
+    /// The pin lives in the context of the device that is current NOW; the guard remembers it and unpins there.
     pub fn pin(curve: c_int, bases: &'a [Affine<P>]) -> Option<Self> {
         if bases.is_empty() || !layout_ok::<P, P::ScalarField>(curve) {
             return None;
         }
+        let device = unsafe { sys::ark_hip_get_device() };
         let rc = unsafe { sys::ark_hip_msm_bases_pin(curve, bases.as_ptr() as *const u64, bases.len()) };
-        (rc == 0).then_some(Self { curve, bases })
+        (rc == 0).then_some(Self { curve, device, bases })
     }
     pub fn bases(&self) -> &'a [Affine<P>] {
         self.bases
@@ -175,7 +191,19 @@ impl<'a, P: SWCurveConfig> ResidentBases<'a, P> {
 }
 impl<'a, P: SWCurveConfig> Drop for ResidentBases<'a, P> {
     fn drop(&mut self) {
-        unsafe { sys::ark_hip_msm_bases_unpin(self.curve, self.bases.as_ptr() as *const u64, self.bases.len()) };
+        // unpin on the device that holds the pin (another device may be current by now: its context does not know the
+        // range, the unpin would fail and the stale range would stay registered -- ADVICE r4), then restore
+        unsafe {
+            let cur = sys::ark_hip_get_device();
+            if self.device >= 0 && cur != self.device {
+                sys::ark_hip_set_device(self.device);
+            }
+            let rc = sys::ark_hip_msm_bases_unpin(self.curve, self.bases.as_ptr() as *const u64, self.bases.len());
+            debug_assert_eq!(rc, 0, "ark-hip: unpin failed; the pinned range may still be registered");
+            if self.device >= 0 && cur != self.device && cur >= 0 {
+                sys::ark_hip_set_device(cur);
+            }
+        }
     }
 }
 

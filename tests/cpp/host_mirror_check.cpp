@@ -126,6 +126,74 @@ void check_fft(const char* name, unsigned log_n) {
   std::printf("%s fft 2^%u checked\n", name, log_n);
 }
 
+// evaluate_over_domain -> pointwise -> interpolate on DEVICE-RESIDENT vectors: one upload per factor,
+// one download, against the oracle's transforms and host field arithmetic
+template <int FIELD>
+void check_device_chain(const char* name, unsigned log_n) {
+  using D = Radix2EvaluationDomain<FIELD>;
+  using V = DeviceVec<FIELD>;
+  const size_t n = (size_t)1 << log_n;
+  auto dom = D::new_(n);
+  EXPECT(dom && dom->size() == n, "domain");
+  const size_t la = n / 2 - 5, lb = n / 8 + 3;   // b takes the degree-aware path, a * b fits the domain
+  std::vector<Fr> a(la), b(lb);
+  ark_oracle_gen_scalars(FIELD, 31, la, 1, reinterpret_cast<uint64_t*>(a.data()));
+  ark_oracle_gen_scalars(FIELD, 32, lb, 1, reinterpret_cast<uint64_t*>(b.data()));
+  Fr k;
+  ark_oracle_gen_scalars(FIELD, 33, 1, 1, k.limbs.data());
+  // oracle: ea = FFT(a), eb = FFT(b); e = ((ea * eb + eb) * k - ea); c = IFFT(e); and -c
+  std::vector<Fr> ea(a), eb(b);
+  ea.resize(n);
+  eb.resize(n);
+  ark_oracle_fft(FIELD, reinterpret_cast<uint64_t*>(ea.data()), log_n, nullptr, 0, 4);
+  ark_oracle_fft(FIELD, reinterpret_cast<uint64_t*>(eb.data()), log_n, nullptr, 0, 4);
+  std::vector<Fr> e(n), kk(n, k);
+  auto u = [](std::vector<Fr>& v) { return reinterpret_cast<uint64_t*>(v.data()); };
+  ark_oracle_field_op(FIELD, 2, u(ea), u(eb), u(e), n);
+  ark_oracle_field_op(FIELD, 0, u(e), u(eb), u(e), n);
+  ark_oracle_field_op(FIELD, 2, u(e), u(kk), u(e), n);
+  ark_oracle_field_op(FIELD, 1, u(e), u(ea), u(e), n);
+  std::vector<Fr> c(e);
+  ark_oracle_fft(FIELD, u(c), log_n, nullptr, 1, 4);
+  // device: two uploads, everything else resident, one download
+  auto da = evaluate_over_domain(V::from_vec(a), *dom);
+  auto db = evaluate_over_domain(V::from_vec(b), *dom);
+  EXPECT(da.evals.len() == n && db.evals.len() == n, "evaluations have the domain's size");
+  auto keep_a = da.evals.clone();
+  da *= db;
+  da += db;
+  da.evals *= k;
+  DeviceEvaluations<FIELD> ea_dev{std::move(keep_a), *dom};
+  da -= ea_dev;
+  auto e_dev = da.evals.clone();
+  auto coeffs = std::move(da).interpolate();
+  auto got_e = e_dev.to_vec();
+  EXPECT(std::memcmp(got_e.data(), e.data(), n * 32) == 0, "pointwise chain on the device == oracle");
+  auto got_c = coeffs.to_vec();
+  EXPECT(got_c.size() == n && std::memcmp(got_c.data(), c.data(), n * 32) == 0, "interpolate on the device == oracle");
+  coeffs.negate();
+  std::vector<Fr> negc(n), zero(n);
+  ark_oracle_field_op(FIELD, 1, u(zero), u(c), u(negc), n);
+  auto got_n = coeffs.to_vec();
+  EXPECT(std::memcmp(got_n.data(), negc.data(), n * 32) == 0, "negate");
+  // Vec semantics: resize with zeros keeps the prefix, truncation keeps it too; a fresh vector is zero
+  coeffs.resize_zeroed(n + 7);
+  auto grown = coeffs.to_vec();
+  EXPECT(grown.size() == n + 7 && std::memcmp(grown.data(), negc.data(), n * 32) == 0 && grown[n + 6].is_zero() && grown[n].is_zero(),
+         "resize_zeroed grows with zeros");
+  coeffs.resize_zeroed(5);
+  EXPECT(coeffs.to_vec().size() == 5, "resize_zeroed truncates");
+  V z(9);
+  auto zv = z.to_vec();
+  bool allz = true;
+  for (auto& x : zv) allz = allz && x.is_zero();
+  EXPECT(allz, "DeviceVec(len) is zero");
+  bool threw = false;
+  try { V w(3); w += z; } catch (const Error&) { threw = true; }
+  EXPECT(threw, "unequal lengths are refused");
+  std::printf("%s device-resident chain 2^%u checked\n", name, log_n);
+}
+
 // the library's RCCL communicator from a compiled host: a world of one on the test box's single GPU (dlopen of librccl,
 // ncclCommInitRank, the sharded MSM and FFT entries through it)
 void check_communicator() {
@@ -177,6 +245,9 @@ int main() {
   check_fft<ARK_HIP_BLS12_381_FR>("BLS12_381_FR", 12);
   check_communicator();
   check_fft<ARK_HIP_BN254_FR>("BN254_FR", 9);
+  check_device_chain<ARK_HIP_BLS12_381_FR>("BLS12_381_FR", 20);
+  check_device_chain<ARK_HIP_BLS12_377_FR>("BLS12_377_FR", 11);
+  check_device_chain<ARK_HIP_BN254_FR>("BN254_FR", 5);
   EXPECT(!Radix2EvaluationDomain<ARK_HIP_BN254_FR>::new_(((size_t)1 << 28) + 1).has_value(), "too large -> None");
   std::printf(fails ? "FAILED (%d)\n" : "all ok\n", fails);
   return fails ? 1 : 0;

@@ -187,3 +187,57 @@ def test_narrow_scalar_entries_are_hooked():
     assert "fn msm_small(" in msm_rs[msm_rs.index("macro_rules! hip_sw_config"):]
     # the five (bytes, max_bits) pairs of the shim are the ones the library documents
     assert re.search(r"S::U1\(s\) => \(.*, 1, 1\)", msm_rs) and re.search(r"S::U64\(s\) => \(.*, 8, 0\)", msm_rs)
+
+
+def test_layout_guard_checks_offsets_not_only_sizes():
+    """SURVEY 8(b) "Memory layout" / VERDICT r4 missing #4: `Affine`, `Projective` and `Fp` are not `#[repr(C)]`, so the shim
+    asserts where the coordinates ARE, not only how large the structs are -- a reordering of equally sized members must
+    fail it.  The field names are the reference's own (affine.rs:30-37, group.rs:34-41)."""
+    msm_rs = open(os.path.join(ROOT, "rust", "ark-hip", "src", "msm.rs")).read()
+    guard = msm_rs[msm_rs.index("fn layout_ok<"):msm_rs.index("fn device_msm<")]
+    for needle in ("offset_of!(Affine<P>, x) == 0", "offset_of!(Affine<P>, y) == fe", "offset_of!(Projective<P>, x) == 0",
+                   "offset_of!(Projective<P>, y) == fe", "offset_of!(Projective<P>, z) == 2 * fe",
+                   "size_of::<Affine<P>>() == 2 * fe", "size_of::<Projective<P>>() == 3 * fe",
+                   "size_of::<P::BaseField>() == fe"):
+        assert needle in guard, needle
+    assert "use core::mem::{offset_of, size_of, MaybeUninit};" in msm_rs
+    toml = open(os.path.join(ROOT, "rust", "ark-hip", "Cargo.toml")).read()
+    assert re.search(r'rust-version = "1\.(7[7-9]|[89]\d)"', toml), "offset_of! needs Rust 1.77"
+    if os.path.isdir(REF):
+        aff = open(os.path.join(REF, "ec/src/models/short_weierstrass/affine.rs")).read()
+        body = aff[aff.index("pub struct Affine<P: SWCurveConfig>"):]
+        body = body[:body.index("}")]
+        assert re.findall(r"pub(?:\(super\))? (\w+):", body) == ["x", "y", "infinity"]
+        grp = open(os.path.join(REF, "ec/src/models/short_weierstrass/group.rs")).read()
+        body = grp[grp.index("pub struct Projective<P: SWCurveConfig>"):]
+        body = body[:body.index("}")]
+        assert re.findall(r"pub (\w+):", body) == ["x", "y", "z"]
+
+
+def test_device_vec_closes_the_transform_chain():
+    """SURVEY 8(f2) / VERDICT r4 next #5: a device-resident owner type in rust/ark-hip so that evaluate_over_domain ->
+    pointwise -> interpolate costs one upload and one download; every C entry it binds exists with the same arity, and
+    the C++ mirror (compiled and run on the GPU by tests/test_gpu_cpp_mirror.py) offers the same operations."""
+    dev = open(os.path.join(ROOT, "rust", "ark-hip", "src", "device.rs")).read()
+    for needle in ("pub struct DeviceVec<F: FftField>", "pub fn from_slice(x: &[F])", "pub fn to_vec(&self)",
+                   "pub fn evaluate_over_domain(mut self, domain: Radix2EvaluationDomain<F>)",
+                   "pub struct DeviceEvaluations<F: FftField>", "pub fn interpolate(mut self)",
+                   "impl<'a, F: FftField> MulAssign<&'a DeviceEvaluations<F>>", "impl<'a, F: FftField> AddAssign<&'a DeviceEvaluations<F>>",
+                   "impl<'a, F: FftField> SubAssign<&'a DeviceEvaluations<F>>", "impl<F: FftField> Drop for DeviceVec<F>"):
+        assert needle in dev, needle
+    decl = _c_decls()
+    used = set(re.findall(r"sys::(ark_hip_\w+)\(", dev))
+    assert {"ark_hip_malloc", "ark_hip_free", "ark_hip_memcpy_h2d", "ark_hip_memcpy_d2h", "ark_hip_memcpy_d2d",
+            "ark_hip_memset_device", "ark_hip_fr_add_device", "ark_hip_fr_sub_device", "ark_hip_fr_mul_device",
+            "ark_hip_fr_scale_device", "ark_hip_fr_neg_device", "ark_hip_fft_in_place_degree_aware_device",
+            "ark_hip_ifft_in_place_device"} <= used
+    sys_rs = open(os.path.join(ROOT, "rust", "ark-hip-sys", "src", "lib.rs")).read()
+    for name in used:
+        assert name in decl, name
+        assert "pub fn %s(" % name in sys_rs, name
+    lib_rs = open(os.path.join(ROOT, "rust", "ark-hip", "src", "lib.rs")).read()
+    assert "pub mod device;" in lib_rs
+    hpp = open(os.path.join(ROOT, "include", "ark_hip.hpp")).read()
+    for needle in ("class DeviceVec", "struct DeviceEvaluations", "evaluate_over_domain(DeviceVec<FIELD_ID>&& coeffs",
+                   "DeviceVec<FIELD_ID> interpolate() &&"):
+        assert needle in hpp, needle

@@ -75,7 +75,7 @@ for step in "$@"; do
       python tools/rocpd_stats.py $(db p_sq) --pmc --min-us 50 > $O/pmc_sq$suffix.txt 2>> $O/post.err
       rm -rf $O/p_sq ;;
     n2gloo)
-      (ARK_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 3 --warmup 1 --log-n 21 --fft-log-n 20 --fft-steps 4 > $O/bench_n2_gloo.json) 2> $O/bench_n2_gloo.err ;;
+      (ARK_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 3 --warmup 1 --log-n 21 --log-total 22 --fft-log-n 20 --fft-steps 4 > $O/bench_n2_gloo.json) 2> $O/bench_n2_gloo.err ;;
     soak) (timeout 1200 python tools/soak.py ${a[1]:-200} 2>&1 | tail -4) > $O/soak.log ;;
     skewsoak) (timeout 1500 python tools/skew_soak.py ${a[1]:-100} ${a[2]:-2024} 2>&1 | grep -v "^it " | tail -8) > $O/skew_soak.log ;;
     mulbench)
