@@ -84,6 +84,7 @@ SYMBOLS = {
     "ark_hip_msm_cache_config": (C.c_int, [C.c_longlong, C.c_int]),
     "ark_hip_msm_cache_clear": (C.c_int, []),
     "ark_hip_msm_cache_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "ark_hip_msm_cache_hash_stats": (C.c_int, [C.POINTER(C.c_uint64)]),
     "ark_hip_msm_sw_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ark_hip_msm_plan": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ark_hip_msm_plan_widths": (C.c_int, [C.c_int, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int),
@@ -130,6 +131,7 @@ SYMBOLS = {
     "ark_hip_test_point_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_test_msm_sharded_emulated": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "ark_hip_test_base_hash": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "ark_hip_test_msm_host_fold": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

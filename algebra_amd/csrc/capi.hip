@@ -9,6 +9,8 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <chrono>
+#include <unistd.h>
 #include <vector>
 #include "msm.cuh"
 #include "fft.cuh"
@@ -172,11 +174,16 @@ struct HostStager {
 //           validated on EVERY call by a hash of the slice's FULL content, computed on host threads while the device
 //           already works from the cached copy; the result is withheld until the hash agrees, otherwise the copy is
 //           refreshed and the MSM rerun.  Never stale, at the price of one pass over the host slice per call.
+struct Hash128 {
+  uint64_t lo = 0, hi = 0;
+  bool operator==(const Hash128& o) const { return lo == o.lo && hi == o.hi; }
+};
 struct BaseCacheEntry {
   int curve = -1;
   const void* host = nullptr;
   size_t n = 0;
-  uint64_t hash = 0;                  // transparent entries: base_hash of the content the device copy holds
+  Hash128 hash;                       // verified entries: base_hash (keyed, 128 bits) of the content the device copy holds
+  double fill_ms = 0;                 // wall time of the call that filled the copy: bases + scalars streamed over PCIe
   DevBuf dev;
   uint64_t last_use = 0;
   unsigned hits = 0;
@@ -184,7 +191,12 @@ struct BaseCacheEntry {
   bool no_prepare = false;            // the per-window table did not fit: do not retry on every call
   PreparedBases* prepared = nullptr;  // built after `auto_prepare` hits (off by default)
 };
-struct BaseCacheStats { uint64_t hits = 0, misses = 0, refreshed = 0, evicted = 0, pinned_hits = 0; };
+struct BaseCacheStats {
+  uint64_t hits = 0, misses = 0, refreshed = 0, evicted = 0, pinned_hits = 0;
+  uint64_t busy_streamed = 0;   // calls that streamed their bases although a copy was cached: the host was too busy to hash it in time
+  double last_hash_ms = 0;      // the latest validation pass
+  double hash_bytes_per_ms = 0; // its rate, smoothed: what the next call's decision rests on
+};
 
 // One context per (logical) device: stream, workspaces, staging.  Every entry point runs on the calling thread's
 // current device (ark_hip_set_device / ark_hip_init; default: the first device initialised) and holds that
@@ -677,9 +689,11 @@ int mark_producer(Context* c) {
 }
 // returns lane * MSM_JOBS + slot, or a negative error
 int msm_enqueue_ctx(Context* c, int curve, const void* pts, size_t wstride, const MsmPlan* prep, const void* d_scalars,
-                    size_t n, int mont, int lane = 0, int sbytes = 0, int sbits = 0, const MsmPiece* piece = nullptr) {
+                    size_t n, int mont, int lane = 0, int sbytes = 0, int sbits = 0, const MsmPiece* piece = nullptr,
+                    bool may_block = true) {
   hipStream_t st;
   if (int rc = msm_lane_stream(c, lane, &st)) return rc;
+  c->msm[lane].probe_allowed = may_block;   // the width probe synchronises the lane's stream (msm.cuh)
   // the device-pointer FFT / pointwise-product entry points are asynchronous on the context stream (= lane 0) and may be
   // producing this job's scalars: the second lane starts behind the last of them (mark_producer), while lane 0's own MSM
   // kernels -- which lane 1 exists to overlap -- are not waited for
@@ -735,28 +749,64 @@ void free_prepared(PreparedBases* pb) {  // the caller has made sure no job in f
   delete pb;
 }
 
-// Hash of a base slice's FULL content (transparent entries).  64 KiB blocks, each hashed with four independent
-// multiply-rotate lanes (every step is a bijection of the lane state for a fixed word and injective in the word, so ANY
-// single-word edit changes the block hash), block hashes chained in order; blocks are dealt to `threads` host threads.
-// Not cryptographic: it guards against a caller's in-place edits, not an adversary.
+// Hash of a base slice's FULL content (verified-cache entries): a keyed 128-bit universal hash (round 5; the round-4
+// hash was 64 bits of unkeyed multiply-rotate lanes -- a collision was constructible from this source).
+//   key      drawn once per process from the OS (getrandom; /dev/urandom; address-space noise as the last resort) and
+//            expanded to 64 KiB of key words: nothing in the source or in another process predicts it
+//   block    64 KiB of the slice under UMAC's NH with 64-bit words,
+//                NH_K(m) = sum_i (m_2i + K_2i mod 2^64) * (m_2i+1 + K_2i+1 mod 2^64)   mod 2^128
+//            for ANY two different equal-length blocks, Pr_K[NH_K(m) = NH_K(m')] <= 2^-64 (Black, Halevi, Krawczyk,
+//            Krovetz, Rogaway: "UMAC", Crypto '99, thm 4.2 with w = 64); one 64 x 64 -> 128 multiply per two words
+//   slice    the 128-bit block values (with the block index and the length folded in) under NH again with a second key
+//            stream: a 128-bit tag; two different slices of one length collide with probability <= 2^-63 over the key
+// The tag guards a cached device copy against in-place edits of the host slice, accidental OR crafted by a party that does
+// not hold the process's key; it is not a MAC against a party that can read this process's memory.
+// Blocks are dealt to host threads (ARK_HIP_HASH_THREADS, default 8).
 constexpr size_t HASH_BLOCK_WORDS = 8192;
-inline uint64_t hash_block(const uint64_t* p, size_t words, uint64_t seed) {
-  const uint64_t K = 0xff51afd7ed558ccdull;
-  uint64_t h0 = seed ^ 0x9e3779b97f4a7c15ull, h1 = seed ^ 0xc2b2ae3d27d4eb4full, h2 = seed ^ 0x165667b19e3779f9ull,
-           h3 = seed ^ 0x27d4eb2f165667c5ull;
-  auto step = [K](uint64_t h, uint64_t v) {
-    h = (h ^ v) * K;
-    return (h << 31) | (h >> 33);
-  };
+struct HashKey {
+  uint64_t k[HASH_BLOCK_WORDS + 2];   // block key (one word per message word, + 2 for the index / length words)
+  uint64_t seed2;                     // seed of the second-level key stream
+};
+inline uint64_t splitmix64(uint64_t& x) {
+  uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+const HashKey& hash_key() {
+  static const HashKey* key = [] {
+    HashKey* hk = new HashKey;
+    uint64_t seed[2] = {0, 0};
+    bool ok = false;
+    if (FILE* f = fopen("/dev/urandom", "rb")) {
+      ok = fread(seed, 1, sizeof(seed), f) == sizeof(seed);
+      fclose(f);
+    }
+    if (!ok) {   // no OS entropy source: time, the heap's and the stack's address (ASLR) -- weaker, still per process
+      seed[0] = (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)hk;
+      seed[1] = (uint64_t)(uintptr_t)&seed ^ ((uint64_t)getpid() << 32);
+    }
+    uint64_t st = seed[0];
+    for (size_t i = 0; i < HASH_BLOCK_WORDS + 2; i++) hk->k[i] = splitmix64(st) ^ seed[1];
+    st ^= seed[1] * 0xd6e8feb86659fd93ull;
+    hk->seed2 = splitmix64(st);
+    return hk;
+  }();
+  return *key;
+}
+// NH over `words` words of p (odd tail: zero-padded) + two trailing words (a, b), key offset 0
+inline Hash128 nh_block(const uint64_t* p, size_t words, uint64_t a, uint64_t b, const uint64_t* k) {
+  unsigned __int128 acc0 = 0, acc1 = 0;
   size_t i = 0;
-  for (; i + 4 <= words; i += 4) {
-    h0 = step(h0, p[i]);
-    h1 = step(h1, p[i + 1]);
-    h2 = step(h2, p[i + 2]);
-    h3 = step(h3, p[i + 3]);
+  for (; i + 4 <= words; i += 4) {   // two independent accumulators: the multiplier pipelines
+    acc0 += (unsigned __int128)(p[i] + k[i]) * (p[i + 1] + k[i + 1]);
+    acc1 += (unsigned __int128)(p[i + 2] + k[i + 2]) * (p[i + 3] + k[i + 3]);
   }
-  for (; i < words; i++) h0 = step(h0, p[i]);
-  return step(step(step(h0, h1), h2), h3);
+  for (; i + 2 <= words; i += 2) acc0 += (unsigned __int128)(p[i] + k[i]) * (p[i + 1] + k[i + 1]);
+  if (i < words) acc0 += (unsigned __int128)(p[i] + k[i]) * k[i + 1];
+  acc1 += (unsigned __int128)(a + k[HASH_BLOCK_WORDS]) * (b + k[HASH_BLOCK_WORDS + 1]);
+  const unsigned __int128 r = acc0 + acc1;
+  return Hash128{(uint64_t)r, (uint64_t)(r >> 64)};
 }
 int hash_threads() {
   static int nt = -1;
@@ -769,13 +819,14 @@ int hash_threads() {
   }
   return nt;
 }
-uint64_t base_hash(const uint64_t* p, size_t words) {
+Hash128 base_hash(const uint64_t* p, size_t words) {
+  const HashKey& hk = hash_key();
   const size_t nblocks = (words + HASH_BLOCK_WORDS - 1) / HASH_BLOCK_WORDS;
-  std::vector<uint64_t> bh(nblocks);
+  std::vector<Hash128> bh(nblocks);
   auto range = [&](size_t b0, size_t b1) {
     for (size_t b = b0; b < b1; b++) {
       const size_t off = b * HASH_BLOCK_WORDS;
-      bh[b] = hash_block(p + off, words - off < HASH_BLOCK_WORDS ? words - off : HASH_BLOCK_WORDS, (uint64_t)b);
+      bh[b] = nh_block(p + off, words - off < HASH_BLOCK_WORDS ? words - off : HASH_BLOCK_WORDS, (uint64_t)b, (uint64_t)words, hk.k);
     }
   };
   int nt = hash_threads();
@@ -792,7 +843,16 @@ uint64_t base_hash(const uint64_t* p, size_t words) {
     range(0, per < nblocks ? per : nblocks);
     for (auto& t : th) t.join();
   }
-  return hash_block(bh.data(), nblocks, (uint64_t)words);
+  // second level: NH over the block values with a key stream of its own (generated on the fly: 2 words per block)
+  unsigned __int128 acc = 0;
+  uint64_t st = hk.seed2;
+  for (size_t b = 0; b < nblocks; b++) {
+    const uint64_t k0 = splitmix64(st), k1 = splitmix64(st);
+    acc += (unsigned __int128)(bh[b].lo + k0) * (bh[b].hi + k1);
+  }
+  const uint64_t k0 = splitmix64(st), k1 = splitmix64(st);
+  acc += (unsigned __int128)((uint64_t)words + k0) * ((uint64_t)nblocks + k1);
+  return Hash128{(uint64_t)acc, (uint64_t)(acc >> 64)};
 }
 
 void cache_configure(Context* c) {
@@ -919,7 +979,7 @@ void cache_maybe_prepare(Context* c, BaseCacheEntry& e) {
 //   run(d_bases, fill, entry)   d_bases == nullptr: no resident copy -- stream the bases with the scalars;
 //                               fill: d_bases is reserved but EMPTY -- upload `bases` into it on the way;
 //                               entry: the cache entry when the WHOLE set is the operand (prepared table), else nullptr.
-// Pinned range: used as is.  Transparent entry (opt-in): the run is speculative -- the slice's full-content hash is
+// Pinned range: used as is.  Verified-cache entry (the cache is ON by default, ark_hip.h): the run is speculative -- the slice's full-content hash is
 // computed on host threads meanwhile and the result only stands if it matches the hash of what the device copy holds.
 template <class Run>
 int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run run) {
@@ -941,8 +1001,38 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
   if (c->cache_budget <= 0 || (long long)bytes > c->cache_budget || bytes < ((size_t)64 << 10)) return run(nullptr, false, nullptr);
   c->cache_clock++;
   long idx = cache_find_exact(c, curve, bases, n, false);
-  uint64_t h = 0;
-  std::thread hasher([&h, bases, n, wpp]() { h = base_hash(bases, n * wpp); });
+  typedef std::chrono::steady_clock Clk;
+  auto ms_since = [](Clk::time_point t) { return std::chrono::duration<double, std::milli>(Clk::now() - t).count(); };
+  // A hit costs one keyed pass over the host slice on hash_threads() host threads, hidden under the MSM -- when the host has
+  // the cores to spare.  Inside a prover whose thread pool already saturates them it does not hide: the pass is measured on
+  // every call (bytes per ms, smoothed), and while the predicted pass exceeds 1.5 x what streaming this slice over PCIe took
+  // when the copy was filled (sets of 64 MiB and more: below, the pass is noise), the call streams instead (the copy stays;
+  // every eighth call hashes again to notice an idle host).
+  if (idx >= 0) {
+    const BaseCacheEntry& e0 = c->base_cache[(size_t)idx];
+    const double rate = c->cache_stats.hash_bytes_per_ms;
+    const char* ad = getenv("ARK_HIP_HASH_ADAPTIVE");   // "0": always validate by hashing (tests that count hits)
+    if (!(ad && ad[0] == '0') && bytes >= ((size_t)64 << 20) && e0.fill_ms > 0 && rate > 0 &&
+        (double)bytes / rate > 1.5 * e0.fill_ms && (c->cache_clock & 7) != 0) {
+      c->cache_stats.busy_streamed++;
+      return run(nullptr, false, nullptr);
+    }
+  }
+  const Clk::time_point t_call = Clk::now();
+  Hash128 h;
+  double hash_ms = 0;
+  std::thread hasher([&h, &hash_ms, bases, n, wpp, ms_since]() {
+    const Clk::time_point t0 = Clk::now();
+    h = base_hash(bases, n * wpp);
+    hash_ms = ms_since(t0);
+  });
+  auto hash_done = [&]() {   // after hasher.join(): fold this pass into the smoothed rate
+    c->cache_stats.last_hash_ms = hash_ms;
+    if (hash_ms > 0) {
+      const double r = (double)bytes / hash_ms, old = c->cache_stats.hash_bytes_per_ms;
+      c->cache_stats.hash_bytes_per_ms = old > 0 ? 0.5 * old + 0.5 * r : r;
+    }
+  };
   if (idx >= 0) {
     {
       BaseCacheEntry& e = c->base_cache[(size_t)idx];
@@ -952,6 +1042,7 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
     idx = cache_find_exact(c, curve, bases, n, false);
     int rc = run(c->base_cache[(size_t)idx].dev.p, false, &c->base_cache[(size_t)idx]);   // speculative
     hasher.join();
+    hash_done();
     BaseCacheEntry& e = c->base_cache[(size_t)idx];
     if (h == e.hash) {
       e.hits++;
@@ -966,7 +1057,9 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
     e.hash = h;
     e.hits = 0;
     c->cache_stats.refreshed++;
+    const Clk::time_point t_fill = Clk::now();
     rc = run(e.dev.p, true, nullptr);
+    e.fill_ms = ms_since(t_fill);
     if (rc) cache_forget(c, curve, bases, n, false);
     return rc;
   }
@@ -978,17 +1071,22 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
   ne.last_use = c->cache_clock;
   if (!cache_make_room(c, (long long)(bytes + bytes / 8 + 256)) || ne.dev.ensure(bytes)) {
     hasher.join();   // no room on the device right now: not an error, the bases stream instead
+    hash_done();
     return run(nullptr, false, nullptr);
   }
   c->cache_stats.misses++;
   c->base_cache.push_back(ne);
   const int rc = run(ne.dev.p, true, nullptr);
+  const double fill_ms = ms_since(t_call);   // bases + scalars over PCIe under the call's kernels: the streamed call's cost
   hasher.join();
+  hash_done();
   if (rc) {
     cache_forget(c, curve, bases, n, false);
     return rc;
   }
-  c->base_cache[(size_t)cache_find_exact(c, curve, bases, n, false)].hash = h;
+  BaseCacheEntry& filled = c->base_cache[(size_t)cache_find_exact(c, curve, bases, n, false)];
+  filled.hash = h;
+  filled.fill_ms = fill_ms;
   return 0;
 }
 
@@ -1031,7 +1129,14 @@ int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t* host_
     std::vector<size_t> wts;
     if (const char* e = getenv("ARK_HIP_STREAM_SCHEDULE")) {
       for (const char* q = e; *q;) {
-        wts.push_back((size_t)strtoul(q, (char**)&q, 10));
+        char* end = nullptr;
+        const size_t v = (size_t)strtoul(q, &end, 10);
+        if (end == q) {   // not a number: strtoul consumed nothing (it used to loop here for ever) -- ignore the variable
+          wts.clear();
+          break;
+        }
+        if (v) wts.push_back(v);
+        q = end;
         if (*q == ',') q++;
       }
     }
@@ -1191,6 +1296,7 @@ int sums_write_block(Context* c, int curve, int slot_full, char* d_block, MsmSum
   const size_t pb = (size_t)CURVES[curve].fe_words * 32;
   MsmSumsHeader* hp = (MsmSumsHeader*)c->comm_sums_pinned + stage_slot;   // staging of this block's header (one slot per block
                                                                           // written in one call: the copies are asynchronous)
+  const bool ran = rc == 0;   // a non-empty job: its kernels ran, ws.hctr holds ITS flags (an empty job touches none)
   if (rc == 1 || info.h.npairs == 0 || info.h.npairs > SUMS_MAX_PARTS) {
     memset(&info.h, 0, sizeof(info.h));   // no usable sums: every rank sees npairs == 0 and falls back
     info.d_sums = nullptr;
@@ -1198,10 +1304,23 @@ int sums_write_block(Context* c, int curve, int slot_full, char* d_block, MsmSum
   *hp = info.h;
   *h_out = info.h;
   ARK_HIP_TRY(hipMemcpyAsync(d_block, hp, sizeof(MsmSumsHeader), hipMemcpyHostToDevice, c->stream));
-  if (info.d_sums) {
+  if (info.d_sums)
     ARK_HIP_TRY(hipMemcpyAsync(d_block + sizeof(MsmSumsHeader), info.d_sums, (size_t)info.h.npairs * pb, hipMemcpyDeviceToDevice, c->stream));
+  // the scalar-range flag travels whether or not sums do (a zeroed header -- empty shard, too many parts -- used to drop
+  // it: the peers then took the fallback while this rank alone returned the error from its own finish)
+  if (ran && ws.hctr.p)
     ARK_HIP_TRY(hipMemcpyAsync(d_block + offsetof(MsmSumsHeader, err), (const u32*)ws.hctr.p + 3, 4, hipMemcpyDeviceToDevice, c->stream));
-  }
+  return 0;
+}
+// A rank whose local part failed BEFORE the collective (bad argument, no memory, busy lanes) must still take part in it, or
+// its peers wait for ever: it posts a header that says so -- err = SUMS_ERR_LOCAL + (-code) -- and every rank returns that code.
+constexpr uint32_t SUMS_ERR_LOCAL = 0x100;
+int sums_write_failure(Context* c, char* d_block, int code, MsmSumsHeader* h_out) {
+  MsmSumsHeader* hp = (MsmSumsHeader*)c->comm_sums_pinned;
+  memset(hp, 0, sizeof(*hp));
+  hp->err = SUMS_ERR_LOCAL + (uint32_t)(-code);
+  *h_out = *hp;
+  ARK_HIP_TRY(hipMemcpyAsync(d_block, hp, sizeof(MsmSumsHeader), hipMemcpyHostToDevice, c->stream));
   return 0;
 }
 // all `world` blocks sit in d_blocks: add them, bring the sums and the headers to the host, decide.  *agree = the ranks
@@ -1218,6 +1337,11 @@ int sums_reduce(Context* c, int curve, const MsmSumsHeader& mine, const char* d_
   if (mine.npairs) ARK_HIP_TRY(hipMemcpyAsync(h_sums, d_out, (size_t)mine.npairs * pb, hipMemcpyDeviceToHost, c->stream));
   ARK_HIP_TRY(hipStreamSynchronize(c->stream));
   bool same = mine.npairs != 0, err = false;
+  for (int r = 0; r < world; r++)   // a rank that failed before the collective: its code is every rank's (lowest rank's first)
+    if (hh[r].err >= SUMS_ERR_LOCAL) {
+      *agree = false;
+      return -(int)(hh[r].err - SUMS_ERR_LOCAL);
+    }
   for (int r = 0; r < world; r++) {
     const MsmSumsHeader& o = hh[r];
     err |= o.err != 0;
@@ -1564,16 +1688,22 @@ int ark_hip_curve_generator(int curve, uint64_t* out_xy) {
 }
 
 // ---- MSM ------------------------------------------------------------------------------------------------
-int ark_hip_msm_sw_device_async(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont,
-                                ark_hip_msm_job** out_job) {
+// may_block: the caller is about to wait for the result anyway (the synchronous entry), so the width probe's read-back may
+// drain the lane's stream; the public *_async entries never block on queued device work
+static int msm_sw_device_enqueue(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont,
+                                 ark_hip_msm_job** out_job, bool may_block) {
   if (curve < 0 || curve > 4 || !out_job || (n && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
   const int lane = msm_pick_lane(sc.c);
   if (lane < 0) return lane;
-  int slot = msm_enqueue_ctx(sc.c, curve, d_bases, 0, nullptr, d_scalars, n, mont, lane);
+  int slot = msm_enqueue_ctx(sc.c, curve, d_bases, 0, nullptr, d_scalars, n, mont, lane, 0, 0, nullptr, may_block);
   if (slot < 0) return slot;
   *out_job = (ark_hip_msm_job*)new MsmJobHandle{sc.c->logical, curve, slot};
   return 0;
+}
+int ark_hip_msm_sw_device_async(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont,
+                                ark_hip_msm_job** out_job) {
+  return msm_sw_device_enqueue(curve, d_bases, d_scalars, n, mont, out_job, false);
 }
 
 int ark_hip_msm_wait(ark_hip_msm_job* job, uint64_t* out_xyz) {
@@ -1598,15 +1728,17 @@ int ark_hip_msm_wait(ark_hip_msm_job* job, uint64_t* out_xyz) {
 int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int mont, uint64_t* out_xyz) {
   if (!out_xyz) return ARK_HIP_ERR_ARG;
   ark_hip_msm_job* job = nullptr;
-  int rc = ark_hip_msm_sw_device_async(curve, d_bases, d_scalars, n, mont, &job);
+  int rc = msm_sw_device_enqueue(curve, d_bases, d_scalars, n, mont, &job, true);
   if (rc) return rc;
   return ark_hip_msm_wait(job, out_xyz);
 }
 
 // The entry SWCurveConfig::msm / the msm_bigint hook land in (rust/ark-hip/src/msm.rs, patches/0001): host slices in,
-// Projective out -- a function of the two slices.  Default: bases and scalars stream over PCIe in pieces under the
-// previous piece's kernels (msm_stream), nothing is retained.  A base slice inside a PINNED range (ark_hip_msm_bases_pin)
-// or found in the opt-in transparent cache uses the resident copy and uploads only its scalars (msm_with_bases).
+// Projective out -- a function of the two slices.  A base slice inside a PINNED range (ark_hip_msm_bases_pin) or found in
+// the verified cache (ON by default with a quarter of the device memory; every hit is validated against a keyed hash of the
+// slice's full content, msm_with_bases) uses the resident copy and uploads only its scalars.  With the cache off (budget 0)
+// or a slice that does not fit it, bases and scalars stream over PCIe in pieces under the previous piece's kernels
+// (msm_stream) and nothing is retained.
 int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xyz) {
   if (curve < 0 || curve > 4 || !out_xyz || (n && (!bases || !scalars))) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
@@ -1691,7 +1823,7 @@ int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, 
   ARK_SCOPE(sc);
   Context* c = sc.c;
   if (n == 0) return ark_hip_msm_sw_small_device(curve, nullptr, nullptr, 0, scalar_bytes, max_bits, out_xyz);
-  // the base set is looked up like ark_hip_msm_sw's (pinned range / opt-in transparent cache); the scalars are small:
+  // the base set is looked up like ark_hip_msm_sw's (pinned range / verified cache, on by default); the scalars are small:
   // one upload.  Uploads ride the copy stream and are complete before the MSM is enqueued on either lane.
   const size_t bb = n * (size_t)CURVES[curve].fe_words * 16, sb = n * (size_t)scalar_bytes;
   return msm_with_bases(c, curve, bases, n, [&](const void* d_res, bool fill, BaseCacheEntry*) -> int {
@@ -1766,6 +1898,27 @@ int ark_hip_msm_cache_stats(uint64_t out[8]) {
   out[5] = sc.c->cache_stats.evicted;
   out[6] = pinned;
   out[7] = sc.c->cache_stats.pinned_hits;
+  return 0;
+}
+// Test hook (host only, no device): the verified cache's tag of `words` u64 words -- tests/test_capi_host.py checks that
+// edits the round-4 hash could not see (a two-word edit built from its published constants) change it.
+int ark_hip_test_base_hash(const uint64_t* p, size_t words, uint64_t out[2]) {
+  if (!out || (words && !p)) return ARK_HIP_ERR_ARG;
+  const Hash128 h = base_hash(p, words);
+  out[0] = h.lo;
+  out[1] = h.hi;
+  return 0;
+}
+// the validation pass itself: [0] calls that streamed their bases although a copy was cached because the host was too busy
+// to hash the slice in the time streaming takes, [1] the latest pass in microseconds, [2] its smoothed rate in MB/s,
+// [3] host threads per pass
+int ark_hip_msm_cache_hash_stats(uint64_t out[4]) {
+  if (!out) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  out[0] = sc.c->cache_stats.busy_streamed;
+  out[1] = (uint64_t)(sc.c->cache_stats.last_hash_ms * 1e3);
+  out[2] = (uint64_t)(sc.c->cache_stats.hash_bytes_per_ms / 1e3);
+  out[3] = (uint64_t)hash_threads();
   return 0;
 }
 
@@ -1865,8 +2018,8 @@ int ark_hip_msm_bases_info(const ark_hip_msm_bases* bases, size_t* n, int* windo
   if (table_bytes) *table_bytes = (size_t)pb->plan.W * pb->n * (size_t)CURVES[pb->curve].fe_words * 16;
   return 0;
 }
-int ark_hip_msm_prepared_device_async(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int mont,
-                                      ark_hip_msm_job** out_job) {
+static int msm_prepared_device_enqueue(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int mont,
+                                       ark_hip_msm_job** out_job, bool may_block) {
   if (!bases || !out_job) return ARK_HIP_ERR_ARG;
   const PreparedBases* pb = (const PreparedBases*)bases;
   if (n > pb->n || (n && !d_scalars)) return ARK_HIP_ERR_ARG;
@@ -1874,24 +2027,28 @@ int ark_hip_msm_prepared_device_async(const ark_hip_msm_bases* bases, const void
   if (int rc = sc.enter(pb->logical)) return rc;
   const int lane = msm_pick_lane(sc.c);
   if (lane < 0) return lane;
-  int slot = msm_enqueue_ctx(sc.c, pb->curve, pb->table.p, pb->n, &pb->plan, d_scalars, n, mont, lane);
+  int slot = msm_enqueue_ctx(sc.c, pb->curve, pb->table.p, pb->n, &pb->plan, d_scalars, n, mont, lane, 0, 0, nullptr, may_block);
   if (slot < 0) return slot;
   *out_job = (ark_hip_msm_job*)new MsmJobHandle{pb->logical, pb->curve, slot};
   return 0;
+}
+int ark_hip_msm_prepared_device_async(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int mont,
+                                      ark_hip_msm_job** out_job) {
+  return msm_prepared_device_enqueue(bases, d_scalars, n, mont, out_job, false);
 }
 int ark_hip_msm_prepared_device(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n, int mont,
                                 uint64_t* out_xyz) {
   if (!out_xyz) return ARK_HIP_ERR_ARG;
   ark_hip_msm_job* job = nullptr;
-  int rc = ark_hip_msm_prepared_device_async(bases, d_scalars, n, mont, &job);
+  int rc = msm_prepared_device_enqueue(bases, d_scalars, n, mont, &job, true);
   if (rc) return rc;
   return ark_hip_msm_wait(job, out_xyz);
 }
 // Host scalars: uploaded on the copy stream into a two-slot ring, so that the upload of the next MSM's scalars
 // overlaps the previous MSM's kernels (the steady state of a prover that commits to one polynomial after another
 // against a resident SRS).  Pinned host memory (ark_hip_host_alloc) makes the copy truly asynchronous.
-int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n, int mont,
-                               ark_hip_msm_job** out_job) {
+static int msm_prepared_host_enqueue(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n, int mont,
+                                     ark_hip_msm_job** out_job, bool may_block) {
   if (!bases || !out_job) return ARK_HIP_ERR_ARG;
   const PreparedBases* pb = (const PreparedBases*)bases;
   if (n > pb->n || (n && !scalars)) return ARK_HIP_ERR_ARG;
@@ -1917,7 +2074,8 @@ int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* s
     }
   }
   int rc = ring_publish(c, k, compute);
-  int slot = rc ? rc : msm_enqueue_ctx(c, pb->curve, pb->table.p, pb->n, &pb->plan, c->ring_s[k].p, n, mont, lane);
+  int slot = rc ? rc : msm_enqueue_ctx(c, pb->curve, pb->table.p, pb->n, &pb->plan, c->ring_s[k].p, n, mont, lane, 0, 0, nullptr,
+                                       may_block);
   (void)ring_release(c, k, compute);
   if (slot < 0) {
     (void)hipStreamSynchronize(c->copy_stream);  // nothing reads caller memory once an error has been returned
@@ -1926,10 +2084,14 @@ int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* s
   *out_job = (ark_hip_msm_job*)new MsmJobHandle{pb->logical, pb->curve, slot};
   return 0;
 }
+int ark_hip_msm_prepared_async(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n, int mont,
+                               ark_hip_msm_job** out_job) {
+  return msm_prepared_host_enqueue(bases, scalars, n, mont, out_job, false);
+}
 int ark_hip_msm_prepared(const ark_hip_msm_bases* bases, const uint64_t* scalars, size_t n, int mont, uint64_t* out_xyz) {
   if (!out_xyz) return ARK_HIP_ERR_ARG;
   ark_hip_msm_job* job = nullptr;
-  int rc = ark_hip_msm_prepared_async(bases, scalars, n, mont, &job);
+  int rc = msm_prepared_host_enqueue(bases, scalars, n, mont, &job, true);
   if (rc) return rc;
   return ark_hip_msm_wait(job, out_xyz);
 }
@@ -2376,6 +2538,7 @@ int ark_hip_comm_unique_id(void* out_id) {
 }
 int ark_hip_comm_init(const void* id, int rank, int world) {
   if (!id || world < 1 || rank < 0 || rank >= world) return ARK_HIP_ERR_ARG;
+  if (world > MAX_DEV) return ARK_HIP_ERR_ARG;   // the gathered headers of the sharded MSM have MAX_DEV pinned slots (sums_buffers)
   ARK_SCOPE(sc);
   Context* c = sc.c;
   if (c->comm) return ARK_HIP_ERR_BUSY;   // one communicator per device: destroy first
@@ -2413,33 +2576,51 @@ int ark_hip_comm_destroy(void) {
 
 // local MSM -> exchange of the part sums -> one host tail (all ranks equal plans), or the fallback on finished partials
 static int msm_sharded_finish(Context* c, int curve, int slot_full, uint64_t* out_xyz) {
-  if (!c->comm || c->comm_world == 1) return msm_finish_ctx(c, curve, slot_full, out_xyz);
+  // slot_full < 0: this rank's enqueue (or its argument check) failed with that code.  With a communicator it still goes
+  // through the exchange -- every rank reaches the collective or none does -- and all ranks return the code together.
+  const bool have_job = slot_full >= 0;
+  if (!c->comm || c->comm_world == 1) return have_job ? msm_finish_ctx(c, curve, slot_full, out_xyz) : slot_full;
+  auto drop = [&]() { if (have_job) msm_discard_ctx(c, curve, slot_full); };   // frees the lane's job slot: on EVERY error exit
   const RcclApi* api = rccl_api();
   if (!api) {
-    msm_discard_ctx(c, curve, slot_full);
+    drop();
     return ARK_HIP_ERR_COMM;
   }
   const int world = c->comm_world;
   int rc = sums_buffers(c, curve, world);
+  if (rc) {   // not even the exchange buffers: nothing can be posted (the peers' collective fails or times out in RCCL)
+    drop();
+    return rc;
+  }
   const size_t bb = sums_block_bytes(curve);
   char* d_send = (char*)c->comm_sums.p;
   char* d_recv = d_send + bb;
   MsmSumsHeader mine{};
-  if (rc == 0) rc = sums_write_block(c, curve, slot_full, d_send, &mine);
-  if (rc) {   // (a local failure before the collective is the caller's to broadcast, as for every sharded entry)
-    msm_discard_ctx(c, curve, slot_full);
-    return rc;
+  rc = have_job ? sums_write_block(c, curve, slot_full, d_send, &mine) : slot_full;
+  if (rc) {
+    const int local = rc;
+    if (int rc2 = sums_write_failure(c, d_send, local, &mine)) {
+      drop();
+      return rc2;
+    }
   }
   // only the header and the parts a plan can have travel: SUMS_MAX_PARTS bounds the block, the count is what every rank posts
-  ARK_RCCL_TRY(api, api->AllGather(d_send, d_recv, bb, ncclUint8, c->comm, c->stream));
+  {
+    ncclResult_t r = api->AllGather(d_send, d_recv, bb, ncclUint8, c->comm, c->stream);
+    if (r != ncclSuccess) {
+      fprintf(stderr, "ark_hip: ncclAllGather of the part sums failed: %s\n", api->GetErrorString(r));
+      drop();
+      return ARK_HIP_ERR_COMM;
+    }
+  }
   bool agree = false;
   rc = sums_reduce(c, curve, mine, d_recv, world, out_xyz, &agree);
-  if (rc || agree) {
-    msm_discard_ctx(c, curve, slot_full);   // the job's own host tail is not needed
-    return rc;
+  if (rc || agree || !have_job) {
+    drop();   // the job's own host tail is not needed
+    return rc ? rc : (have_job ? 0 : slot_full);
   }
   uint64_t part[36];
-  if (int rc2 = msm_finish_ctx(c, curve, slot_full, part)) return rc2;
+  if (int rc2 = msm_finish_ctx(c, curve, slot_full, part)) return rc2;   // (finish frees the slot itself)
   return msm_sharded_combine(c, curve, part, out_xyz);
 }
 int ark_hip_msm_sw_device_sharded(int curve, const void* d_bases, const void* d_scalars, size_t n_local, int mont,
@@ -2447,18 +2628,17 @@ int ark_hip_msm_sw_device_sharded(int curve, const void* d_bases, const void* d_
   if (curve < 0 || curve > 4 || !out_xyz || (n_local && (!d_bases || !d_scalars))) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
   int slot = msm_enqueue_ctx(sc.c, curve, d_bases, 0, nullptr, d_scalars, n_local, mont);
-  if (slot < 0) return slot;
-  return msm_sharded_finish(sc.c, curve, slot, out_xyz);   // every rank reaches the collective or none
+  return msm_sharded_finish(sc.c, curve, slot, out_xyz);   // (a failed enqueue included: every rank reaches the collective)
 }
 int ark_hip_msm_prepared_device_sharded(const ark_hip_msm_bases* bases, const void* d_scalars, size_t n_local, int mont,
                                         uint64_t* out_xyz) {
   if (!bases || !out_xyz) return ARK_HIP_ERR_ARG;
   const PreparedBases* pb = (const PreparedBases*)bases;
-  if (n_local > pb->n) return ARK_HIP_ERR_ARG;
   Scope sc;
   if (int rc = sc.enter(pb->logical)) return rc;
-  int slot = msm_enqueue_ctx(sc.c, pb->curve, pb->table.p, pb->n, &pb->plan, d_scalars, n_local, mont);
-  if (slot < 0) return slot;
+  // more scalars than the set holds is THIS rank's error only: it still joins the exchange and every rank returns it
+  int slot = n_local > pb->n ? ARK_HIP_ERR_ARG
+                             : msm_enqueue_ctx(sc.c, pb->curve, pb->table.p, pb->n, &pb->plan, d_scalars, n_local, mont);
   return msm_sharded_finish(sc.c, pb->curve, slot, out_xyz);
 }
 // Test hook: the exchange of msm_sharded_finish with the ranks EMULATED in one process (one GPU): `world` local MSMs run one

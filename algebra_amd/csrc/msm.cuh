@@ -1410,6 +1410,7 @@ struct MsmWorkspace {
   hipStream_t side = nullptr;
   hipEvent_t grp_ev[2] = {nullptr, nullptr};
   u32* probe_host = nullptr;   // pinned word the width probe reads back into (a pageable target costs a staged copy)
+  bool probe_allowed = true;   // set per call by the C ABI: the *_async entries must not wait for the lane's stream to drain
   void release() {
     if (probe_host) (void)hipHostFree(probe_host);
     probe_host = nullptr;
@@ -1498,7 +1499,9 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     }();
     bool idle = true;
     for (int i = 0; i < MSM_JOBS; i++) idle = idle && !ws.jobs[i].busy;
-    if (probe_on && idle) {
+    // (the probe waits for its 40-byte read-back, i.e. for everything already queued on this stream -- a device transform
+    //  producing the scalars, say: the asynchronous entry points skip it and keep the uniform-scalar plan)
+    if (probe_on && idle && ws.probe_allowed) {
       constexpr size_t PW = (1 + MSM_WIDTH_CLASSES) * 4;
       if (ws.probe.ensure(PW)) return -3;
       if (!ws.probe_host) ARK_HIP_TRY(hipHostMalloc((void**)&ws.probe_host, 64, hipHostMallocDefault));

@@ -170,6 +170,14 @@ def base_cache_stats():
                     [int(v) for v in out]))
 
 
+def base_cache_hash_stats():
+    """the verified cache's validation pass: calls streamed because the host was too busy to hash in time, the latest pass
+    (us), its smoothed rate (MB/s), host threads per pass"""
+    out = (C.c_uint64 * 4)()
+    check(lib().ark_hip_msm_cache_hash_stats(out), "ark_hip_msm_cache_hash_stats")
+    return dict(zip(("busy_streamed", "last_hash_us", "hash_mb_per_s", "threads"), [int(v) for v in out]))
+
+
 def sum_projective(curve, points):
     """Sum of Projective points on the host (Projective: Sum, group.rs:659-663): the multi-GPU combine."""
     cid = cv.curve_id(curve)

@@ -100,7 +100,7 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
  * copies of base slices are kept in two ways:
  *
  * Verified cache (on by default).  Device copies keyed by (curve, host address, length), validated on EVERY call by a
- * hash of the slice's FULL content: host threads (ARK_HIP_HASH_THREADS, default 8) hash the slice while the device already
+ * keyed 128-bit hash of the slice's FULL content: host threads (ARK_HIP_HASH_THREADS, default 8) hash the slice while the device already
  * works from the cached copy, and the result is returned only if the hash equals that of the content the copy was filled
  * from -- otherwise the copy is refreshed and the MSM rerun.  An in-place edit of the slice, of a single limb, is therefore
  * honoured on the next call; a hit costs one pass over the host slice instead of its PCIe transfer (2^24 BLS12-381 G1:
@@ -128,13 +128,20 @@ int ark_hip_msm_bases_unpin(int curve, const uint64_t* bases, size_t n);
 int ark_hip_msm_cache_config(long long budget_bytes, int auto_prepare_after);
 int ark_hip_msm_cache_clear(void);
 int ark_hip_msm_cache_stats(uint64_t out[8]);
+/* The validation pass of the verified cache (round 5): a keyed 128-bit universal hash (NH with 64-bit words under a key
+ * drawn from the OS once per process -- two different slices of one length collide with probability <= 2^-63 over the key,
+ * and nothing in the source predicts it).  The pass is timed on every call; while its predicted duration exceeds what
+ * streaming the slice over PCIe took when the copy was filled (a host whose cores are saturated by the caller's own thread
+ * pool), calls stream instead and every eighth call hashes again.  out: [0] calls streamed for that reason, [1] the
+ * latest pass in microseconds, [2] its smoothed rate in MB/s, [3] host threads per pass (ARK_HIP_HASH_THREADS). */
+int ark_hip_msm_cache_hash_stats(uint64_t out[4]);
 /* VariableBaseMSM::msm_u1 / msm_u8 / msm_u16 / msm_u32 / msm_u64 (variable_base/mod.rs:87-117; CPU bodies msm_binary /
  * msm_u8.. :373-434): scalars are n unsigned integers of scalar_bytes (1, 2, 4 or 8) bytes -- exactly the reference's
  * &[bool] (one byte each, max_bits = 1), &[u8], &[u16], &[u32], &[u64] -- whose low max_bits bits may be set (0 = all
  * 8 * scalar_bytes).  Only the ceil((max_bits + 1) / c) windows such scalars reach are built: nothing is widened to 32
  * bytes (a u8 vector uploads 1/32 of what msm_bigint would) and no empty window is sorted.  The host-pointer form shares
  * ark_hip_msm_sw's
- * pinned sets / opt-in cache. */
+ * pinned sets and verified cache (on by default). */
 int ark_hip_msm_sw_small(int curve, const uint64_t* bases, const void* scalars, size_t n, int scalar_bytes, int max_bits,
                          uint64_t* out_xyz);
 int ark_hip_msm_sw_small_device(int curve, const void* d_bases, const void* d_scalars, size_t n, int scalar_bytes,
@@ -155,7 +162,10 @@ int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars,
  * may be in flight per device (ARK_HIP_ERR_BUSY beyond).  Inputs must stay valid until the wait returns.
  * With a job already in flight the next one runs on the device's second MSM lane (own stream and workspace): its
  * digits / sort / reduction overlap the first job's accumulate kernel (two jobs in flight: +20 % MSMs/s at 2^20, +5 % at
- * 2^24).  Synchronous calls from one thread never use (or allocate) the second lane. */
+ * 2^24).  Synchronous calls from one thread never use (or allocate) the second lane.
+ * The *_async entries never wait for device work already queued (a transform producing the scalars, an earlier job): the
+ * width probe of the synchronous entries (one 40-byte read-back that plans narrow / skewed scalar vectors) is skipped
+ * here, and the plan is the one for n uniform full-width scalars -- correct for any input, optimal for those. */
 typedef struct ark_hip_msm_job ark_hip_msm_job;
 int ark_hip_msm_sw_device_async(int curve, const void* d_bases, const void* d_scalars, size_t n,
                                 int scalars_are_montgomery, ark_hip_msm_job** out_job);
@@ -390,6 +400,8 @@ int ark_hip_test_msm_sharded_emulated(int curve, int world, const void* const* d
  * window combine) as msm_finish runs it.  parts: windows x (nbits + 1) bucket-form points (x | y | zz | zzz), row w =
  * U_(w,0) .. U_(w,nbits-1), A_w; widths: the windows' bit widths.  out = sum_w 2^(off_w) (A_w + 2^log2_l0 sum_b 2^b U_(w,b))
  * as a Projective (x | y | z). */
+/* Host only: the verified cache's 128-bit tag of a buffer (keyed per process: equal only within one process). */
+int ark_hip_test_base_hash(const uint64_t* p, size_t words, uint64_t out[2]);
 int ark_hip_test_msm_host_fold(int curve, const uint64_t* parts, int windows, int nbits, int log2_l0, const int* widths,
                                uint64_t* out_xyz);
 

@@ -80,6 +80,8 @@ extern "C" {
     pub fn ark_hip_msm_cache_config(budget_bytes: c_longlong, auto_prepare_after: c_int) -> c_int;
     pub fn ark_hip_msm_cache_clear() -> c_int;
     pub fn ark_hip_msm_cache_stats(out: *mut u64) -> c_int;
+    /// `[calls streamed because the host was too busy to hash in time, latest pass (us), smoothed rate (MB/s), threads]`
+    pub fn ark_hip_msm_cache_hash_stats(out: *mut u64) -> c_int;
     pub fn ark_hip_msm_sw_device(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,
                                  scalars_are_montgomery: c_int, out_xyz: *mut u64) -> c_int;
     pub fn ark_hip_msm_sw_device_async(curve: c_int, d_bases: *const c_void, d_scalars: *const c_void, n: usize,

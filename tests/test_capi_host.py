@@ -1,6 +1,7 @@
 """CPU-side checks of the product library (no GPU needed): it loads, exports every symbol the header
 declares, and its host-side pieces (domain constants, projective sum, into_affine -- the same
 templated formulas the kernels use, compiled for the host) agree with the oracle."""
+import ctypes as C
 import os
 import re
 
@@ -301,3 +302,57 @@ def test_msm_host_tail_folds_bit_sums_like_the_window_combine(cname):
         want = O.to_affine(cid, O.msm(cid, np.stack(pts), sc, O.NAIVE))
         assert np.array_equal(A.into_affine(cid, out), want), (cname, windows, nbits, l0)
     assert _lib.lib().ark_hip_test_msm_host_fold(cid, None, 1, 1, 0, None, None) != 0      # argument check
+
+
+def _tag(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
+    out = (C.c_uint64 * 2)()
+    assert A.lib().ark_hip_test_base_hash(a.ctypes.data_as(C.c_void_p), a.size, out) == 0
+    return int(out[0]) | (int(out[1]) << 64)
+
+
+def test_verified_cache_tag_is_keyed_128_bits_and_sees_what_the_round4_hash_missed():
+    """the round-4 validation hash -- four unkeyed 64-bit multiply-rotate lanes with published
+    constants -- admitted collisions constructible from the source: flip any bits of word i and repair the lane's state with
+    word i + 4.  The round-5 tag (NH under a per-process key) must tell such a pair apart, must see every single-bit edit,
+    transpositions, length changes, edits in any 64 KiB block, and must be stable within the process."""
+    M64 = (1 << 64) - 1
+    K = 0xff51afd7ed558ccd
+
+    def step(h, v):
+        h = ((h ^ v) * K) & M64
+        return ((h << 31) | (h >> 33)) & M64
+
+    rng = np.random.default_rng(5)
+    words = 3 * 8192 + 77                      # three full blocks and a ragged one
+    a = rng.integers(0, 1 << 63, size=words, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=words, dtype=np.uint64)
+    t0 = _tag(a)
+    assert t0 == _tag(a.copy()) and t0 >> 64 != 0 and t0 & M64 != 0
+    # the constructible collision of the old hash, lane 0 of block 1 (seed = block index 1): words i = 8192 and i + 4
+    i = 8192
+    h_before = 1 ^ 0x9e3779b97f4a7c15          # lane 0's state entering the block
+    v0, v4 = int(a[i]), int(a[i + 4])
+    v0x = v0 ^ 0x0123456789abcdef
+    h1, h1x = step(h_before, v0), step(h_before, v0x)
+    v4x = v4 ^ h1 ^ h1x                        # (h1x ^ v4x) == (h1 ^ v4): the old lane state is identical from here on
+    assert step(h1, v4) == step(h1x, v4x)      # ... which is exactly why the old hash could not see the edit
+    b = a.copy()
+    b[i] = np.uint64(v0x)
+    b[i + 4] = np.uint64(v4x)
+    assert not np.array_equal(a, b) and _tag(b) != t0
+    # every kind of local edit, in every block
+    for pos in (0, 1, 5, 8191, 8192, 2 * 8192 + 3, words - 1):
+        for bit in (0, 31, 63):
+            c = a.copy()
+            c[pos] ^= np.uint64(1 << bit)
+            assert _tag(c) != t0, (pos, bit)
+    c = a.copy()
+    c[[10, 11]] = c[[11, 10]]
+    assert _tag(c) != t0
+    c = a.copy()
+    c[[3, 3 + 8192]] = c[[3 + 8192, 3]]        # the same position of two blocks swapped
+    assert _tag(c) != t0
+    assert _tag(a[:-1]) != t0 and _tag(np.concatenate([a, np.zeros(1, dtype=np.uint64)])) != t0
+    z = np.zeros(8192 * 2, dtype=np.uint64)
+    assert _tag(z) != _tag(z[:8192]) and _tag(z) != 0
+    assert len({_tag(rng.integers(0, 1 << 62, size=64, dtype=np.uint64)) for _ in range(200)}) == 200

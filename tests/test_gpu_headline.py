@@ -108,3 +108,37 @@ def test_fft_2_22_host_pointer_entries_vs_oracle():
     gen = O.field_const(fid, 3)                                   # Fr::GENERATOR, the offset of poly/benches/fft.rs:107
     dc = d.get_coset(gen)
     assert np.array_equal(dc.fft(x).reshape(-1), O.fft(fid, x, log_n, gen, False, threads))
+
+
+def test_2_20_bases_from_the_oracle_through_every_entry():
+    """the at-size tests above build their bases ON THE DEVICE (tools/synth.py grow_bases) and check
+    k*G -- independent of the MSM kernels, but no oracle-generated base set was fed through the device entries above 2^18.
+    Here 2^20 bases come from the ORACLE's generator (oracle/ gen_bases: host arithmetic only), the expected point from the
+    oracle's own msm_bigint_wnaf restatement on the same arrays, and the product path runs them through the plain device
+    entry, a prepared base set, and the host-pointer entry (streamed with the cache off; default settings: miss, then a hit
+    validated by the keyed hash)."""
+    import torch
+    cid = O.CID[CNAME]
+    n = 1 << 20
+    a4 = np.array([0x5EED, 11, 0, 0], dtype=np.uint64)
+    b4 = np.array([0xFACE, 0, 5, 0], dtype=np.uint64)
+    bases = O.gen_bases(cid, a4, b4, n)
+    sc = O.gen_scalars(O.curve_info(cid)[1], 0x2020, n)
+    want = O.to_affine(cid, O.msm(cid, bases, sc, O.WNAF, 16))
+    d_b = torch.from_numpy(bases.view(np.int64)).cuda()
+    d_s = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, d_b, d_s)), want)
+    pb = A.PreparedBases(cid, d_b)
+    assert np.array_equal(A.into_affine(cid, pb.msm_bigint(d_s)), want)
+    pb.free()
+    A.base_cache_config(0, 0)
+    assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, bases, sc)), want)
+    A.base_cache_config(-2, 0)
+    A.base_cache_clear()
+    s0 = A.base_cache_stats()
+    for _ in range(2):
+        assert np.array_equal(A.into_affine(cid, A.msm_bigint(cid, bases, sc)), want)
+    s1 = A.base_cache_stats()
+    assert (s1["misses"] - s0["misses"], s1["hits"] - s0["hits"]) == (1, 1)
+    A.base_cache_clear()
