@@ -99,6 +99,12 @@ typedef uint64_t u64;
   ARK_STMT(13, STR, HI, OPS)
 
 struct Acc96 { u64 lo; u32 hi; };
+// -p0^-1 mod 2^64 by Newton iteration (host Montgomery product: a compile-time constant per modulus)
+constexpr u64 host_inv64(u64 p0) {
+  u64 z = 1;
+  for (int i = 0; i < 6; i++) z *= 2 - p0 * z;
+  return 0 - z;
+}
 ARK_DEV void acc_shift(Acc96& c) { c.lo = (c.lo >> 32) | ((u64)c.hi << 32); c.hi = 0; }
 
 // compile-time access to modulus limbs (keeps them immediates -> s_mov)
@@ -322,13 +328,7 @@ struct Fp {
       y[i] = ((u64)b.l[2 * i + 1] << 32) | b.l[2 * i];
       pp[i] = ((u64)P::P[2 * i + 1] << 32) | P::P[2 * i];
     }
-    u64 inv = 1;  // -p^-1 mod 2^64 by Newton iteration from the 32-bit constant
-    {
-      u64 p0 = pp[0];
-      u64 z = 1;
-      for (int i = 0; i < 6; i++) z *= 2 - p0 * z;
-      inv = 0 - z;
-    }
+    constexpr u64 inv = host_inv64(((u64)P::P[1] << 32) | P::P[0]);  // -p^-1 mod 2^64, folded at compile time
     for (int i = 0; i < M + 2; i++) t[i] = 0;
     for (int i = 0; i < M; i++) {
       unsigned __int128 c = 0;
