@@ -102,8 +102,11 @@ static constexpr int FFT_MAX_EPT = 4;  // elements per lane: tiles of up to 1024
 // One pass = load tile -> kp butterfly stages in LDS -> store tile.  Loops over the lane's elements /
 // butterflies are fully unrolled with predication so that all global loads of a phase (tile rows,
 // twiddles of a stage) are in flight together before the first dependent use.
+#ifndef ARK_FFT_MIN_WAVES
+#define ARK_FFT_MIN_WAVES 1   // A/B builds: 5 caps the kernel at 96 registers (27 spilled) for a fifth workgroup per CU
+#endif
 template <class FP>
-__global__ void __launch_bounds__(FFT_THREADS) fft_pass_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
+__global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
                                                                FftPassArgs a) {
   typedef Fp<FP> F;
   extern __shared__ uint4 lds[];
