@@ -1112,6 +1112,41 @@ __global__ void __launch_bounds__(128, (C::LAZY_A && C::FA::LANES == 2) ? 1 : 2)
   Ops::fin(Ops::unpark(slot)).store(outA + (size_t)t * Pt::BYTES);
 }
 
+// K5a with the two chains of a chunk on two WAVES (round 5).  In the kernel above a lane alternates between the running
+// sum and the weighted sum: 2 L dependent additions, ~25 us each when a SIMD holds one or two waves -- at 2^16 .. 2^20 pairs
+// the whole level is that latency (65 536 lanes at 2^20).  Here wave 0 of a workgroup keeps the running sums of 64 chunks and
+// wave 1 their weighted sums one step behind, the running sum crossing through a double-buffered LDS slot: L + 1 dependent
+// additions, twice the lanes.  Used where the doubled lane count still fits the chip's resident lanes (msm_enqueue).
+template <class C>
+__global__ void __launch_bounds__(128, (C::LAZY_A && C::FA::LANES == 2) ? 1 : 2) msm_reduce_level_split_kernel(
+    const char* __restrict__ in, u32 L, u32 total_out, char* __restrict__ outS, char* __restrict__ outA) {
+  typedef AccOps<C> Ops;
+  typedef typename Ops::Pt Pt;
+  constexpr u32 PTS = 64 / Ops::LANES;   // chunks per workgroup
+  __shared__ uint4 hand_lds[2 * PTS * Ops::ACC_BYTES / 16];
+  const u32 role = threadIdx.x >> 6;     // 0: running sum, 1: weighted sum
+  const u32 pslot = (threadIdx.x & 63u) / Ops::LANES;
+  const u32 t = blockIdx.x * PTS + pslot;
+  const bool live = t < total_out;
+  const size_t base = (size_t)t * L;
+  char* slot0 = (char*)hand_lds + (size_t)pslot * Ops::ACC_BYTES;
+  char* slot1 = slot0 + (size_t)PTS * Ops::ACC_BYTES;
+  typename Ops::Acc a = Ops::zero();
+  for (u32 step = 0; step <= L; step++) {
+    if (role == 0) {
+      if (step < L && live) {
+        Pt x = Pt::load(in + (base + (L - 1 - step)) * Pt::BYTES);
+        Ops::add(a, x);
+        Ops::park(a, (step & 1u) ? slot1 : slot0);
+      }
+    } else if (step > 0 && live) {
+      Ops::add_acc(a, Ops::unpark(((step - 1) & 1u) ? slot1 : slot0));
+    }
+    __syncthreads();   // the running sum of this step is visible; the slot read in this step may be overwritten in the next
+  }
+  if (live) Ops::fin(a).store((role == 0 ? outS : outA) + (size_t)t * Pt::BYTES);
+}
+
 // ---- K5b: the rest of the reduction, bit-sliced -------------------------------------------------------
 // After level 0 every window holds m pairs (S_j, A_j) with  sum_k k B_k = sum_j A_j + L0 * sum_j j S_j.
 // Continuing with chunked running sums costs ~0.4 ms of pure latency per level (a handful of lanes, each a
@@ -1299,7 +1334,10 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       if (!shared && fp2) {
         // measured reduction of the plain G2 path: 0.45 ms + 2.6 ns per bucket up to ~10^6 buckets (short level-0 chunks: the
         // bit-sliced stage is almost half of it), 1.25 ns per bucket beyond (same sweeps)
-        red0 = 0.45e-3 + nbk * (nbk < 1.2e6 ? 2.6e-9 : 1.25e-9);
+        // (round 5 refit, profiles/r5_g2_window_sweep.txt: the lane-pair kernels of round 4 reduce 1.97e6 buckets in 4.6 ms,
+        // 4.98e6 in 10.6, 1.36e7 in 23 -- 1.7 ns per bucket beyond the first 1.2e6, not the 1.25 of the saturated kernels this
+        // line was fitted on; the old figure made c = 19 look 1.7 ms cheaper than it is and cost BLS12-377 G2 2^20 14 %)
+        red0 = 0.45e-3 + (nbk < 1.2e6 ? nbk : 1.2e6) * 2.6e-9 + (nbk > 1.2e6 ? nbk - 1.2e6 : 0.0) * 1.7e-9;
         bits_stage = 0.0;
       }
       if (!shared && !fp2) {
@@ -1909,6 +1947,21 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   auto reduce_windows = [&](size_t w0, size_t wg, hipStream_t st) {
     const size_t bo = w0 * m * Pt::BYTES;                       // (S, A) pairs of window w0
     const size_t po = w0 * (size_t)Q * nchunks * Pt::BYTES;     // chunk partials of window w0
+    // level 0: the two chains of a chunk on one lane (2 L0 dependent additions) or on two waves (L0 + 1, twice the lanes):
+    // the split form where its lanes still fit the chip's resident ones -- 2 waves x 1024 SIMDs (ARK_HIP_MSM_SPLIT_LEVEL=0/1 forces)
+    static const int split_env = [] { const char* e = getenv("ARK_HIP_MSM_SPLIT_LEVEL"); return e ? atoi(e) : -1; }();
+    // measured (profiles/r5_reduce_split_level.txt, BLS12-381 G1): 2^16 0.48 -> 0.44 ms, 2^18 0.70 -> 0.54, 2^20 0.89 -> 0.71
+    // (split lanes <= 131 072: one round of the chip); 2^23 2.31 -> 2.00 (L0 = 32: 33 steps instead of 64 outweigh the 1.75
+    // rounds of 229 376 lanes); 2^21 / 2^22 (L0 = 8, 245 760 lanes) 1.15 -> 1.21 / equal; 2^24, 2^26 equal; the lane-pair
+    // curves (G2) lose 2-3 % everywhere: off there
+    const size_t split_lanes = m * wg * 2;
+    const bool split_level = split_env >= 0 ? split_env != 0
+                                            : (LNr == 1 && L0 >= 2 && (split_lanes <= 131072 || (L0 >= 16 && split_lanes <= 262144)));
+    if (split_level)
+      hipLaunchKernelGGL((msm_reduce_level_split_kernel<C>), dim3((u32)((m * wg * LNr + 63) / 64)), dim3(128), 0, st,
+                         (const char*)d_buckets + w0 * mwin * Pt::BYTES, L0, (u32)(m * wg), (char*)ws.lvlS[0].p + bo,
+                         (char*)ws.lvlA[0].p + bo);
+    else
     hipLaunchKernelGGL((msm_reduce_level_kernel<C>), dim3((u32)((m * wg * LNr + 127) / 128)), dim3(128), 0, st,
                        (const char*)d_buckets + w0 * mwin * Pt::BYTES, L0, (u32)(m * wg), (char*)ws.lvlS[0].p + bo,
                        (char*)ws.lvlA[0].p + bo);
