@@ -268,7 +268,8 @@ def test_msm_host_tail_folds_bit_sums_like_the_window_combine(cname):
     import ctypes as C
     cid = O.CID[cname]
     fw = O.fe_words(cid)
-    for windows, nbits, l0, widths in ((3, 4, 2, [7, 7, 6]), (1, 5, 0, [20]), (4, 3, 3, [6, 6, 6, 5])):
+    for windows, nbits, l0, widths in ((3, 4, 2, [7, 7, 6]), (1, 5, 0, [20]), (4, 3, 3, [6, 6, 6, 5]),
+                                       (11, 4, 2, [9, 9, 9, 9, 9, 9, 9, 8, 8, 8, 8])):   # (>= 4 windows over Fp2: the threaded tail)
         npts = windows * (nbits + 1)
         aff = O.gen_bases(cid, A4, B4, npts + 1)
         t_src = O.gen_bases(cid, B4, A4, npts)                      # x coordinates of other points: the t values
