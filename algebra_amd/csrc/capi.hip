@@ -418,6 +418,11 @@ int fr_scale_dispatch(int field, const void* a, const uint64_t* k4, void* r, siz
   ARK_FIELD_SWITCH(field, X);
 #undef X
 }
+int fr_div_dispatch(int field, const void* num, const void* den, void* r, size_t n, hipStream_t st) {
+#define X(NAME) fr_div_##NAME(num, den, r, n, st)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
 int fr_op_dispatch(int field, int op, const void* a, const void* b, void* r, size_t n, hipStream_t st) {
 #define X(NAME) test_field_op_##NAME(op, a, b, r, n, st)
   ARK_FIELD_SWITCH(field, X);
@@ -2486,6 +2491,21 @@ int ark_hip_fr_scale_device(int field, const void* d_a, const uint64_t* k, void*
   if (!k || (n && (!d_a || !d_r))) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
   if (int rc = fr_scale_dispatch(field, d_a, k, d_r, n, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+// r[i] = a[i] / b[i] (Evaluations /= Evaluations, evaluations/univariate/mod.rs:142-163) and r[i] = 1 / a[i]
+// (ark_ff::batch_inversion, ff/src/fields/mod.rs:358-385): a zero divisor gives zero, as the reference's batch inversion
+// leaves zeros in place.  r may alias an operand.
+int ark_hip_fr_div_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n) {
+  if (n && (!d_a || !d_b || !d_r)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (int rc = fr_div_dispatch(field, d_a, d_b, d_r, n, sc.c->stream)) return rc;
+  return mark_producer(sc.c);
+}
+int ark_hip_fr_inverse_device(int field, const void* d_a, void* d_r, size_t n) {
+  if (n && (!d_a || !d_r)) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  if (int rc = fr_div_dispatch(field, nullptr, d_a, d_r, n, sc.c->stream)) return rc;
   return mark_producer(sc.c);
 }
 // device-to-device copy / byte fill on the context stream (a device vector's clone() and its zero-extension), ordered with

@@ -10,6 +10,9 @@ int fft_run_BLS12_377_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* 
 int test_field_op_BLS12_377_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<Fp<BLS12_377_FR>, true>(op, a, b, r, n, s);
 }
+int fr_div_BLS12_377_FR(const void* num, const void* den, void* r, size_t n, hipStream_t s) {
+  return fr_div_launch<Fp<BLS12_377_FR>>(num, den, r, n, s);
+}
 int fr_scale_BLS12_377_FR(const void* a, const uint64_t* k4, void* r, size_t n, hipStream_t s) {
   return fr_scale_launch<Fp<BLS12_377_FR>>(a, k4, r, n, s);
 }

@@ -10,6 +10,9 @@ int fft_run_BN254_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* root
 int test_field_op_BN254_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<Fp<BN254_FR>, true>(op, a, b, r, n, s);
 }
+int fr_div_BN254_FR(const void* num, const void* den, void* r, size_t n, hipStream_t s) {
+  return fr_div_launch<Fp<BN254_FR>>(num, den, r, n, s);
+}
 int fr_scale_BN254_FR(const void* a, const uint64_t* k4, void* r, size_t n, hipStream_t s) {
   return fr_scale_launch<Fp<BN254_FR>>(a, k4, r, n, s);
 }

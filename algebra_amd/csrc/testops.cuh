@@ -84,6 +84,31 @@ int fr_scale_launch(const void* a, const uint64_t* k4, void* r, size_t n, hipStr
   return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// r[i] = num[i] / den[i] (num == nullptr: 1 / den[i]); a zero denominator gives zero, as ark_ff::batch_inversion leaves zeros
+// in place (ff/src/fields/mod.rs:358-385) and Evaluations::div_assign then multiplies by them (evaluations/univariate/
+// mod.rs:153-163).  Montgomery's trick inside every lane over its own 8 values (lane_batch_inverse, ec.cuh): 3 products per
+// value + 1/8 of a Fermat inversion.  r may alias num or den: a lane reads an index before it writes it and owns it alone.
+template <class F>
+__global__ void __launch_bounds__(128) fr_div_kernel(const char* num, const char* den, char* r, size_t n, size_t lanes) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lanes) return;
+  lane_batch_inverse<F, 8>(
+      t, lanes, n, [&](size_t i) { return F::load(den + i * F::BYTES); },
+      [&](size_t i, const F& zi, bool nonzero) {
+        F out = F::zero();
+        if (nonzero) out = num ? F::mul(F::load(num + i * F::BYTES), zi) : zi;
+        out.store(r + i * F::BYTES);
+      });
+}
+template <class F>
+int fr_div_launch(const void* num, const void* den, void* r, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  const size_t lanes = (n + 7) / 8;
+  hipLaunchKernelGGL((fr_div_kernel<F>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, s, (const char*)num,
+                     (const char*)den, (char*)r, n, lanes);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 // acc: XYZZ (kinds 2..6) or affine (kind 7); other: affine (2,3) or XYZZ (4); out: XYZZ, or Jacobian for kind 6
 template <class C>
 __global__ void __launch_bounds__(128) test_point_op_kernel(int kind, const char* __restrict__ acc_in,

@@ -143,6 +143,16 @@ class DeviceVec:
         check(lib().ark_hip_fr_mul_device(self.field, self.ptr, other.ptr, self.ptr, self.len), "ark_hip_fr_mul_device")
         return self
 
+    def __itruediv__(self, other):
+        """Evaluations /= Evaluations (a zero divisor gives zero, as ark_ff::batch_inversion leaves zeros in place)"""
+        self._same(other)
+        check(lib().ark_hip_fr_div_device(self.field, self.ptr, other.ptr, self.ptr, self.len), "ark_hip_fr_div_device")
+        return self
+
+    def batch_inverse(self):
+        check(lib().ark_hip_fr_inverse_device(self.field, self.ptr, self.ptr, self.len), "ark_hip_fr_inverse_device")
+        return self
+
     def scale(self, k):
         k = np.ascontiguousarray(k, dtype=np.uint64).reshape(4)
         check(lib().ark_hip_fr_scale_device(self.field, self.ptr, k.ctypes.data_as(C.c_void_p), self.ptr, self.len),

@@ -321,6 +321,10 @@ int ark_hip_fr_add_device(int field, const void* d_a, const void* d_b, void* d_r
 int ark_hip_fr_sub_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
 int ark_hip_fr_neg_device(int field, const void* d_a, void* d_r, size_t n);
 int ark_hip_fr_scale_device(int field, const void* d_a, const uint64_t* k, void* d_r, size_t n);
+/* r[i] = a[i] / b[i] (Evaluations /= Evaluations, mod.rs:142-163) and r[i] = 1 / a[i] (ark_ff::batch_inversion,
+ * ff/src/fields/mod.rs:358-385): a zero divisor gives zero, as the reference's batch inversion leaves zeros in place. */
+int ark_hip_fr_div_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
+int ark_hip_fr_inverse_device(int field, const void* d_a, void* d_r, size_t n);
 /* `&DensePolynomial * &DensePolynomial` (poly/src/polynomial/univariate/dense.rs:641-656: evaluate both factors over the
  * radix-2 domain of size >= na + nb - 1, multiply pointwise, interpolate) from HOST coefficient vectors: ONE upload of a and
  * b, both forward transforms in flight together (short factors on the degree-aware path), the pointwise product and the

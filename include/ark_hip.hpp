@@ -494,6 +494,8 @@ class DeviceVec {
   DeviceVec& operator+=(const DeviceVec& o) { same(o); check(ark_hip_fr_add_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_add_device"); return *this; }
   DeviceVec& operator-=(const DeviceVec& o) { same(o); check(ark_hip_fr_sub_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_sub_device"); return *this; }
   DeviceVec& operator*=(const DeviceVec& o) { same(o); check(ark_hip_fr_mul_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_mul_device"); return *this; }
+  DeviceVec& operator/=(const DeviceVec& o) { same(o); check(ark_hip_fr_div_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_div_device"); return *this; }
+  void batch_inverse() { check(ark_hip_fr_inverse_device(FIELD_ID, p_, p_, len_), "ark_hip_fr_inverse_device"); }   // zeros stay zero
   DeviceVec& operator*=(const Fr& k) { check(ark_hip_fr_scale_device(FIELD_ID, p_, k.limbs.data(), p_, len_), "ark_hip_fr_scale_device"); return *this; }
   void negate() { check(ark_hip_fr_neg_device(FIELD_ID, p_, p_, len_), "ark_hip_fr_neg_device"); }
 
@@ -536,6 +538,7 @@ struct DeviceEvaluations {
   DeviceEvaluations& operator+=(const DeviceEvaluations& o) { evals += o.evals; return *this; }
   DeviceEvaluations& operator-=(const DeviceEvaluations& o) { evals -= o.evals; return *this; }
   DeviceEvaluations& operator*=(const DeviceEvaluations& o) { evals *= o.evals; return *this; }
+  DeviceEvaluations& operator/=(const DeviceEvaluations& o) { evals /= o.evals; return *this; }
 };
 // DensePolynomial::evaluate_over_domain (polynomial/univariate/mod.rs:305-360) for coefficients already on the device:
 // zero-extension and transform in place; at most size/4 coefficients take the degree-aware path (radix2/mod.rs:141).

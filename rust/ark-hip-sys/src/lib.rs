@@ -131,6 +131,9 @@ extern "C" {
     pub fn ark_hip_fr_add_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
     pub fn ark_hip_fr_sub_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
     pub fn ark_hip_fr_neg_device(field: c_int, d_a: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    /// `r[i] = a[i] / b[i]`; a zero divisor gives zero (as `ark_ff::batch_inversion` leaves zeros in place).
+    pub fn ark_hip_fr_div_device(field: c_int, d_a: *const c_void, d_b: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
+    pub fn ark_hip_fr_inverse_device(field: c_int, d_a: *const c_void, d_r: *mut c_void, n: usize) -> c_int;
     /// `r[i] = a[i] * k`, `k`: one Montgomery element in host memory (read before the call returns).
     pub fn ark_hip_fr_scale_device(field: c_int, d_a: *const c_void, k: *const u64, d_r: *mut c_void, n: usize) -> c_int;
     pub fn ark_hip_fft_in_place_degree_aware_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void,

@@ -19,7 +19,7 @@ use ark_poly::domain::{EvaluationDomain, Radix2EvaluationDomain};
 use ark_std::vec::Vec;
 use core::ffi::{c_int, c_void};
 use core::marker::PhantomData;
-use core::ops::{AddAssign, MulAssign, SubAssign};
+use core::ops::{AddAssign, DivAssign, MulAssign, SubAssign};
 
 /// Why a device operation did not happen; the data a `DeviceVec` holds is unchanged when an `Err` comes back.
 #[derive(Debug, Clone, Copy, PartialEq, Eq)]
@@ -129,6 +129,16 @@ impl<F: FftField> DeviceVec<F> {
         self.same_len(other)?;
         rc(unsafe { sys::ark_hip_fr_mul_device(self.field, self.ptr, other.ptr, self.ptr, self.len) })
     }
+    /// `Evaluations /= &Evaluations` (mod.rs:153-163): a zero divisor gives zero, as the reference's `batch_inversion` leaves
+    /// zeros in place and `div_assign` multiplies by them
+    pub fn div_assign_pointwise(&mut self, other: &Self) -> Result<(), DeviceError> {
+        self.same_len(other)?;
+        rc(unsafe { sys::ark_hip_fr_div_device(self.field, self.ptr, other.ptr, self.ptr, self.len) })
+    }
+    /// `ark_ff::batch_inversion` on the device (zeros stay zero)
+    pub fn batch_inverse(&mut self) -> Result<(), DeviceError> {
+        rc(unsafe { sys::ark_hip_fr_inverse_device(self.field, self.ptr, self.ptr, self.len) })
+    }
     /// every element times `k` (`&DensePolynomial * F`, dense.rs:604-622)
     pub fn scale(&mut self, k: &F) -> Result<(), DeviceError> {
         let kl = sys::limbs(k);
@@ -226,5 +236,11 @@ impl<'a, F: FftField> MulAssign<&'a DeviceEvaluations<F>> for DeviceEvaluations<
     fn mul_assign(&mut self, other: &'a DeviceEvaluations<F>) {
         self.same_domain(other);
         self.evals.mul_assign_pointwise(&other.evals).expect("ark-hip: pointwise mul on the device");
+    }
+}
+impl<'a, F: FftField> DivAssign<&'a DeviceEvaluations<F>> for DeviceEvaluations<F> {
+    fn div_assign(&mut self, other: &'a DeviceEvaluations<F>) {
+        self.same_domain(other);
+        self.evals.div_assign_pointwise(&other.evals).expect("ark-hip: pointwise division on the device");
     }
 }

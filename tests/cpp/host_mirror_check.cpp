@@ -166,6 +166,15 @@ void check_device_chain(const char* name, unsigned log_n) {
   DeviceEvaluations<FIELD> ea_dev{std::move(keep_a), *dom};
   da -= ea_dev;
   auto e_dev = da.evals.clone();
+  {  // Evaluations /= Evaluations against the oracle's inversion (mod.rs:153-163)
+    auto q = e_dev.clone();
+    q /= db.evals;
+    std::vector<Fr> inv(n), want(n);
+    ark_oracle_field_op(FIELD, 6, u(eb), nullptr, u(inv), n);
+    ark_oracle_field_op(FIELD, 2, u(e), u(inv), u(want), n);
+    auto got_q = q.to_vec();
+    EXPECT(std::memcmp(got_q.data(), want.data(), n * 32) == 0, "pointwise division on the device == oracle");
+  }
   auto coeffs = std::move(da).interpolate();
   auto got_e = e_dev.to_vec();
   EXPECT(std::memcmp(got_e.data(), e.data(), n * 32) == 0, "pointwise chain on the device == oracle");

@@ -49,6 +49,14 @@ def test_pointwise_ops_match_the_oracle(fname, n):
         assert np.array_equal(m.to_host().reshape(-1), O.field_op(fid, "mul", a, b))
         assert np.array_equal(ng.to_host().reshape(-1), O.field_op(fid, "neg", a))
         assert np.array_equal(sc.to_host().reshape(-1), O.field_op(fid, "mul", a, np.tile(k, (n, 1))))
+    if n:
+        q = da.clone()
+        q /= db                                                                     # b[0] = 0 (n > 3): the quotient there is zero
+        binv = O.field_op(fid, "inv", b).reshape(-1, 4)
+        zero_rows = ~b.any(axis=1)
+        binv[zero_rows] = 0
+        assert np.array_equal(q.to_host().reshape(-1), O.field_op(fid, "mul", a, binv))
+        assert np.array_equal(db.clone().batch_inverse().to_host(), binv)
     assert np.array_equal(da.to_host(), a) and np.array_equal(db.to_host(), b)     # operands untouched
     with pytest.raises(ValueError):
         da += A.DeviceVec(fname, n + 1)

@@ -223,13 +223,14 @@ def test_device_vec_closes_the_transform_chain():
                    "pub fn evaluate_over_domain(mut self, domain: Radix2EvaluationDomain<F>)",
                    "pub struct DeviceEvaluations<F: FftField>", "pub fn interpolate(mut self)",
                    "impl<'a, F: FftField> MulAssign<&'a DeviceEvaluations<F>>", "impl<'a, F: FftField> AddAssign<&'a DeviceEvaluations<F>>",
-                   "impl<'a, F: FftField> SubAssign<&'a DeviceEvaluations<F>>", "impl<F: FftField> Drop for DeviceVec<F>"):
+                   "impl<'a, F: FftField> SubAssign<&'a DeviceEvaluations<F>>", "impl<'a, F: FftField> DivAssign<&'a DeviceEvaluations<F>>",
+                   "impl<F: FftField> Drop for DeviceVec<F>"):
         assert needle in dev, needle
     decl = _c_decls()
     used = set(re.findall(r"sys::(ark_hip_\w+)\(", dev))
     assert {"ark_hip_malloc", "ark_hip_free", "ark_hip_memcpy_h2d", "ark_hip_memcpy_d2h", "ark_hip_memcpy_d2d",
             "ark_hip_memset_device", "ark_hip_fr_add_device", "ark_hip_fr_sub_device", "ark_hip_fr_mul_device",
-            "ark_hip_fr_scale_device", "ark_hip_fr_neg_device", "ark_hip_fft_in_place_degree_aware_device",
+            "ark_hip_fr_scale_device", "ark_hip_fr_neg_device", "ark_hip_fr_div_device", "ark_hip_fr_inverse_device", "ark_hip_fft_in_place_degree_aware_device",
             "ark_hip_ifft_in_place_device"} <= used
     sys_rs = open(os.path.join(ROOT, "rust", "ark-hip-sys", "src", "lib.rs")).read()
     for name in used:
