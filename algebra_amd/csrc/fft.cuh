@@ -80,6 +80,8 @@ struct FftPassArgs {
   const u32* post_lo;  // last pass: out[pos] *= post_hi[pos >> 10] * post_lo[pos & 1023]  (nullable)
   const u32* post_hi;
   const u32* post_const;  // last pass: out *= const (nullable; used when post tables are absent)
+  const u32* pre_full;    // round 5: the expanded tables h^pos (pre) / c h^-pos (post), one entry per position (nullable): one
+  const u32* post_full;   // product per element instead of two, for 32 more bytes read -- the saturated kernel only
 };
 
 // element <-> two 16-byte LDS planes
@@ -155,7 +157,11 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
         const size_t spos = a.zskip ? (pos & (((size_t)1 << (k - a.zskip)) - 1)) : pos;
         if (a.pre_lo) {
           F x = fft_unpack<F>(v0[it], v1[it]);
-          F pw = F::mul(F::load(a.pre_hi + (spos >> PW_LO_BITS) * F::N),
+          F pw;
+          if (a.pre_full)
+            pw = F::load(a.pre_full + spos * F::N);
+          else
+            pw = F::mul(F::load(a.pre_hi + (spos >> PW_LO_BITS) * F::N),
                         F::load(a.pre_lo + (spos & ((1u << PW_LO_BITS) - 1)) * F::N));
           x = F::mul(x, pw);
           fft_pack<F>(x, v0[it], v1[it]);
@@ -353,7 +359,9 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
         if (a.post_lo || a.post_const) {
           F x = fft_unpack<F>(v0, v1);
           F pw;
-          if (a.post_lo)
+          if (a.post_full)
+            pw = F::load(a.post_full + opos * F::N);
+          else if (a.post_lo)
             pw = F::mul(F::load(a.post_hi + (opos >> PW_LO_BITS) * F::N),
                         F::load(a.post_lo + (opos & ((1u << PW_LO_BITS) - 1)) * F::N));
           else
@@ -952,6 +960,11 @@ static inline bool fft_lazy_env() {
   static const bool v = getenv("ARK_HIP_FFT_LAZY") && getenv("ARK_HIP_FFT_LAZY")[0] == '1';
   return v;
 }
+// ARK_HIP_FFT_FULL_POWERS=0: coset scaling from the two factor tables (two products per element; the round-4 path; A/B only)
+static inline bool fft_full_powers_env() {
+  static const bool v = [] { const char* e = getenv("ARK_HIP_FFT_FULL_POWERS"); return !(e && e[0] == '0'); }();
+  return v;
+}
 // ARK_HIP_FFT_COMPACT=0: every stage reads the size-n table strided (the round-4 access pattern; A/B only)
 static inline bool fft_compact_env() {
   static const bool v = [] { const char* e = getenv("ARK_HIP_FFT_COMPACT"); return !(e && e[0] == '0'); }();
@@ -1074,8 +1087,11 @@ int fft_get_roots(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
 // The power-table cache is bounded (a caller cycling through offsets must not grow it for ever).  Eviction happens
 // only here, BEFORE a transform looks anything up: a transform takes at most two entries (pre + post), so the pointers
 // it has fetched are never freed under it.
+static constexpr size_t FFT_POWERS_BUDGET = (size_t)8 << 30;   // expanded power tables are n x 32 B each
 static inline int fft_powers_make_room(FftWorkspace& ws) {
-  if (ws.powers.size() + 2 <= 64) return 0;
+  size_t bytes = 0;
+  for (auto& kv : ws.powers) bytes += kv.second.cap;
+  if (ws.powers.size() + 2 <= 64 && bytes <= FFT_POWERS_BUDGET) return 0;
   ARK_HIP_TRY(hipDeviceSynchronize());  // transforms in flight on any stream may still read the tables
   for (auto& kv : ws.powers) kv.second.release();
   ws.powers.clear();
@@ -1086,9 +1102,11 @@ static inline int fft_powers_make_room(FftWorkspace& ws) {
 // constant `base4`, resident and cached.  base4 / mul4 are host pointers.
 // form29: BOTH factors carry 2^261 instead of R (the carry-free kernel multiplies them with its own product, which divides
 // by 2^261 once), and so does a single constant.
+// full (optional out): the expanded table full[i] = hi[i >> 10] * lo[i & 1023], i < 2^k -- built behind the two factor
+// tables for the saturated kernel when 2^k x 32 B is worth a cache slot (k >= 12, at most a quarter of the budget)
 template <class FP>
 int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_t* mul4, hipStream_t stream,
-                   const u32** lo, const u32** hi, bool form29 = false) {
+                   const u32** lo, const u32** hi, bool form29 = false, const u32** full = nullptr) {
   typedef Fp<FP> F;
   FftPwKey key{FP::ID, k, {base4[0], base4[1], base4[2], base4[3]}, {0, 0, 0, 0}, form29 ? 1 : 0};
   if (mul4) key.mul = {mul4[0], mul4[1], mul4[2], mul4[3]};
@@ -1096,14 +1114,16 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
   if (it == ws.powers.end()) {
     const size_t nlo = k < 0 ? 0 : ((size_t)1 << PW_LO_BITS);
     const size_t nhi = k < 0 ? 0 : (k > PW_LO_BITS ? ((size_t)1 << (k - PW_LO_BITS)) : 1);
+    const bool want_full = !form29 && k >= 12 && fft_full_powers_env() && (((size_t)32 << k) <= FFT_POWERS_BUDGET / 4);
+    const size_t nfull = want_full ? ((size_t)1 << k) : 0;
     DevBuf buf;
     struct Guard {
       DevBuf* b;
       ~Guard() { if (b) b->release(); }
     } guard{&buf};
-    if (buf.ensure((nlo + nhi + 3) * F::BYTES)) return -3;
+    if (buf.ensure((nlo + nhi + 3 + nfull) * F::BYTES)) return -3;
     u32* base = (u32*)buf.p;
-    u32* d_c = base + (nlo + nhi) * F::N;  // [base | mul | 2^261 mod p]
+    u32* d_c = base + (nlo + nhi) * F::N;  // [base | mul | 2^261 mod p], then the expanded table
     // host-side scaling of the hi factor / the constant: m 2^261 = mont_mul(m R, 2^261 mod p)
     uint64_t hi_mul[4], cin[4];
     memcpy(cin, FP::LZ_CIN, 32);
@@ -1130,6 +1150,9 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
                          form29 ? (const u32*)(d_c + 2 * F::N) : (const u32*)nullptr, base);
       hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((nhi + 255) / 256)), dim3(256), 0, stream, d_c, (u64)nlo,
                          (u32)nhi, hi_mul_p ? (const u32*)(d_c + F::N) : (const u32*)nullptr, base + nlo * F::N);
+      if (nfull)
+        hipLaunchKernelGGL((fft_expand_table_kernel<FP>), dim3((u32)((nfull + 255) / 256)), dim3(256), 0, stream,
+                           (const u32*)base, (const u32*)(base + nlo * F::N), PW_LO_BITS, nfull, d_c + 3 * F::N);
       ARK_HIP_TRY(hipGetLastError());
     }
     ARK_HIP_TRY(hipStreamSynchronize(stream));  // base4 / mul4 are caller memory
@@ -1137,12 +1160,17 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
     guard.b = nullptr;
   }
   const u32* base = (const u32*)it->second.p;
+  if (full) *full = nullptr;
   if (k < 0) {
     *lo = base;  // the constant itself
     if (hi) *hi = nullptr;
   } else {
     *lo = base;
     *hi = base + ((size_t)1 << PW_LO_BITS) * F::N;
+    const size_t nlo2 = (size_t)1 << PW_LO_BITS, nhi2 = k > PW_LO_BITS ? ((size_t)1 << (k - PW_LO_BITS)) : 1;
+    // (an entry built for the carry-free form, or before the budget allowed it, has no expanded table: its size tells)
+    if (full && !form29 && it->second.cap >= (nlo2 + nhi2 + 3 + ((size_t)1 << k)) * F::BYTES && k >= 12 && fft_full_powers_env())
+      *full = base + (nlo2 + nhi2 + 3) * F::N;
   }
   return 0;
 }
@@ -1174,12 +1202,13 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
   // coset scaling tables (cached per offset): x[i] *= h^i on the way in; out[i] *= postc * h^-i on the way out
   if (int rc = fft_powers_make_room(ws)) return rc;
   const u32 *pre_lo = nullptr, *pre_hi = nullptr, *post_lo = nullptr, *post_hi = nullptr, *post_const = nullptr;
+  const u32 *pre_full = nullptr, *post_full = nullptr;
   if (pre4) {
-    int rc = fft_get_powers<FP>(ws, k, pre4, nullptr, stream, &pre_lo, &pre_hi, lazy29);
+    int rc = fft_get_powers<FP>(ws, k, pre4, nullptr, stream, &pre_lo, &pre_hi, lazy29, &pre_full);
     if (rc) return rc;
   }
   if (post4) {
-    int rc = fft_get_powers<FP>(ws, k, post4, postc4, stream, &post_lo, &post_hi, lazy29);
+    int rc = fft_get_powers<FP>(ws, k, post4, postc4, stream, &post_lo, &post_hi, lazy29, &post_full);
     if (rc) return rc;
   } else if (postc4) {
     int rc = fft_get_powers<FP>(ws, -1, postc4, nullptr, stream, &post_const, nullptr, lazy29);
@@ -1256,6 +1285,8 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     a.post_lo = a.last ? post_lo : nullptr;
     a.post_hi = a.last ? post_hi : nullptr;
     a.post_const = a.last ? post_const : nullptr;
+    a.pre_full = (i == 0) ? pre_full : nullptr;
+    a.post_full = a.last ? post_full : nullptr;
     const u32* src;
     u32* dst;
     if (P == 1 && zlog) { src = data; dst = tmp; }  // the compact input is read by every tile: not in place
