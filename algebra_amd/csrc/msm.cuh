@@ -125,19 +125,24 @@ struct MsmWidths {
   u32 max_bits;
   u32 count[MSM_WIDTH_CLASSES];
 };
+// chunk > 0 (the exact pass, stride 1): workgroup b owns the contiguous scalars [b chunk, (b + 1) chunk) and also leaves the
+// number of NON-ZERO ones among them in nz_counts[b] -- what the zero-scalar compaction below needs, for free
 template <class SP>
 __global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __restrict__ scalars, u32 n, u32 stride, int mont,
-                                                               u32* __restrict__ out /*[1 + MSM_WIDTH_CLASSES]*/) {
+                                                               u32* __restrict__ out /*[1 + MSM_WIDTH_CLASSES]*/,
+                                                               u32 chunk = 0, u32* __restrict__ nz_counts = nullptr) {
   typedef Fp<SP> S;
   __shared__ u32 blk[1 + MSM_WIDTH_CLASSES];
   if (threadIdx.x <= MSM_WIDTH_CLASSES) blk[threadIdx.x] = 0;
   __syncthreads();
   u32 bits = 0;
   u32 mine[MSM_WIDTH_CLASSES] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // lane 0 of the wave: its wave's counts
-  const u64 step = (u64)gridDim.x * blockDim.x;
-  const u64 rounds = (((u64)n + stride - 1) / stride + step - 1) / step;   // the same trip count for every lane (ballots below)
+  const u64 step = chunk ? (u64)blockDim.x : (u64)gridDim.x * blockDim.x;
+  const u64 first = chunk ? (u64)blockIdx.x * chunk + threadIdx.x : (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 rounds = chunk ? (u64)chunk / blockDim.x
+                           : (((u64)n + stride - 1) / stride + step - 1) / step;   // the same trip count for every lane (ballots below)
   for (u64 it = 0; it < rounds; it++) {
-    const u64 t = it * step + blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 t = it * step + first;
     int cls = -1;
     if (t * stride < n) {
       u32 v[S::N + 1];
@@ -166,6 +171,12 @@ __global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __rest
       if (mine[k]) atomicAdd(&blk[1 + k], mine[k]);
   }
   __syncthreads();
+  if (nz_counts && threadIdx.x == 0) {
+    u32 seen = 0;
+#pragma unroll
+    for (int k = 0; k < MSM_WIDTH_CLASSES; k++) seen += blk[1 + k];
+    nz_counts[blockIdx.x] = seen - blk[1];   // scalars of this chunk whose magnitude is not zero
+  }
   // one same-address atomic per wave serialises (2^18 waves: 3 ms, measured): one per workgroup and counter, and the
   // maximum only where it can still rise
   if (gridDim.x == 1) {   // the sample: one workgroup, plain stores, no zeroing beforehand
@@ -174,6 +185,68 @@ __global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __rest
     if (blk[0] > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, blk[0]);
   } else if (threadIdx.x <= MSM_WIDTH_CLASSES && blk[threadIdx.x]) {
     atomicAdd(out + threadIdx.x, blk[threadIdx.x]);
+  }
+}
+
+// ---- K0c: zero scalars leave before the sort (round 5) ----------------------------------------------------------------
+// A prover's witness is mostly zeros and ones (the bench's witness vector: 60 % zeros; a bool vector: half).  A zero scalar
+// has no digit anywhere, yet its W KEY_NONE keys are written, histogrammed and scattered like any others: the sort of a
+// 2^24-pair witness MSM moves 2^24 x 15 keys of which 7 % are live (1.35 ms of 6.5).  With the classes measured (K0's exact
+// pass: the number of zero scalars is known on the host, and each of its chunks has left its non-zero count), the non-zero
+// scalars are copied out in order with their indices, the pipeline runs on n' = n - zeros scalars, and the sorted entries
+// are mapped back to base indices before the accumulate kernels read them.  Same magnitude function as K0 and K1: "zero"
+// is s = 0 (mod r); a scalar out of range counts as zero here too and raises the same flag K1 would have raised.
+template <class SP>
+__global__ void __launch_bounds__(1024) msm_compact_scalars_kernel(const u32* __restrict__ scalars, u32 n, int mont, u32 chunk,
+                                                                   const u32* __restrict__ chunk_off, u32* __restrict__ err,
+                                                                   u32* __restrict__ out_scalars, u32* __restrict__ out_idx) {
+  typedef Fp<SP> S;
+  __shared__ u32 wave_cnt[16];
+  __shared__ u32 run_s;
+  if (threadIdx.x == 0) run_s = chunk_off[blockIdx.x];
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 rounds = chunk / blockDim.x;
+  for (u32 it = 0; it < rounds; it++) {
+    const u64 i = (u64)blockIdx.x * chunk + (u64)it * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+      u32 v[S::N + 1];
+      (void)msm_scalar_magnitude<SP>(scalars, (u32)i, mont, v, err);
+      u32 any = 0;
+#pragma unroll
+      for (int k = 0; k < S::N; k++) any |= v[k];
+      keep = any != 0;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = run_s;
+    for (u32 w = 0; w < wave; w++) before += wave_cnt[w];
+    if (keep) {
+      const u32 pos = before + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      const uint4* src = (const uint4*)(scalars + (size_t)i * S::N);
+      uint4* dst = (uint4*)(out_scalars + (size_t)pos * S::N);
+      dst[0] = src[0];
+      dst[1] = src[1];
+      out_idx[pos] = (u32)i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u32 tot = 0;
+      for (u32 w = 0; w < (blockDim.x >> 6); w++) tot += wave_cnt[w];
+      run_s += tot;
+    }
+    __syncthreads();
+  }
+}
+// sorted entries (sign bit | index into the compacted scalars) -> (sign bit | base index); *total = number of live entries
+static __global__ void __launch_bounds__(256) msm_remap_sorted_kernel(u32* __restrict__ sorted, const u32* __restrict__ total,
+                                                                      const u32* __restrict__ idx) {
+  const u32 n = *total;
+  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const u32 e = sorted[j];
+    sorted[j] = (e & 0x80000000u) | idx[e & 0x7fffffffu];
   }
 }
 
@@ -1449,11 +1522,13 @@ struct MsmWorkspace {
   hipStream_t side = nullptr;
   hipEvent_t grp_ev[2] = {nullptr, nullptr};
   u32* probe_host = nullptr;   // pinned word the width probe reads back into (a pageable target costs a staged copy)
+  DevBuf nzcnt, cscal, cidx;   // zero-scalar compaction (K0c): per-chunk non-zero counts + their scan, the compacted scalars, their indices
   bool probe_allowed = true;   // set per call by the C ABI: the *_async entries must not wait for the lane's stream to drain
   void release() {
     if (probe_host) (void)hipHostFree(probe_host);
     probe_host = nullptr;
     hctr.release(); hlist.release(); hitems.release(); hpart.release(); hfinal.release();
+    nzcnt.release(); cscal.release(); cidx.release();
     keys.release(); part.release(); thist.release(); toff.release(); sorted.release();
     offsets.release(); sums.release();
     order.release(); ohist.release(); ooff.release(); probe.release(); big.release(); parts.release();
@@ -1531,6 +1606,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   int plan_bits = sbytes ? sbits + 1 : C::S::BITS;
   MsmWidths widths{};
   bool have_widths = false;
+  u32 nz_chunk = 0, nz_blocks = 0;   // the exact probe's chunks (K0c)
+  bool measured_exact = false;
   if (!sbytes && !piece && n >= ((size_t)1 << 19)) {
     static const bool probe_on = [] {
       const char* e = getenv("ARK_HIP_MSM_PROBE");
@@ -1549,6 +1626,14 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
         u32 blocks = cnt <= 8192 ? 1u : (cnt + 1023) / 1024;
         if (blocks > 1024) blocks = 1024;
         if (blocks > 1) ARK_HIP_TRY(hipMemsetAsync(ws.probe.p, 0, PW, stream));
+        if (stride == 1 && blocks > 1) {
+          // the exact pass in contiguous chunks, one per workgroup, each leaving its non-zero count (K0c)
+          nz_chunk = (u32)(((n + blocks - 1) / blocks + 1023) / 1024 * 1024);
+          nz_blocks = (u32)((n + nz_chunk - 1) / nz_chunk);
+          if (ws.nzcnt.ensure((size_t)(2 * nz_blocks + 2) * 4)) return -3;
+          hipLaunchKernelGGL((msm_scalar_bits_kernel<typename C::S>), dim3(nz_blocks), dim3(1024), 0, stream,
+                             (const u32*)d_scalars, (u32)n, stride, scalars_mont, (u32*)ws.probe.p, nz_chunk, (u32*)ws.nzcnt.p);
+        } else
         hipLaunchKernelGGL((msm_scalar_bits_kernel<typename C::S>), dim3(blocks), dim3(1024), 0, stream,
                            (const u32*)d_scalars, (u32)n, stride, scalars_mont, (u32*)ws.probe.p);
         ARK_HIP_TRY(hipMemcpyAsync(ws.probe_host, ws.probe.p, PW, hipMemcpyDeviceToHost, stream));
@@ -1562,6 +1647,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
       if (int rc = measure((u32)(n / 4096), &sample)) return rc;
       if (msm_widths_skewed(sample)) {
         if (int rc = measure(1u, &widths)) return rc;
+        measured_exact = nz_blocks > 1;
         if (!prepared) {
           have_widths = true;
         } else if (widths.max_bits <= 48) {   // (u32: 8.9 ms prepared, 6.8 plain; u64: 11.0 prepared, 12.4 plain -- at 2^24)
@@ -1579,6 +1665,25 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                      : piece  ? *piece->plan
                      : have_widths ? msm_plan_for_widths(n, C::S::BITS, msm_mul_cost(C::ID), C::LAZY_A, widths)
                                    : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A);
+  // K0c: a quarter or more of the scalars zero (known exactly from the probe's class 0) -> they leave before the sort.
+  // From here on `n` is the number of scalars the pipeline carries; base indices come back through ws.cidx after the sort.
+  const size_t n_all = n;
+  const void* const d_scalars_all = d_scalars;
+  bool compacted = false;
+  if (measured_exact && !sbytes && !piece) {
+    static const bool compact_env = [] { const char* e = getenv("ARK_HIP_MSM_COMPACT"); return !(e && e[0] == '0'); }();
+    const size_t zeros = widths.count[0];
+    // what the compaction saves grows with zeros x windows (the keys that are never written, counted and scattered), what it
+    // costs with n (one more pass over the scalars): witness-like 2^24 (60 % zeros, 15 windows) 6.52 -> 5.90 ms, a bool vector
+    // (half zeros, ONE window) 3.22 -> 3.32 -- so: at least a quarter zeros and zeros x W >= 3 n (profiles/r5_zero_compaction.txt)
+    if (compact_env && zeros * 4 >= n && zeros < n && zeros * (size_t)pl.W >= 3 * n) {
+      const size_t nz = n - zeros;
+      if (ws.cscal.ensure(nz * 32) || ws.cidx.ensure(nz * 4)) return -3;
+      compacted = true;
+      n = nz;
+      d_scalars = ws.cscal.p;
+    }
+  }
   const int c = pl.c, W = pl.W;
   const size_t nb = pl.nb;                      // sort slots
   const size_t nbk = pl.nbuckets();             // accumulated buckets
@@ -1690,6 +1795,14 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     return -3;
   if (pl.shared && ws.hfinal.ensure(max_heavy * Pt::BYTES)) return -3;
   ARK_HIP_TRY(hipMemsetAsync(ws.hctr.p, 0, 64, stream));  // per window group: [chunk items, heavy runs, threshold, -]; [3]: scalar-range error flag; [8 + g]: super-buckets of group g left to the sliced pass B
+  if (compacted) {
+    u32* const cnt = (u32*)ws.nzcnt.p;
+    u32* const off = cnt + nz_blocks + 1;
+    scan_exclusive(cnt, nz_blocks, nullptr, off, stream);   // (nz_blocks <= 1024: the one-workgroup scan)
+    hipLaunchKernelGGL((msm_compact_scalars_kernel<typename C::S>), dim3(nz_blocks), dim3(1024), 0, stream,
+                       (const u32*)d_scalars_all, (u32)n_all, scalars_mont, nz_chunk, (const u32*)off, (u32*)ws.hctr.p + 3,
+                       (u32*)ws.cscal.p, (u32*)ws.cidx.p);
+  }
   const u32 nblk = (u32)((n + 255) / 256);
   if (sbytes) {
     const u64 vmask = sbits >= 64 ? ~0ull : ((1ull << sbits) - 1ull);
@@ -1857,6 +1970,9 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                          ((size_t)8 << LB) + 4096, st, G.part, G.toff, ntiles, LB, G.big_count, G.big, bigcnt, cursor, G.offsets,
                          G.sorted);
     }
+    if (compacted)   // sorted entries carry indices into the compacted scalars: back to base indices before anyone gathers
+      hipLaunchKernelGGL(msm_remap_sorted_kernel, dim3(2048), dim3(256), 0, st, G.sorted, (const u32*)(G.offsets + G.nslots),
+                         (const u32*)ws.cidx.p);
     int shift = 0;  // class width 2^shift so that the mean load falls around class 32..63
     while ((mean_load >> shift) >= 64) shift++;
     const u32 noblk_g = (u32)((G.nbk_g + ORDER_TILE - 1) / ORDER_TILE);

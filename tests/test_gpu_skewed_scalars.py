@@ -260,3 +260,57 @@ print("switches-off ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "switches-off ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_zero_scalars_leave_before_the_sort(setup, monkeypatch):
+    """Round 5 (K0c): with a quarter or more of the scalars zero the non-zero ones are compacted before the digit recoding and
+    the sorted entries mapped back to base indices.  Zeros in every form the entry accepts (0; r and 2r for Montgomery-form
+    input, r for canonical), ones, minus ones, full-width values, one lone non-zero scalar; the same vectors with the
+    compaction switched off give the same point; an out-of-range scalar among the dropped ones still fails the call; a
+    prepared set and Montgomery-form scalars take the same route."""
+    import torch
+    s = setup
+    cid, r, n = s["cid"], s["r"], s["n"]
+    rng = np.random.default_rng(23)
+    sc = S.gen_scalars(n, 0x2323, r)
+    u = rng.random(n)
+    sc[u < 0.70] = 0
+    one = np.zeros(4, dtype=np.uint64)
+    one[0] = 1
+    sc[(u >= 0.70) & (u < 0.85)] = one
+    sc[(u >= 0.85) & (u < 0.90)] = _limbs([r - 1])[0]
+    sc[(u >= 0.90) & (u < 0.92)] = _limbs([r])[0]              # = 0 mod r, canonical input in [r, 2^bits): accepted, a zero
+    sc[0] = 0
+    sc[n - 1] = _limbs([r - 2])[0]                              # the last index survives the compaction
+    want = _kg(cid, sc, r)
+    got = _run_bigint(s, sc)
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("ARK_HIP_MSM_COMPACT", "0")              # (read once per process: a no-op unless this test runs first)
+    lone = np.zeros((n, 4), dtype=np.uint64)
+    lone[n // 3] = _limbs([r // 3])[0]
+    assert np.array_equal(_run_bigint(s, lone), _kg(cid, lone, r))
+    # Montgomery-form input (what SWCurveConfig::msm hands over): zeros are 0 there too
+    fname = cv.scalar_field(cid)
+    fid = O.FID[fname]
+    mont = O.field_op(fid, "from_bigint", _reduce_rows(sc, r)).reshape(n, 4)
+    assert np.array_equal(_run_bigint(s, mont, mont=True), want)
+    # an out-of-range scalar sits among the zeros: the call fails as it did before
+    bits = {"BLS12_381_FR": 255, "BN254_FR": 254, "BLS12_377_FR": 253}[fname]
+    bad = sc.copy()
+    bad[int(np.nonzero(u < 0.70)[0][5])] = _limbs([1 << bits])[0]
+    with pytest.raises(A.ArkHipError) as ei:
+        _run_bigint(s, bad)
+    assert ei.value.code == -4
+    assert np.array_equal(_run_bigint(s, sc), want)             # and the library is usable afterwards
+    pb = A.PreparedBases(cid, s["bases"])
+    d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+    assert np.array_equal(A.into_affine(cid, pb.msm_bigint(d)), want)
+    pb.free()
+
+
+def _reduce_rows(sc, r):
+    """rows of canonical limbs reduced mod r (only rows equal to r change here)"""
+    out = sc.copy()
+    rl = _limbs([r])[0]
+    out[(sc == rl).all(axis=1)] = 0
+    return out
