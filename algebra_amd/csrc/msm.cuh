@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __rest
 // has no digit anywhere, yet its W KEY_NONE keys are written, histogrammed and scattered like any others: the sort of a
 // 2^24-pair witness MSM moves 2^24 x 15 keys of which 7 % are live (1.35 ms of 6.5).  With the classes measured (K0's exact
 // pass: the number of zero scalars is known on the host, and each of its chunks has left its non-zero count), the non-zero
-// scalars are copied out in order with their indices, the pipeline runs on n' = n - zeros scalars, and the sorted entries
-// are mapped back to base indices before the accumulate kernels read them.  Same magnitude function as K0 and K1: "zero"
+// scalars are copied out in order with their indices, the pipeline runs on n' = n - zeros scalars, and the sort's first
+// scatter (msm_part_scatter_kernel) writes base indices into its pairs -- a coalesced read of the index list there.  Same magnitude function as K0 and K1: "zero"
 // is s = 0 (mod r); a scalar out of range counts as zero here too and raises the same flag K1 would have raised.
 template <class SP>
 __global__ void __launch_bounds__(1024) msm_compact_scalars_kernel(const u32* __restrict__ scalars, u32 n, int mont, u32 chunk,
@@ -240,16 +240,6 @@ __global__ void __launch_bounds__(1024) msm_compact_scalars_kernel(const u32* __
     __syncthreads();
   }
 }
-// sorted entries (sign bit | index into the compacted scalars) -> (sign bit | base index); *total = number of live entries
-static __global__ void __launch_bounds__(256) msm_remap_sorted_kernel(u32* __restrict__ sorted, const u32* __restrict__ total,
-                                                                      const u32* __restrict__ idx) {
-  const u32 n = *total;
-  for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const u32 e = sorted[j];
-    sorted[j] = (e & 0x80000000u) | idx[e & 0x7fffffffu];
-  }
-}
-
 // The same classes for HOST scalars, estimated from a spread sample of about 1024 of them (the streamed entries plan
 // before the first piece is uploaded and cannot wait for a device pass over all scalars): counts scaled to n, max_bits
 // = the field's -- an estimate may choose the window size, never the number of windows.
@@ -1958,7 +1948,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     scan_exclusive(G.thist, nthist_g, G.sums, G.toff, st);
     if (mark && timing) ARK_HIP_TRY(hipEventRecord(job.ev[2], st));
     hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(ntiles, G.Wg), dim3(1024), lds_a, st, G.keys, (u32)n, HB, LB, ntiles,
-                       ptile, G.toff, G.part);
+                       ptile, G.toff, G.part, compacted ? (const u32*)ws.cidx.p : (const u32*)nullptr);
     hipLaunchKernelGGL(msm_part_finish_kernel, dim3(nsuper_g), dim3(1024), lds_b, st, G.part, G.toff, ntiles, LB, nsuper_g,
                        stage_cap, big_on ? PART_BIG : 0u, G.big_count, G.big, G.offsets, G.sorted);
     if (big_on) {
@@ -1970,9 +1960,6 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
                          ((size_t)8 << LB) + 4096, st, G.part, G.toff, ntiles, LB, G.big_count, G.big, bigcnt, cursor, G.offsets,
                          G.sorted);
     }
-    if (compacted)   // sorted entries carry indices into the compacted scalars: back to base indices before anyone gathers
-      hipLaunchKernelGGL(msm_remap_sorted_kernel, dim3(2048), dim3(256), 0, st, G.sorted, (const u32*)(G.offsets + G.nslots),
-                         (const u32*)ws.cidx.p);
     int shift = 0;  // class width 2^shift so that the mean load falls around class 32..63
     while ((mean_load >> shift) >= 64) shift++;
     const u32 noblk_g = (u32)((G.nbk_g + ORDER_TILE - 1) / ORDER_TILE);

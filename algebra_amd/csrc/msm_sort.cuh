@@ -145,7 +145,10 @@ static __global__ void __launch_bounds__(256) msm_part_hist_kernel(const u32* __
 static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const u32* __restrict__ keys, u32 n, int HB,
                                                                        int LB, u32 ntiles, u32 tile,
                                                                        const u32* __restrict__ tile_off,
-                                                                       uint2* __restrict__ part) {
+                                                                       uint2* __restrict__ part,
+                                                                       const u32* __restrict__ point_idx = nullptr) {
+  // point_idx (nullable): key position i stands for base point_idx[i] (zero scalars compacted away, msm.cuh K0c): the pair
+  // carries the base index from here on -- a coalesced read here instead of a random gather per sorted entry later
   extern __shared__ u32 part_lds[];
   const u32 nbins = 1u << HB;
   u32* cnt = part_lds;                       // per-bin count, then local cursor
@@ -161,11 +164,12 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
   for (u32 b = threadIdx.x; b < nbins; b += blockDim.x) cnt[b] = 0;
   // the lane's keys stay in registers for both sweeps (tile <= PART_SCATTER_KEYS * blockDim.x); all loads are issued
   // before the first LDS atomic waits
-  u32 key[PART_SCATTER_KEYS];
+  u32 key[PART_SCATTER_KEYS], pidx[PART_SCATTER_KEYS];
 #pragma unroll
   for (int b = 0; b < PART_SCATTER_KEYS; b++) {
     const u32 i = lo + (u32)b * blockDim.x + threadIdx.x;
     key[b] = i < hi ? keys[base + i] : PART_KEY_NONE;
+    pidx[b] = (point_idx && i < hi) ? point_idx[i] : i;
   }
   __syncthreads();
 #pragma unroll
@@ -203,7 +207,7 @@ static __global__ void __launch_bounds__(1024, 8) msm_part_scatter_kernel(const 
   for (int b = 0; b < PART_SCATTER_KEYS; b++) {
     if (key[b] != PART_KEY_NONE) {
       const u32 pos = atomicAdd(&cnt[key[b] & hmask], 1u);
-      stage[pos] = make_uint2(key[b], lo + (u32)b * blockDim.x + threadIdx.x);   // full key kept: the bin is re-derived below
+      stage[pos] = make_uint2(key[b], pidx[b]);   // full key kept: the bin is re-derived below
     }
   }
   __syncthreads();
