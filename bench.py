@@ -303,8 +303,107 @@ def main():
     exact = bool(np.array_equal(A.into_affine(cid, result), want)) if rank == 0 else None
     extras = not args.no_extras
 
-    # ---- N > 1: the two other scalings of the same path, each labelled (never `value`) ---------------------------
+    # ---- the line is assembled by a closure over the legs' results, so that a watchdog can print what is there ------
+    prepared = pipelined = trait = config4 = others = fft = fft_sharded = cpu = None
     side_legs = {}
+
+    def build_line():
+        acc_ms = float(phases[3])
+        W = int(phases[7])
+        cbits = int(phases[6])
+        achieved = 128.0 * n / (acc_ms * 1e-3) / 1e9  # algorithmic bytes: 96 B base + 32 B scalar per pair
+        # mixed additions actually executed by the accumulate kernel: one per (scalar, window) with a non-zero digit,
+        # minus the first point of every non-empty bucket (a copy, not an addition)
+        entries = n * W * (1.0 - 2.0 ** -cbits)
+        nbuckets = W * (1 << (cbits - 1))
+        madds = entries - nbuckets * (1.0 - np.exp(-entries / nbuckets))
+        mads_per_add = MADS_PER_MIXED_ADD["lazy28" if LAZY else "saturated"]
+        mads_per_s = madds * mads_per_add / (acc_ms * 1e-3)
+        traffic, traffic_src = pmc_traffic(ACC_KERNEL, log_local)
+        out = {
+            "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (int(round(np.log2(n_total))), "" if world == 1 else
+                                                             ", ONE job split over %d GPUs" % world),
+            "value": n_total * args.steps / elapsed,
+            "unit": "scalar-muls/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": headline_scaling,
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "BLS12-381 G1 MSM, one job of 2^%d random bases/scalars, device resident, plain entry "
+                                   "(raw bases, nothing precomputed: VariableBaseMSM::msm_bigint)%s"
+                                   % (int(round(np.log2(n_total))), "" if world == 1 else
+                                      " -- BASELINE config 4, split by base range over %d GPUs (strong scaling: the total is "
+                                      "fixed; one-GPU reference = `config4_strong_2_26.value` of the --gpus 1 line)" % world),
+                       "arithmetic": "exact integers on v_mad_u64_u32: Montgomery Fp384, bucket accumulation on %s, "
+                                     "everything else on saturated 32-bit limbs" %
+                                     ("carry-free 28-bit limbs" if LAZY else "saturated 32-bit limbs"),
+                       "curve": CURVE, "window_bits": cbits, "windows": W,
+                       "pairs_per_gpu": n, "sharding": "base-range, %d rank(s), partials all-gathered" % world,
+                       "exchange": exchange},
+            "bit_exact_vs_kG": exact,
+            "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
+                          "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},
+            "roofline": {"bound": "hbm", "kernel": ACC_KERNEL,
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "alu": {"what": "v_mad_u64_u32 lane-ops/s issued by the mixed additions the accumulate kernel "
+                                         "executes (%d per addition, %s) vs the instruction's measured issue rate on "
+                                         "this chip" % (mads_per_add, "carry-free 28-bit limbs: 6 products, 2 squares, "
+                                                        "one two-product sum" if LAZY else
+                                                        "saturated 32-bit limbs: 8 products + one two-product sum"),
+                                 "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
+                                 "frac": mads_per_s / MAD_U64_U32_PER_S,
+                                 "two_waves": {"what": "the same instruction's issue rate at the kernel's occupancy (two "
+                                                       "waves per SIMD, 219 VGPRs)",
+                                               "peak": MAD_U64_U32_PER_S_TWO_WAVES,
+                                               "frac": mads_per_s / MAD_U64_U32_PER_S_TWO_WAVES},
+                                 "peak_source": "profiles/r3_issue_rates.txt: v_mad_u64_u32, four independent chains per "
+                                                "lane -- 34.96e12 lane-ops/s at eight waves per SIMD (the best rate "
+                                                "measured on this chip: `peak`), 26.6e12/s at two waves"},
+                         "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
+            "cpu_baseline": cpu,
+            "trait_surface": trait,
+            "prepared": prepared,
+            "pipelined": pipelined,
+            "config4_strong_2_26": config4 if world == 1 else "this line's `value` (N > 1: the headline IS config 4)",
+            "other_scalings": side_legs if world > 1 else None,
+            "other_configs": others,
+            "fft": fft,
+            "fft_sharded": fft_sharded,
+        }
+        return out
+
+    # N > 1: the exchange legs (RCCL inside the library: sharded MSM, sharded FFT) have only ever run on one-GPU boxes with
+    # emulated ranks -- a collective that hangs on real hardware must not cost the headline line.  Once `value` exists a
+    # watchdog prints the line with whatever legs have finished and ends the process (every rank runs its own).
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("ARK_BENCH_WATCHDOG_S", "1200"))
+
+        def show():   # rank 0, three seconds before every rank leaves: the line with whatever legs have finished
+            line = build_line()
+            line["watchdog"] = "side legs did not finish within %.0f s of the headline: line printed without them" % limit
+            print(json.dumps(line), flush=True)
+
+        def leave():  # every rank at the same moment, exit code 0 (a rank that outlives its peers dies in its collective)
+            os._exit(0)
+        if rank == 0:
+            early = threading.Timer(max(limit - 3.0, 0.0), show)
+            early.daemon = True
+            early.start()
+        watchdog = threading.Timer(limit, leave)
+        watchdog.daemon = True
+        watchdog.start()
+
+
+    # ---- N > 1: the two other scalings of the same path, each labelled (never `value`) ---------------------------
     if world > 1 and extras:
         for key, n_leg, scal, what in (
                 ("weak_2_%d_per_gpu" % log_weak, 1 << log_weak, "weak",
@@ -782,77 +881,12 @@ def main():
                          "bit-exact: %s"
                          % ("all" if ns == n else "first", int(np.log2(ns)), cpu_s, cores, os.cpu_count() or 1, cores, same)}
 
+    if watchdog is not None:
+        watchdog.cancel()
+        if rank == 0:
+            early.cancel()
     if rank == 0:
-        acc_ms = float(phases[3])
-        W = int(phases[7])
-        cbits = int(phases[6])
-        achieved = 128.0 * n / (acc_ms * 1e-3) / 1e9  # algorithmic bytes: 96 B base + 32 B scalar per pair
-        # mixed additions actually executed by the accumulate kernel: one per (scalar, window) with a non-zero digit,
-        # minus the first point of every non-empty bucket (a copy, not an addition)
-        entries = n * W * (1.0 - 2.0 ** -cbits)
-        nbuckets = W * (1 << (cbits - 1))
-        madds = entries - nbuckets * (1.0 - np.exp(-entries / nbuckets))
-        mads_per_add = MADS_PER_MIXED_ADD["lazy28" if LAZY else "saturated"]
-        mads_per_s = madds * mads_per_add / (acc_ms * 1e-3)
-        traffic, traffic_src = pmc_traffic(ACC_KERNEL, log_local)
-        out = {
-            "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (int(round(np.log2(n_total))), "" if world == 1 else
-                                                             ", ONE job split over %d GPUs" % world),
-            "value": n_total * args.steps / elapsed,
-            "unit": "scalar-muls/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True,
-            "scaling": headline_scaling,
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": "BLS12-381 G1 MSM, one job of 2^%d random bases/scalars, device resident, plain entry "
-                                   "(raw bases, nothing precomputed: VariableBaseMSM::msm_bigint)%s"
-                                   % (int(round(np.log2(n_total))), "" if world == 1 else
-                                      " -- BASELINE config 4, split by base range over %d GPUs (strong scaling: the total is "
-                                      "fixed; one-GPU reference = `config4_strong_2_26.value` of the --gpus 1 line)" % world),
-                       "arithmetic": "exact integers on v_mad_u64_u32: Montgomery Fp384, bucket accumulation on %s, "
-                                     "everything else on saturated 32-bit limbs" %
-                                     ("carry-free 28-bit limbs" if LAZY else "saturated 32-bit limbs"),
-                       "curve": CURVE, "window_bits": cbits, "windows": W,
-                       "pairs_per_gpu": n, "sharding": "base-range, %d rank(s), partials all-gathered" % world,
-                       "exchange": exchange},
-            "bit_exact_vs_kG": exact,
-            "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
-                          "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},
-            "roofline": {"bound": "hbm", "kernel": ACC_KERNEL,
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "alu": {"what": "v_mad_u64_u32 lane-ops/s issued by the mixed additions the accumulate kernel "
-                                         "executes (%d per addition, %s) vs the instruction's measured issue rate on "
-                                         "this chip" % (mads_per_add, "carry-free 28-bit limbs: 6 products, 2 squares, "
-                                                        "one two-product sum" if LAZY else
-                                                        "saturated 32-bit limbs: 8 products + one two-product sum"),
-                                 "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
-                                 "frac": mads_per_s / MAD_U64_U32_PER_S,
-                                 "two_waves": {"what": "the same instruction's issue rate at the kernel's occupancy (two "
-                                                       "waves per SIMD, 219 VGPRs)",
-                                               "peak": MAD_U64_U32_PER_S_TWO_WAVES,
-                                               "frac": mads_per_s / MAD_U64_U32_PER_S_TWO_WAVES},
-                                 "peak_source": "profiles/r3_issue_rates.txt: v_mad_u64_u32, four independent chains per "
-                                                "lane -- 34.96e12 lane-ops/s at eight waves per SIMD (the best rate "
-                                                "measured on this chip: `peak`), 26.6e12/s at two waves"},
-                         "note": "MSM is integer-ALU bound (SURVEY 8d): the HBM fraction is tiny by construction"},
-            "cpu_baseline": cpu,
-            "trait_surface": trait,
-            "prepared": prepared,
-            "pipelined": pipelined,
-            "config4_strong_2_26": config4 if world == 1 else "this line's `value` (N > 1: the headline IS config 4)",
-            "other_scalings": side_legs if world > 1 else None,
-            "other_configs": others,
-            "fft": fft,
-            "fft_sharded": fft_sharded,
-        }
-        print(json.dumps(out))
+        print(json.dumps(build_line()), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
