@@ -176,7 +176,20 @@ def main():
     L = lib()
     check(L.ark_hip_init(dev_index), "ark_hip_init")
     cid = cv.curve_id(CURVE)
+    start_guard = None
     if world > 1:
+        # nothing below is allowed to hang the driver: if the communicators, the pre-flight or the timed headline steps have
+        # not finished after ARK_BENCH_HEADLINE_WATCHDOG_S (default 900 s) the rank says why on stderr and leaves with code 3
+        import threading
+
+        def give_up():
+            sys.stderr.write("bench.py: rank %d: no headline after the watchdog's limit (a collective did not return?); "
+                             "ARK_BENCH_EXCHANGE=torch keeps the exchange in torch.distributed\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
+        start_guard = threading.Timer(float(os.environ.get("ARK_BENCH_HEADLINE_WATCHDOG_S", "900")), give_up)
+        start_guard.daemon = True
+        start_guard.start()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -192,7 +205,10 @@ def main():
             return f.item() != 0.0
         why = ""
         try:
-            ok = D.comm_init()
+            if os.environ.get("ARK_BENCH_EXCHANGE", "") == "torch":
+                ok, why = False, "ARK_BENCH_EXCHANGE=torch"
+            else:
+                ok = D.comm_init()
         except Exception as e:  # noqa: BLE001 -- the headline must survive a communicator problem
             ok, why = False, repr(e)[:120]
         if backend == "nccl" and all_ranks(ok):
@@ -302,6 +318,8 @@ def main():
     want = expected_affine(scalars_h, first)
     exact = bool(np.array_equal(A.into_affine(cid, result), want)) if rank == 0 else None
     extras = not args.no_extras
+    if start_guard is not None:
+        start_guard.cancel()
 
     # ---- the line is assembled by a closure over the legs' results, so that a watchdog can print what is there ------
     prepared = pipelined = trait = config4 = others = fft = fft_sharded = cpu = None
