@@ -120,6 +120,8 @@ SYMBOLS = {
     "ark_hip_fr_add_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_fr_sub_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_fr_neg_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_fft_group_in_place": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "ark_hip_fft_group_in_place_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "ark_hip_fr_div_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_fr_inverse_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_fr_scale_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

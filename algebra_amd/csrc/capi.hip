@@ -217,6 +217,7 @@ struct Context {
   MsmWorkspace msm[2];
   FftWorkspace fft;
   DevBuf stage_a, stage_b, stage_c;    // host-pointer entry points: device copies
+  DevBuf gfft_work, gfft_scal;         // transform over group elements: XYZZ scratch, per-position scalars
   DevBuf ring_s[2], ring_b[2];         // double-buffered scalar / base uploads of the streaming entry points
   hipEvent_t ring_free[2] = {nullptr, nullptr}, ring_up[2] = {nullptr, nullptr};
   int ring_next = 0;
@@ -418,6 +419,36 @@ int fr_scale_dispatch(int field, const void* a, const uint64_t* k4, void* r, siz
   ARK_FIELD_SWITCH(field, X);
 #undef X
 }
+bool field_is_one(int field, const uint64_t* x);
+int fft_roots_dispatch(int field, FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st, const uint32_t** out) {
+#define X(NAME) fft_roots_##NAME(ws, k, root4, st, out)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+int fft_scalars_dispatch(int field, FftWorkspace& ws, const uint64_t* base4, const uint64_t* mul4, size_t count, void* d_out,
+                         hipStream_t st) {
+#define X(NAME) fft_scalars_##NAME(ws, base4, mul4, count, d_out, st)
+  ARK_FIELD_SWITCH(field, X);
+#undef X
+}
+int gfft_run_dispatch(int curve, void* d_jac, int k, const uint32_t* roots, const uint32_t* pre, const uint32_t* post, void* work,
+                      hipStream_t st) {
+#define X(NAME) gfft_run_##NAME(d_jac, k, roots, pre, post, work, st)
+  ARK_CURVE_SWITCH(curve, X);
+#undef X
+}
+size_t gfft_work_bytes_any(int curve, int k) {
+  switch (curve) {
+#ifndef ARK_HIP_DEV
+    case ARK_HIP_BN254_G1: return gfft_work_bytes_BN254_G1(k);
+    case ARK_HIP_BLS12_377_G1: return gfft_work_bytes_BLS12_377_G1(k);
+    case ARK_HIP_BLS12_377_G2: return gfft_work_bytes_BLS12_377_G2(k);
+    case ARK_HIP_BLS12_381_G2: return gfft_work_bytes_BLS12_381_G2(k);
+#endif
+    case ARK_HIP_BLS12_381_G1: return gfft_work_bytes_BLS12_381_G1(k);
+  }
+  return 0;
+}
 int fr_div_dispatch(int field, const void* num, const void* den, void* r, size_t n, hipStream_t st) {
 #define X(NAME) fr_div_##NAME(num, den, r, n, st)
   ARK_FIELD_SWITCH(field, X);
@@ -555,6 +586,16 @@ bool host_is_one(const uint64_t* x) {
   return Fp<FP>::eq(a, Fp<FP>::one());
 }
 
+bool field_is_one(int field, const uint64_t* x) {
+  switch (field) {
+#ifndef ARK_HIP_DEV
+    case ARK_HIP_BN254_FR: return host_is_one<BN254_FR>(x);
+    case ARK_HIP_BLS12_377_FR: return host_is_one<BLS12_377_FR>(x);
+#endif
+    case ARK_HIP_BLS12_381_FR: return host_is_one<BLS12_381_FR>(x);
+  }
+  return false;
+}
 template <class FP>
 int domain_new(size_t num_coeffs, ark_hip_radix2_domain* out) {
   typedef Fp<FP> F;
@@ -2461,6 +2502,63 @@ int ark_hip_fft_axis_device(int field, void* d_data, unsigned G, size_t cols, co
   ARK_SCOPE(sc);
   if (int rc = fft_axis_dispatch(field, sc.c->fft, d_data, d_data, G, cols, root, sc.c->stream)) return rc;
   return mark_producer(sc.c);
+}
+
+// ---- transform whose coefficients are GROUP elements --------------------------------------------------------------------
+// EvaluationDomain::fft_in_place / ifft_in_place for T = Projective<P> (poly/src/domain/mod.rs:332-362 with
+// radix2/fft.rs:74-119; the reference's own use: poly/src/test.rs:57): n = dom->size Jacobian points of `curve`, whose scalar
+// field must be the domain's field, transformed in place -- forward: X_j = sum_i [(h g^j)^i] P_i; inverse:
+// P_i = [n^-1 h^-i] sum_j [g^-ij] X_j.  The caller pads with identities (z = 0) to the domain size as the reference's
+// resize does.  gfft.cuh.
+static int gfft_entry(Context* c, int curve, const ark_hip_radix2_domain* dom, void* d_jac, int inverse) {
+  const int field = CURVES[curve].scalar_field;
+  const int k = (int)dom->log_size_of_group;
+  if (k < 0 || k > 26 || dom->size != ((uint64_t)1 << k)) return ARK_HIP_ERR_ARG;
+  const size_t n = (size_t)1 << k;
+  const bool coset = !field_is_one(field, dom->offset);
+  const uint32_t* roots = nullptr;
+  if (k >= 1)
+    if (int rc = fft_roots_dispatch(field, c->fft, k, inverse ? dom->group_gen_inv : dom->group_gen, c->stream, &roots)) return rc;
+  const size_t wb = gfft_work_bytes_any(curve, k);
+  if (wb == 0) return ARK_HIP_ERR_ARG;
+  if (c->gfft_work.cap < wb || c->gfft_scal.cap < n * 32) {
+    if (int rc = sync_compute(c)) return rc;
+    if (c->gfft_work.ensure(wb) || c->gfft_scal.ensure(n * 32)) return ARK_HIP_ERR_NOMEM;
+  }
+  const uint32_t *pre = nullptr, *post = nullptr;
+  if (!inverse && coset) {        // distribute_powers(coeffs, offset)                                   fft.rs:74-79
+    if (int rc = fft_scalars_dispatch(field, c->fft, dom->offset, nullptr, n, c->gfft_scal.p, c->stream)) return rc;
+    pre = (const uint32_t*)c->gfft_scal.p;
+  }
+  if (inverse) {                  // x[i] *= size_inv * offset_inv^i  (offset_inv = 1 off a coset)         fft.rs:81-88
+    if (int rc = fft_scalars_dispatch(field, c->fft, dom->offset_inv, dom->size_inv, n, c->gfft_scal.p, c->stream)) return rc;
+    post = (const uint32_t*)c->gfft_scal.p;
+  }
+  if (int rc = gfft_run_dispatch(curve, d_jac, k, roots, pre, post, c->gfft_work.p, c->stream)) return rc;
+  return mark_producer(c);
+}
+int ark_hip_fft_group_in_place_device(int curve, const ark_hip_radix2_domain* dom, void* d_jac_points, int inverse) {
+  if (curve < 0 || curve > 4 || !dom || !d_jac_points) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  return gfft_entry(sc.c, curve, dom, d_jac_points, inverse);
+}
+int ark_hip_fft_group_in_place(int curve, const ark_hip_radix2_domain* dom, uint64_t* jac_points, int inverse) {
+  if (curve < 0 || curve > 4 || !dom || !jac_points) return ARK_HIP_ERR_ARG;
+  ARK_SCOPE(sc);
+  Context* c = sc.c;
+  const size_t bytes = (size_t)dom->size * CURVES[curve].fe_words * 3 * 8;
+  if (c->stage_a.cap < bytes) {
+    if (int rc = sync_compute(c)) return rc;
+    if (c->stage_a.ensure(bytes)) return ARK_HIP_ERR_NOMEM;
+  }
+  if (int rc = c->stager.upload(c->stage_a.p, jac_points, bytes, c->stream)) return rc;
+  if (int rc = gfft_entry(c, curve, dom, c->stage_a.p, inverse)) {
+    (void)hipStreamSynchronize(c->stream);
+    return rc;   // the device worked on its own copy: the caller's points are intact
+  }
+  ARK_HIP_TRY(hipMemcpyAsync(jac_points, c->stage_a.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 // The rest of the pointwise algebra on device-resident vectors of Fr (Evaluations +=, -=, negation; a polynomial or an

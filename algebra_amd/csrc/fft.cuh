@@ -1175,6 +1175,30 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
   return 0;
 }
 
+// out[i] = mul * base^i, i < count (mul = nullptr: 1): the per-position scalars of a transform over GROUP elements
+// (gfft.cuh: h^i before the stages of a coset transform, size_inv * h^-i after the inverse's).  base4 / mul4: host pointers.
+template <class FP>
+int fft_scalars_run(FftWorkspace& ws, const uint64_t* base4, const uint64_t* mul4, size_t count, void* d_out, hipStream_t stream) {
+  typedef Fp<FP> F;
+  if (count == 0) return 0;
+  std::lock_guard<std::mutex> lock(ws.mu);
+  if (ws.pw.ensure(2 * F::BYTES)) return -3;
+  u32* d_base = (u32*)ws.pw.p;
+  u32* d_mul = d_base + F::N;
+  ARK_HIP_TRY(hipMemcpyAsync(d_base, base4, F::BYTES, hipMemcpyHostToDevice, stream));
+  if (mul4) ARK_HIP_TRY(hipMemcpyAsync(d_mul, mul4, F::BYTES, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((count + 255) / 256)), dim3(256), 0, stream, (const u32*)d_base, (u64)1,
+                     (u32)count, mul4 ? (const u32*)d_mul : (const u32*)nullptr, (u32*)d_out);
+  ARK_HIP_TRY(hipGetLastError());
+  ARK_HIP_TRY(hipStreamSynchronize(stream));   // base4 / mul4 are caller memory; ws.pw is reused by the next call
+  return 0;
+}
+template <class FP>
+int fft_roots_run(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t stream, const u32** out) {
+  std::lock_guard<std::mutex> lock(ws.mu);
+  return fft_get_roots<FP>(ws, k, root4, stream, out);
+}
+
 // d_data: device pointer to 2^k elements (Montgomery, reference layout).
 // root4:  group_gen (forward) or group_gen_inv (inverse) of the size-2^k domain, host pointer.
 // pre4:   coset offset h (forward coset FFT) or nullptr.        x[i] *= h^i before the transform

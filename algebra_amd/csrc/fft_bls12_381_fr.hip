@@ -10,6 +10,12 @@ int fft_run_BLS12_381_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* 
 int test_field_op_BLS12_381_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
   return test_field_op_launch<Fp<BLS12_381_FR>, true>(op, a, b, r, n, s);
 }
+int fft_roots_BLS12_381_FR(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t s, const uint32_t** out) {
+  return fft_roots_run<BLS12_381_FR>(ws, k, root4, s, out);
+}
+int fft_scalars_BLS12_381_FR(FftWorkspace& ws, const uint64_t* base4, const uint64_t* mul4, size_t count, void* d_out, hipStream_t s) {
+  return fft_scalars_run<BLS12_381_FR>(ws, base4, mul4, count, d_out, s);
+}
 int fr_div_BLS12_381_FR(const void* num, const void* den, void* r, size_t n, hipStream_t s) {
   return fr_div_launch<Fp<BLS12_381_FR>>(num, den, r, n, s);
 }

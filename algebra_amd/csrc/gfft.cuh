@@ -1,0 +1,121 @@
+// Radix-2 FFT / IFFT whose COEFFICIENTS are group elements (round 5).
+//
+// Replaces, for T = Projective<P> of a served curve, the generic half of the reference's transform:
+//   poly/src/domain/mod.rs:332-362      fft_in_place<T: DomainCoeff<F>> -- T only needs  T + T,  T - T  and  T *= F
+//   poly/src/domain/radix2/fft.rs:74-119 in_order_fft / in_order_ifft_in_place (distribute_powers for cosets, the IFFT's
+//                                        x[i] *= size_inv * offset_inv^i), :190-210 butterflies, :373-380 derange
+//   poly/src/test.rs:57                 the reference's own use with G1Projective (a commitment key moved between bases)
+// T *= F on a Projective is a scalar multiplication (group.rs Mul<ScalarField>: mul_bigint of the canonical scalar), so a
+// butterfly costs two additions and one 255-bit double-and-add -- ~380 point operations: a different kernel family from the
+// field transform (fft.cuh: one product per butterfly) and from the MSM (no buckets: every butterfly has its own scalar).
+//
+// GPU organisation: log2 n decimation-in-frequency stages, one kernel launch per stage, one lane per butterfly on
+// XYZZ coordinates (bucket.rs formulas: ec.cuh) in a scratch array; the first kernel converts the caller's Jacobian points
+// (and applies the coset's h^i), the last one undoes the bit reversal (derange), applies size_inv * h^-i and converts back.
+// Latency-bound below ~2^17 butterflies per stage (a lane walks its 255 doublings alone); against the reference's CPU loop
+// -- n/2 log2 n scalar multiplications of ~80 us each -- two to three orders of magnitude at 2^10 .. 2^16.
+// Results are group elements: Projective representatives differ from the reference's, into_affine() agrees.
+#pragma once
+#include "msm.cuh"
+
+namespace arkhip {
+
+// [k] p for a Montgomery-form scalar k of the curve's scalar field (MSB-first double-and-add on XYZZ)
+template <class C>
+ARK_DEV XYZZ<typename C::F> gfft_scalar_mul(const XYZZ<typename C::F>& p, const u32* k_mont) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  typedef Fp<typename C::S> S;
+  const S kc = S::from_mont(S::load(k_mont));   // canonical integer of the field element (group.rs: into_bigint)
+  int top = -1;
+#pragma unroll
+  for (int i = 0; i < S::N; i++)
+    if (kc.l[i]) top = 32 * i + 31 - __builtin_clz(kc.l[i]);
+  Pt acc = Pt::zero();
+  if (p.is_zero()) return acc;
+  for (int b = top; b >= 0; b--) {
+    acc = xyzz_dbl<F>(acc);
+    u32 word = 0;
+#pragma unroll
+    for (int i = 0; i < S::N; i++) word = (b >> 5) == i ? kc.l[i] : word;   // (no dynamic indexing into registers)
+    if ((word >> (b & 31)) & 1u) xyzz_add<F>(acc, p);
+  }
+  return acc;
+}
+
+// Jacobian (x, y, z) -> XYZZ (x, y, z^2, z^3), identity (z = 0) -> zero; optionally times scal[i]
+template <class C>
+__global__ void __launch_bounds__(64) gfft_load_kernel(const char* __restrict__ jac, char* __restrict__ work, size_t n,
+                                                       const u32* __restrict__ scal) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const char* p = jac + i * 3 * F::FULL_BYTES;
+  const F z = F::load(p + 2 * F::FULL_BYTES);
+  Pt q = Pt::zero();
+  if (!z.is_zero()) {
+    q.x = F::load(p);
+    q.y = F::load(p + F::FULL_BYTES);
+    q.zz = F::sqr(z);
+    q.zzz = F::mul(q.zz, z);
+  }
+  if (scal) q = gfft_scalar_mul<C>(q, scal + i * 8);
+  q.store(work + i * Pt::BYTES);
+}
+
+// one DIF stage: (lo, hi) <- (lo + hi, (lo - hi) * w^(j << s)),  gap = n >> (s + 1), j = b mod gap      fft.rs:190-198, 262-293
+template <class C>
+__global__ void __launch_bounds__(64) gfft_stage_kernel(char* __restrict__ work, size_t n, size_t gap, int s,
+                                                        const u32* __restrict__ roots) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n / 2) return;
+  const size_t j = b & (gap - 1);
+  const size_t i0 = ((b - j) << 1) | j, i1 = i0 + gap;
+  Pt lo = Pt::load(work + i0 * Pt::BYTES);
+  const Pt hi = Pt::load(work + i1 * Pt::BYTES);
+  Pt dif = lo;
+  xyzz_add<F>(dif, Pt::neg(hi));
+  xyzz_add<F>(lo, hi);
+  if (j != 0) dif = gfft_scalar_mul<C>(dif, roots + (j << s) * 8);
+  lo.store(work + i0 * Pt::BYTES);
+  dif.store(work + i1 * Pt::BYTES);
+}
+
+// position i holds X[bitrev_k(i)] (derange, fft.rs:373-380): out[j] = [scal[j]] work[bitrev(j)], XYZZ -> Jacobian
+template <class C>
+__global__ void __launch_bounds__(64) gfft_store_kernel(const char* __restrict__ work, char* __restrict__ jac, size_t n, int k,
+                                                        const u32* __restrict__ scal) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const size_t i = k == 0 ? 0 : (size_t)(__brevll((unsigned long long)j) >> (64 - k));
+  Pt q = Pt::load(work + i * Pt::BYTES);
+  if (scal) q = gfft_scalar_mul<C>(q, scal + j * 8);
+  xyzz_to_jac<F>(q).store(jac + j * 3 * F::FULL_BYTES);
+}
+
+// d_jac: n = 2^k Projective points of curve C in device memory, transformed in place.
+// d_roots: w^j, j < n/2, Montgomery residues of the curve's scalar field (the field transform's own table: its first n/2
+// entries) for w = group_gen (forward) or group_gen_inv (inverse); d_pre / d_post: n scalars each or nullptr
+// (h^i before the stages; size_inv * h^-i after them); d_work: n * XYZZ::BYTES of scratch.
+template <class C>
+int gfft_run(void* d_jac, int k, const u32* d_roots, const u32* d_pre, const u32* d_post, void* d_work, hipStream_t stream) {
+  const size_t n = (size_t)1 << k;
+  const unsigned nb = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL((gfft_load_kernel<C>), dim3(nb), dim3(64), 0, stream, (const char*)d_jac, (char*)d_work, n, d_pre);
+  for (int s = 0; s < k; s++) {
+    const size_t gap = n >> (s + 1);
+    hipLaunchKernelGGL((gfft_stage_kernel<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (char*)d_work, n, gap,
+                       s, d_roots);
+  }
+  hipLaunchKernelGGL((gfft_store_kernel<C>), dim3(nb), dim3(64), 0, stream, (const char*)d_work, (char*)d_jac, n, k, d_post);
+  return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <class C>
+size_t gfft_work_bytes(int k) { return ((size_t)1 << k) * XYZZ<typename C::F>::BYTES; }
+
+}  // namespace arkhip

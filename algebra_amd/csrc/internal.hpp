@@ -30,7 +30,10 @@ struct FftTimings;
   int test_basefield_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);    \
   int test_point_op_##NAME(int kind, const void* d_acc, const void* d_other, void* d_out, size_t n, hipStream_t s); \
   int sw_add_affine_##NAME(const void* d_in, void* d_out, size_t n, const void* d_delta, hipStream_t s);        \
-  int sw_normalize_batch_##NAME(const void* d_in, void* d_out, size_t n, hipStream_t s);
+  int sw_normalize_batch_##NAME(const void* d_in, void* d_out, size_t n, hipStream_t s);                          \
+  int gfft_run_##NAME(void* d_jac, int k, const uint32_t* d_roots, const uint32_t* d_pre, const uint32_t* d_post, \
+                      void* d_work, hipStream_t s);                                                                 \
+  size_t gfft_work_bytes_##NAME(int k);
 ARK_DECL_CURVE(BN254_G1)
 ARK_DECL_CURVE(BLS12_381_G1)
 ARK_DECL_CURVE(BLS12_377_G1)
@@ -44,6 +47,9 @@ ARK_DECL_CURVE(BLS12_381_G2)
   int test_field_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);          \
   int fr_scale_##NAME(const void* d_a, const uint64_t* k4, void* d_r, size_t n, hipStream_t s);                     \
   int fr_div_##NAME(const void* d_num, const void* d_den, void* d_r, size_t n, hipStream_t s);                      \
+  int fft_roots_##NAME(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t s, const uint32_t** out);        \
+  int fft_scalars_##NAME(FftWorkspace& ws, const uint64_t* base4, const uint64_t* mul4, size_t count, void* d_out,  \
+                         hipStream_t s);                                                                            \
   int fft_axis_##NAME(FftWorkspace& ws, const void* d_src, void* d_dst, unsigned G, size_t cols, const uint64_t* root4, \
                       hipStream_t s);                                                                               \
   int fft_axis_prepare_##NAME(FftWorkspace& ws, unsigned G, const uint64_t* root4, hipStream_t s, const uint32_t** pw); \

@@ -3,6 +3,7 @@
 #include "msm.cuh"
 #include "batchmul.cuh"
 #include "testops.cuh"
+#include "gfft.cuh"
 #include "internal.hpp"
 namespace arkhip {
 int msm_enqueue_BLS12_377_G1(MsmWorkspace& ws, const void* d_points, size_t wstride, const MsmPlan* prepared, const void* d_scalars,
@@ -41,4 +42,8 @@ int sw_add_affine_BLS12_377_G1(const void* in, void* out, size_t n, const void* 
 int sw_normalize_batch_BLS12_377_G1(const void* in, void* out, size_t n, hipStream_t s) {
   return sw_normalize_batch_launch<BLS12_377_G1>(in, out, n, s);
 }
+int gfft_run_BLS12_377_G1(void* d_jac, int k, const uint32_t* d_roots, const uint32_t* d_pre, const uint32_t* d_post, void* d_work, hipStream_t s) {
+  return gfft_run<BLS12_377_G1>(d_jac, k, d_roots, d_pre, d_post, d_work, s);
+}
+size_t gfft_work_bytes_BLS12_377_G1(int k) { return gfft_work_bytes<BLS12_377_G1>(k); }
 }  // namespace arkhip

@@ -185,3 +185,27 @@ class Radix2EvaluationDomain:
 
     def __repr__(self):
         return "Radix-2 multiplicative subgroup of size %d" % self.size()
+
+    def fft_group_in_place(self, curve, points, inverse=False):
+        """EvaluationDomain::fft_in_place / ifft_in_place for T = Projective<P> (poly/src/domain/mod.rs:332-362; the
+        reference's own use: poly/src/test.rs:57): `points` = size() Jacobian points (x | y | z limbs, the reference's
+        Projective) of `curve`, whose scalar field is this domain's -- numpy uint64 [n, 3 * fe_words] in host memory or a
+        torch CUDA tensor of the same bytes; transformed in place and returned.  Pad with identities (z = 0) yourself."""
+        from . import curves as cv
+        L = lib()
+        cid = cv.curve_id(curve)
+        n = self.size()
+        if _is_torch(points):
+            import torch
+            assert points.is_cuda and points.is_contiguous() and points.numel() * points.element_size() == n * cv.projective_words(cid) * 8
+            torch.cuda.current_stream().synchronize()
+            check(L.ark_hip_fft_group_in_place_device(cid, C.byref(self._s), points.data_ptr(), 1 if inverse else 0),
+                  "ark_hip_fft_group_in_place_device")
+            check(L.ark_hip_synchronize(), "ark_hip_synchronize")
+            return points
+        a = np.ascontiguousarray(points, dtype=np.uint64)
+        assert a.size == n * cv.projective_words(cid)
+        check(L.ark_hip_fft_group_in_place(cid, C.byref(self._s), a.ctypes.data_as(C.c_void_p), 1 if inverse else 0),
+              "ark_hip_fft_group_in_place")
+        return a
+

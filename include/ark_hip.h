@@ -312,6 +312,14 @@ int ark_hip_fft_batch_in_place_device(int field, const ark_hip_radix2_domain* do
  * (poly/src/evaluations/univariate/mod.rs), the pointwise step between the two FFTs and the IFFT of
  * DensePolynomial multiplication (poly/src/polynomial/univariate/dense.rs:641-656).  Asynchronous. */
 int ark_hip_fr_mul_device(int field, const void* d_a, const void* d_b, void* d_r, size_t n);
+/* The transform over GROUP elements (round 5): EvaluationDomain::fft_in_place / ifft_in_place for T = Projective<P>
+ * (poly/src/domain/mod.rs:332-362, radix2/fft.rs:74-119; the reference's own use: poly/src/test.rs:57 with G1Projective).
+ * jac_points: dom->size Jacobian points (x | y | z, the reference's Projective) of `curve`, whose scalar field must be the
+ * field the domain was made for; the caller pads with identities (z = 0) to the domain size, as the reference's resize does.
+ * Forward: X_j = sum_i [(h g^j)^i] P_i; inverse: P_i = [n^-1 h^-i] sum_j [g^-ij] X_j.  Results are group elements: the
+ * Projective representatives differ from the reference's, into_affine() agrees.  The device form is asynchronous. */
+int ark_hip_fft_group_in_place(int curve, const ark_hip_radix2_domain* dom, uint64_t* jac_points, int inverse);
+int ark_hip_fft_group_in_place_device(int curve, const ark_hip_radix2_domain* dom, void* d_jac_points, int inverse);
 /* The rest of the pointwise algebra of device-resident Fr vectors (round 5): Evaluations += / -= / negation
  * (poly/src/evaluations/univariate/mod.rs:104-180) and a vector times ONE field element (dense.rs:604-622; k is a host
  * pointer to one Montgomery element, read before the call returns).  With the transforms above, a chain

@@ -418,6 +418,17 @@ class Radix2EvaluationDomain {
   void fft_sharded_in_place_device(void* d_local, bool inverse = false) const {
     check(ark_hip_fft_sharded_device(FIELD_ID, &s_, d_local, inverse ? 1 : 0), "ark_hip_fft_sharded_device");
   }
+  // fft_in_place / ifft_in_place for T = Projective<P> (poly/src/domain/mod.rs:332-362; poly/src/test.rs:57): points of a
+  // curve whose scalar field is this domain's; resized to the domain size with identities (z = 0) first
+  template <class Curve>
+  void fft_group_in_place(std::vector<typename Curve::ProjectiveT>& pts, bool inverse = false) const {
+    static_assert(Curve::SCALAR_FIELD == FIELD_ID, "the domain must be over the curve's scalar field");
+    if (pts.size() > size()) throw Error(ARK_HIP_ERR_ARG, "more coefficients than the domain size");
+    typename Curve::ProjectiveT zero{};   // all-zero limbs: z = 0, the identity the transform expects
+    pts.resize(size(), zero);
+    check(ark_hip_fft_group_in_place(Curve::ID, &s_, reinterpret_cast<uint64_t*>(pts.data()), inverse ? 1 : 0),
+          "ark_hip_fft_group_in_place");
+  }
   const ark_hip_radix2_domain& raw() const { return s_; }
 
  private:

@@ -123,6 +123,11 @@ extern "C" {
     pub fn ark_hip_ifft_in_place(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64) -> c_int;
     pub fn ark_hip_fft_in_place_degree_aware(field: c_int, dom: *const ark_hip_radix2_domain, data: *mut u64,
                                              num_coeffs: usize) -> c_int;
+    /// `fft_in_place` / `ifft_in_place` for `T = Projective<P>`: `dom.size` Jacobian points of `curve`, in place.
+    pub fn ark_hip_fft_group_in_place(curve: c_int, dom: *const ark_hip_radix2_domain, jac_points: *mut u64,
+                                      inverse: c_int) -> c_int;
+    pub fn ark_hip_fft_group_in_place_device(curve: c_int, dom: *const ark_hip_radix2_domain, d_jac_points: *mut c_void,
+                                             inverse: c_int) -> c_int;
     pub fn ark_hip_fft_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void) -> c_int;
     pub fn ark_hip_ifft_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *mut c_void) -> c_int;
     pub fn ark_hip_fft_batch_in_place_device(field: c_int, dom: *const ark_hip_radix2_domain, d_data: *const *mut c_void,
@@ -196,13 +201,37 @@ pub fn limbs<F>(x: &F) -> [u64; 4] {
     unsafe { *(x as *const F as *const [u64; 4]) }
 }
 
+/// `T = Projective<P>` of a served curve -> (library curve id, its scalar field's id, bytes per point).  Rust has no
+/// specialisation: the coefficient type of `fft_in_place<T: DomainCoeff<F>>` is recognised by NAME (the curve crates' config
+/// paths, arkworks 0.6) and LAYOUT (three base-field elements, no padding); anything else is `None` and stays on the CPU.
+fn projective_curve<T>() -> Option<(c_int, c_int, usize)> {
+    let name = core::any::type_name::<T>();
+    if !name.contains("short_weierstrass::group::Projective<") {
+        return None;
+    }
+    const TABLE: [(&str, c_int, c_int, usize); 5] = [
+        ("bls12_381::curves::g1::Config", BLS12_381_G1, BLS12_381_FR, 144),
+        ("bls12_381::curves::g2::Config", BLS12_381_G2, BLS12_381_FR, 288),
+        ("bn254::curves::g1::Config", BN254_G1, BN254_FR, 96),
+        ("bls12_377::curves::g1::Config", BLS12_377_G1, BLS12_377_FR, 144),
+        ("bls12_377::curves::g2::Config", BLS12_377_G2, BLS12_377_FR, 288),
+    ];
+    for (cfg, curve, field, bytes) in TABLE {
+        if name.contains(cfg) && core::mem::size_of::<T>() == bytes && core::mem::align_of::<T>() == core::mem::align_of::<u64>() {
+            return Some((curve, field, bytes));
+        }
+    }
+    None
+}
+
 /// `Radix2EvaluationDomain::{fft,ifft}_in_place` on the GPU when the coefficients are elements of a served scalar
 /// field (radix2/mod.rs:140-153).  Called by ark-poly's `hip` feature (patches/0003) with the domain's public fields
 /// `consts = [size_inv, group_gen, group_gen_inv, offset, offset_inv]`.  Returns `false` -- having changed nothing
 /// the CPU path cares about -- when `T` is not `F` (Rust has no specialisation: the coefficient type is recognised by
 /// name and layout), the field is not served, or the device reports an error; the caller then runs the CPU code.
 /// Forward transforms of at most size/4 coefficients take the degree-aware entry (fft.rs:29-71): only the
-/// coefficients cross PCIe.
+/// coefficients cross PCIe.  `T = Projective<P>` of a served curve over `F` goes to the device's transform over points
+/// (round 5); any other `T` returns `false`.
 pub fn radix2_fft_in_place<F: FftField, T: Copy>(
     size: u64,
     log_size_of_group: u32,
@@ -211,16 +240,46 @@ pub fn radix2_fft_in_place<F: FftField, T: Copy>(
     zero: T,
     inverse: bool,
 ) -> bool {
-    if core::any::type_name::<T>() != core::any::type_name::<F>()
-        || core::mem::size_of::<T>() != 32
-        || core::mem::size_of::<F>() != 32
-        || core::mem::align_of::<T>() != core::mem::align_of::<u64>()
-    {
-        return false;
-    }
     let Some(fid) = fr_field_id::<F>() else {
         return false;
     };
+    if core::mem::size_of::<F>() != 32 {
+        return false;
+    }
+    if core::any::type_name::<T>() != core::any::type_name::<F>() {
+        // coefficients that are GROUP elements (poly/src/test.rs:57: G1Projective): the device's transform over points
+        // (ark_hip_fft_group_in_place) when T is the Projective of a served curve over this very scalar field
+        let Some((curve, curve_field, _)) = projective_curve::<T>() else {
+            return false;
+        };
+        let n = size as usize;
+        let len = coeffs.len();
+        if curve_field != fid || len > n {
+            return false;
+        }
+        let dom = ark_hip_radix2_domain {
+            size,
+            log_size_of_group,
+            _pad: 0,
+            size_as_field_element: [0; 4],
+            size_inv: limbs(&consts[0]),
+            group_gen: limbs(&consts[1]),
+            group_gen_inv: limbs(&consts[2]),
+            offset: limbs(&consts[3]),
+            offset_inv: limbs(&consts[4]),
+            offset_pow_size: [0; 4],
+        };
+        coeffs.resize(n, zero); // radix2/mod.rs:144,151; Projective::zero() has z = 0: the identity the device expects
+        let rc = unsafe { ark_hip_fft_group_in_place(curve, &dom, coeffs.as_mut_ptr() as *mut u64, inverse as c_int) };
+        if rc != 0 {
+            coeffs.truncate(len); // the device works on its own copy and writes back only on success
+            return false;
+        }
+        return true;
+    }
+    if core::mem::size_of::<T>() != 32 || core::mem::align_of::<T>() != core::mem::align_of::<u64>() {
+        return false;
+    }
     let n = size as usize;
     let len = coeffs.len();
     if len > n {

@@ -203,6 +203,54 @@ void check_device_chain(const char* name, unsigned log_n) {
   std::printf("%s device-resident chain 2^%u checked\n", name, log_n);
 }
 
+// fft_in_place for T = Projective (poly/src/test.rs:57): coefficients P_i = [a + i b] G, so FFT(P)_j = [FFT_F(a + i b)_j] G --
+// the field transform and the scalar multiplications from the oracle
+void check_group_fft() {
+  using Curve = Bls12_381G1;
+  using M = VariableBaseMSM<Curve>;
+  using D = Radix2EvaluationDomain<ARK_HIP_BLS12_381_FR>;
+  const unsigned log_n = 4;
+  const size_t n = (size_t)1 << log_n, have = n - 3;   // resized to the domain size with identities
+  uint64_t a4[4] = {0xA11CE, 1, 2, 0}, b4[4] = {0xB0B, 3, 0, 0};
+  std::vector<Curve::AffineT> aff(have);
+  ark_oracle_gen_bases(Curve::ID, a4, b4, have, reinterpret_cast<uint64_t*>(aff.data()));
+  uint64_t one[6];
+  ark_oracle_field_const(ARK_HIP_BLS12_381_FQ, 1, one);
+  std::vector<Curve::ProjectiveT> pts(have);
+  for (size_t i = 0; i < have; i++) {
+    pts[i].x = aff[i].x;
+    pts[i].y = aff[i].y;
+    for (int k = 0; k < 6; k++) pts[i].z.limbs[k] = one[k];
+  }
+  // scalars a + i b as canonical integers (small enough here: no reduction), zero beyond `have`
+  std::vector<Fr> canon(n), mont(n), out(n);
+  for (size_t i = 0; i < have; i++) {
+    unsigned __int128 c = 0;
+    for (int k = 0; k < 4; k++) {
+      c += (unsigned __int128)a4[k] + (unsigned __int128)b4[k] * i;
+      canon[i].limbs[k] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  ark_oracle_field_op(ARK_HIP_BLS12_381_FR, 8, reinterpret_cast<uint64_t*>(canon.data()), nullptr, reinterpret_cast<uint64_t*>(mont.data()), n);
+  ark_oracle_fft(ARK_HIP_BLS12_381_FR, reinterpret_cast<uint64_t*>(mont.data()), log_n, nullptr, 0, 2);
+  ark_oracle_field_op(ARK_HIP_BLS12_381_FR, 7, reinterpret_cast<uint64_t*>(mont.data()), nullptr, reinterpret_cast<uint64_t*>(out.data()), n);
+  uint64_t gen[12];
+  ark_oracle_curve_generator(Curve::ID, gen);
+  auto dom = D::new_(n);
+  EXPECT(dom.has_value(), "domain");
+  dom->fft_group_in_place<Curve>(pts);
+  EXPECT(pts.size() == n, "resized to the domain");
+  bool ok = true;
+  for (size_t j = 0; j < n; j++) {
+    Curve::ProjectiveT ref;
+    ark_oracle_scalar_mul(Curve::ID, gen, out[j].limbs.data(), reinterpret_cast<uint64_t*>(&ref));
+    ok = ok && (M::into_affine(pts[j]) == M::into_affine(ref));
+  }
+  EXPECT(ok, "group fft == [field fft of the discrete logs] G");
+  std::printf("BLS12_381_G1 group fft 2^%u checked\n", log_n);
+}
+
 // the library's RCCL communicator from a compiled host: a world of one on the test box's single GPU (dlopen of librccl,
 // ncclCommInitRank, the sharded MSM and FFT entries through it)
 void check_communicator() {
@@ -254,6 +302,7 @@ int main() {
   check_fft<ARK_HIP_BLS12_381_FR>("BLS12_381_FR", 12);
   check_communicator();
   check_fft<ARK_HIP_BN254_FR>("BN254_FR", 9);
+  check_group_fft();
   check_device_chain<ARK_HIP_BLS12_381_FR>("BLS12_381_FR", 20);
   check_device_chain<ARK_HIP_BLS12_377_FR>("BLS12_377_FR", 11);
   check_device_chain<ARK_HIP_BN254_FR>("BN254_FR", 5);
