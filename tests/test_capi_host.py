@@ -125,6 +125,19 @@ def test_no_gpu_means_loud_failure_not_a_cpu_fallback():
     with pytest.raises(A.ArkHipError) as e:
         d.fft(np.zeros((8, 4), dtype=np.uint64))
     assert e.value.code == -5
+    # the round-5 entries refuse the same way: device-resident vectors, the pointwise algebra, the transform over points
+    import ctypes as C
+    with pytest.raises(A.ArkHipError) as e:
+        A.DeviceVec.from_host("BLS12_381_FR", np.zeros((4, 4), dtype=np.uint64))
+    assert e.value.code == -5
+    dummy = C.c_void_p(64)
+    for rc in (L.ark_hip_fr_add_device(3, dummy, dummy, dummy, 1), L.ark_hip_fr_div_device(3, dummy, dummy, dummy, 1),
+               L.ark_hip_fr_inverse_device(3, dummy, dummy, 1), L.ark_hip_memcpy_d2d(dummy, dummy, 32),
+               L.ark_hip_memset_device(dummy, 0, 32)):
+        assert rc == -5
+    with pytest.raises(A.ArkHipError) as e:
+        d.fft_group_in_place("BLS12_381_G1", np.zeros((8, 18), dtype=np.uint64))
+    assert e.value.code == -5
 
 
 def test_cpp_host_mirror_compiles_and_links(tmp_path):
