@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(1024) msm_scalar_bits_kernel(const u32* __rest
 template <class SP>
 __global__ void __launch_bounds__(1024) msm_compact_scalars_kernel(const u32* __restrict__ scalars, u32 n, int mont, u32 chunk,
                                                                    const u32* __restrict__ chunk_off, u32* __restrict__ err,
-                                                                   u32* __restrict__ out_scalars, u32* __restrict__ out_idx) {
+                                                                   u32* __restrict__ out_scalars, u32* __restrict__ out_idx, u32 cap) {
   typedef Fp<SP> S;
   __shared__ u32 wave_cnt[16];
   __shared__ u32 run_s;
@@ -225,11 +225,15 @@ __global__ void __launch_bounds__(1024) msm_compact_scalars_kernel(const u32* __
     for (u32 w = 0; w < wave; w++) before += wave_cnt[w];
     if (keep) {
       const u32 pos = before + (u32)__popcll(m & ((1ull << lane) - 1ull));
-      const uint4* src = (const uint4*)(scalars + (size_t)i * S::N);
-      uint4* dst = (uint4*)(out_scalars + (size_t)pos * S::N);
-      dst[0] = src[0];
-      dst[1] = src[1];
-      out_idx[pos] = (u32)i;
+      if (pos < cap) {
+        const uint4* src = (const uint4*)(scalars + (size_t)i * S::N);
+        uint4* dst = (uint4*)(out_scalars + (size_t)pos * S::N);
+        dst[0] = src[0];
+        dst[1] = src[1];
+        out_idx[pos] = (u32)i;
+      } else {
+        atomicOr(err, 2u);   // cannot happen while K0 and this kernel agree on "zero"; never write past the buffers if they do not
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1791,7 +1795,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     scan_exclusive(cnt, nz_blocks, nullptr, off, stream);   // (nz_blocks <= 1024: the one-workgroup scan)
     hipLaunchKernelGGL((msm_compact_scalars_kernel<typename C::S>), dim3(nz_blocks), dim3(1024), 0, stream,
                        (const u32*)d_scalars_all, (u32)n_all, scalars_mont, nz_chunk, (const u32*)off, (u32*)ws.hctr.p + 3,
-                       (u32*)ws.cscal.p, (u32*)ws.cidx.p);
+                       (u32*)ws.cscal.p, (u32*)ws.cidx.p, (u32)n);
   }
   const u32 nblk = (u32)((n + 255) / 256);
   if (sbytes) {
