@@ -10,7 +10,8 @@
 //! [`DeviceEvaluations::interpolate`] the chain costs ONE upload per input and ONE download.
 //!
 //! Every operation is asynchronous on the library's stream of the current device and ordered with the others;
-//! [`DeviceVec::to_vec`] waits.  A vector belongs to the device that was current when it was created and is freed there.
+//! [`DeviceVec::to_vec`] waits.  A vector belongs to the device that was current when it was created: it is freed there, and
+//! an operation attempted while another device is current returns `DeviceError::WrongDevice` instead of touching it.
 //! Mirrors: `ark_hip::DeviceVec` in include/ark_hip.hpp (compiled and run by tests/test_gpu_cpp_mirror.py against the
 //! oracle at 2^20), `algebra_amd.DeviceVec` in Python.
 use ark_ff::FftField;
@@ -28,6 +29,8 @@ pub enum DeviceError {
     UnsupportedField,
     /// lengths / domains of the operands differ (the reference asserts `self.domain == other.domain`)
     Mismatch,
+    /// the vector lives on another device than the calling thread's current one (`ark_hip_set_device`)
+    WrongDevice,
     /// the library's return code (include/ark_hip.h `ARK_HIP_ERR_*`)
     Library(c_int),
 }
@@ -76,12 +79,14 @@ impl<F: FftField> DeviceVec<F> {
     }
     /// One download; waits for everything queued on the vector.
     pub fn to_vec(&self) -> Result<Vec<F>, DeviceError> {
+        self.here()?;
         let mut out: Vec<F> = Vec::with_capacity(self.len);
         rc(unsafe { sys::ark_hip_memcpy_d2h(out.as_mut_ptr() as *mut c_void, self.ptr, self.len * 32) })?;
         unsafe { out.set_len(self.len) }; // canonical Montgomery residues, the reference's own representation
         Ok(out)
     }
     pub fn try_clone(&self) -> Result<Self, DeviceError> {
+        self.here()?;
         let v = Self::alloc(self.len)?;
         rc(unsafe { sys::ark_hip_memcpy_d2d(v.ptr, self.ptr, self.len * 32) })?;
         Ok(v)
@@ -101,6 +106,7 @@ impl<F: FftField> DeviceVec<F> {
     }
     /// `Vec::resize(new_len, F::zero())` (also truncates).
     pub fn resize_zeroed(&mut self, new_len: usize) -> Result<(), DeviceError> {
+        self.here()?;
         if new_len > self.cap {
             let mut v = Self::alloc(new_len)?;
             rc(unsafe { sys::ark_hip_memcpy_d2d(v.ptr, self.ptr, self.len * 32) })?;
@@ -114,7 +120,13 @@ impl<F: FftField> DeviceVec<F> {
         }
         Ok(())
     }
+    /// every operation runs on the stream of the thread's CURRENT device: refuse a vector that lives elsewhere
+    fn here(&self) -> Result<(), DeviceError> {
+        if self.ptr.is_null() || unsafe { sys::ark_hip_get_device() } == self.device { Ok(()) } else { Err(DeviceError::WrongDevice) }
+    }
     fn same_len(&self, other: &Self) -> Result<(), DeviceError> {
+        self.here()?;
+        other.here()?;
         if self.len == other.len && self.field == other.field { Ok(()) } else { Err(DeviceError::Mismatch) }
     }
     pub fn add_assign_pointwise(&mut self, other: &Self) -> Result<(), DeviceError> {
@@ -137,14 +149,17 @@ impl<F: FftField> DeviceVec<F> {
     }
     /// `ark_ff::batch_inversion` on the device (zeros stay zero)
     pub fn batch_inverse(&mut self) -> Result<(), DeviceError> {
+        self.here()?;
         rc(unsafe { sys::ark_hip_fr_inverse_device(self.field, self.ptr, self.ptr, self.len) })
     }
     /// every element times `k` (`&DensePolynomial * F`, dense.rs:604-622)
     pub fn scale(&mut self, k: &F) -> Result<(), DeviceError> {
+        self.here()?;
         let kl = sys::limbs(k);
         rc(unsafe { sys::ark_hip_fr_scale_device(self.field, self.ptr, kl.as_ptr(), self.ptr, self.len) })
     }
     pub fn negate(&mut self) -> Result<(), DeviceError> {
+        self.here()?;
         rc(unsafe { sys::ark_hip_fr_neg_device(self.field, self.ptr, self.ptr, self.len) })
     }
     /// `DensePolynomial::evaluate_over_domain` (polynomial/univariate/mod.rs:305-360) for coefficients already on the
@@ -210,6 +225,7 @@ impl<F: FftField> DeviceEvaluations<F> {
     /// `Evaluations::interpolate` (mod.rs:47-50): the `domain.size()` coefficients, still on the device.  The reference
     /// then drops leading zeros (`DensePolynomial::from_coefficients_vec`): do that on the host after `to_vec()`.
     pub fn interpolate(mut self) -> Result<DeviceVec<F>, DeviceError> {
+        self.evals.here()?;
         let d = raw_domain(&self.domain);
         rc(unsafe { sys::ark_hip_ifft_in_place_device(self.evals.field, &d, self.evals.ptr) })?;
         Ok(self.evals)
