@@ -473,12 +473,14 @@ class DeviceVec {
   DeviceVec& operator=(const DeviceVec&) = delete;
   ~DeviceVec() { release(); }
   DeviceVec clone() const {
+    here();
     DeviceVec v;
     v.alloc(len_);
     check(ark_hip_memcpy_d2d(v.p_, p_, len_ * 32), "ark_hip_memcpy_d2d");
     return v;
   }
   std::vector<Fr> to_vec() const {
+    here();
     std::vector<Fr> out(len_);
     check(ark_hip_memcpy_d2h(out.data(), p_, len_ * 32), "ark_hip_memcpy_d2h");
     return out;
@@ -489,6 +491,7 @@ class DeviceVec {
   const void* device_ptr() const { return p_; }
   // Vec::resize(new_len, F::zero()) / Vec::truncate
   void resize_zeroed(size_t new_len) {
+    here();
     if (new_len > cap_) {
       DeviceVec v;
       v.alloc(new_len);
@@ -506,9 +509,9 @@ class DeviceVec {
   DeviceVec& operator-=(const DeviceVec& o) { same(o); check(ark_hip_fr_sub_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_sub_device"); return *this; }
   DeviceVec& operator*=(const DeviceVec& o) { same(o); check(ark_hip_fr_mul_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_mul_device"); return *this; }
   DeviceVec& operator/=(const DeviceVec& o) { same(o); check(ark_hip_fr_div_device(FIELD_ID, p_, o.p_, p_, len_), "ark_hip_fr_div_device"); return *this; }
-  void batch_inverse() { check(ark_hip_fr_inverse_device(FIELD_ID, p_, p_, len_), "ark_hip_fr_inverse_device"); }   // zeros stay zero
-  DeviceVec& operator*=(const Fr& k) { check(ark_hip_fr_scale_device(FIELD_ID, p_, k.limbs.data(), p_, len_), "ark_hip_fr_scale_device"); return *this; }
-  void negate() { check(ark_hip_fr_neg_device(FIELD_ID, p_, p_, len_), "ark_hip_fr_neg_device"); }
+  void batch_inverse() { here(); check(ark_hip_fr_inverse_device(FIELD_ID, p_, p_, len_), "ark_hip_fr_inverse_device"); }   // zeros stay zero
+  DeviceVec& operator*=(const Fr& k) { here(); check(ark_hip_fr_scale_device(FIELD_ID, p_, k.limbs.data(), p_, len_), "ark_hip_fr_scale_device"); return *this; }
+  void negate() { here(); check(ark_hip_fr_neg_device(FIELD_ID, p_, p_, len_), "ark_hip_fr_neg_device"); }
 
  private:
   void* p_ = nullptr;
@@ -522,7 +525,13 @@ class DeviceVec {
   void zero_from(size_t from) {
     if (len_ > from) check(ark_hip_memset_device((char*)p_ + from * 32, 0, (len_ - from) * 32), "ark_hip_memset_device");
   }
+  // every operation runs on the stream of the thread's CURRENT device: refuse a vector that lives elsewhere
+  void here() const {
+    if (p_ && ark_hip_get_device() != dev_) throw Error(ARK_HIP_ERR_ARG, "the device vector lives on another device than the current one");
+  }
   void same(const DeviceVec& o) const {
+    here();
+    o.here();
     if (o.len_ != len_) throw Error(ARK_HIP_ERR_ARG, "domains are unequal");   // the reference's assert_eq!(self.domain, other.domain)
   }
   void release() {
