@@ -67,7 +67,13 @@ ARK_DEV XYZZ<typename C::F> gfft_scalar_mul(const XYZZ<typename C::F>& p, const 
 }
 
 // lanes of one launch that multiply by a scalar: the window tables of a launch are GFFT_SLAB * 8 points at most
+// (ARK_HIP_GFFT_SLAB_LOG = 6..18 lowers it: the tests run a small transform in several slabs)
 static constexpr size_t GFFT_SLAB = (size_t)1 << 18;
+static inline size_t gfft_slab() {
+  const char* e = getenv("ARK_HIP_GFFT_SLAB_LOG");
+  const int l = e ? atoi(e) : 18;
+  return l >= 6 && l <= 18 ? (size_t)1 << l : GFFT_SLAB;
+}
 
 // Jacobian (x, y, z) -> XYZZ (x, y, z^2, z^3), identity (z = 0) -> zero; optionally times scal[i]
 template <class C>
@@ -135,7 +141,8 @@ template <class C>
 int gfft_run(void* d_jac, int k, const u32* d_roots, const u32* d_pre, const u32* d_post, void* d_work, hipStream_t stream) {
   typedef XYZZ<typename C::F> Pt;
   const size_t n = (size_t)1 << k;
-  const size_t slab = n < GFFT_SLAB ? n : GFFT_SLAB;     // lanes per launch (a launch's window tables: slab * 8 points)
+  const size_t cap = gfft_slab();
+  const size_t slab = n < cap ? n : cap;                 // lanes per launch (a launch's window tables: slab * 8 points)
   char* work = (char*)d_work;
   char* tab = work + n * Pt::BYTES;
   const unsigned nb = (unsigned)((slab + 63) / 64);

@@ -87,3 +87,28 @@ def test_group_fft_2_10_device_resident_and_linear():
     e0[0] = pts[1]
     spread = A.into_affine(cid, dom.fft_group_in_place(cname, e0))
     assert np.array_equal(spread, np.tile(A.into_affine(cid, pts[1:2]).reshape(1, -1), (n, 1)))
+
+
+@pytest.mark.parametrize("cname", ["BLS12_381_G1", "BLS12_377_G2"])
+def test_group_fft_in_several_slabs(cname, monkeypatch):
+    # a transform above 2^18 lanes runs its launches in slabs that share one set of window tables: the same code at 2^8 with
+    # slabs of 64 lanes (ARK_HIP_GFFT_SLAB_LOG, read per call) -- plain, coset and inverse against the single-slab results,
+    # which the first test pins to the oracle
+    import torch
+    log_n = 8
+    n = 1 << log_n
+    cid, sf, r, pts, scal = _setup(cname, n, zero_at=(3, n - 1))
+    fname = [k for k, v in O.FID.items() if v == sf][0]
+    dom = A.Radix2EvaluationDomain.new(fname, n)
+    for d in (dom, dom.get_coset(O.field_const(sf, 3))):
+        whole_f = d.fft_group_in_place(cname, pts.copy())
+        whole_i = d.fft_group_in_place(cname, pts.copy(), inverse=True)
+        monkeypatch.setenv("ARK_HIP_GFFT_SLAB_LOG", "6")
+        slab_f = d.fft_group_in_place(cname, pts.copy())
+        slab_i = d.fft_group_in_place(cname, pts.copy(), inverse=True)
+        dd = torch.from_numpy(pts.view(np.int64).copy()).cuda()
+        slab_dev = d.fft_group_in_place(cname, dd).cpu().numpy().view(np.uint64).reshape(n, -1)
+        monkeypatch.delenv("ARK_HIP_GFFT_SLAB_LOG")
+        assert np.array_equal(slab_f, whole_f) and np.array_equal(slab_i, whole_i) and np.array_equal(slab_dev, whole_f)
+        back = d.fft_group_in_place(cname, whole_f.copy(), inverse=True)
+        assert np.array_equal(A.into_affine(cid, back), A.into_affine(cid, pts))
