@@ -1971,7 +1971,8 @@ int ark_hip_msm_cache_hash_stats(uint64_t out[4]) {
 // the window plan the library would use (host arithmetic only: no GPU needed)
 int ark_hip_msm_plan(int curve, size_t n, int prepared, int* window_bits, int* windows) {
   if (curve < 0 || curve > 4) return ARK_HIP_ERR_ARG;
-  const MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve), prepared != 0, msm_lazy28(curve));
+  const MsmPlan pl = msm_make_plan(n ? n : 1, msm_scalar_bits(curve), msm_mul_cost(curve), prepared != 0, msm_lazy28(curve), nullptr,
+                                   prepared == 0 && msm_lazy_enabled());
   if (window_bits) *window_bits = pl.c;
   if (windows) *windows = pl.W;
   return 0;

@@ -1276,6 +1276,7 @@ struct MsmPlan {
                   // window is left with only a few significant bits (0: uniform widths)
   size_t nb;      // bucket slots of the sort = W << (c-1)
   bool shared;    // prepared base set: the W windows share one set of 2^(c-1) buckets
+  unsigned parts = 0;   // small plain MSMs: lanes per (window, bucket) run the accumulate kernel should use (0: its own rule)
   size_t nbuckets() const { return shared ? ((size_t)1 << (c - 1)) : nb; }
   int red_windows() const { return shared ? 1 : W; }
 };
@@ -1328,7 +1329,7 @@ static inline int msm_window_offset(int w, int c, int W, int narrow) {
 // level costs 2 full additions per bucket, the bit-sliced remainder ~0.5 ms.  With a prepared base set
 // (`shared`) only one bucket set is reduced, which moves the optimum to wider windows.
 static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool shared, bool lazy28 = false,
-                                    const MsmWidths* widths = nullptr) {
+                                    const MsmWidths* widths = nullptr, bool split_runs = false) {
   const double plain_k = lazy28 ? 0.79 : 1.0;   // plain path only: see the accumulate model below
   int best_c = 3;
   double best = 1e300;
@@ -1437,9 +1438,31 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       if (cost < best) { best = cost; best_c = c; }
     }
   }
+  unsigned parts = 0;
+  if (split_runs && !shared && !widths && bits > 128 && !(env && atoi(env) >= 3 && atoi(env) <= 26)) {
+    // Small plain MSMs (round 5, profiles/r5_small_n_run_parts.txt).  Below ~2^17 pairs the accumulate kernel lasts as long as
+    // its most loaded bucket (a Poisson tail of dependent additions at ~17 us each) and the model above answers with wide
+    // windows -- few points per bucket, many buckets to reduce.  Narrower windows with every run walked by 4 or 8 lanes
+    // (msm_accumulate_parts_kernel: the chain is cut, the pieces are summed by msm_sum_parts_kernel) win on both sides:
+    // BLS12-381 G1 2^16 c = 14 -> 12: reduce 0.43 -> 0.27 ms, accumulate 0.36 -> 0.40, call 1.11 -> 0.99 ms; 2^14 0.91 -> 0.79;
+    // 2^12 0.80 -> 0.71; 2^8 0.69 -> 0.60; BN254 2^16 0.67 -> 0.60; BLS12-377 G2 2^14 2.00 -> 1.61, 2^12 1.74 -> 1.39.
+    // From 2^17 (G2: 2^16) the model's choice with one lane per run is the faster one again.  BLS12-377 G1 leaves the rule at
+    // 2^15 already (1.09 against 1.07 ms, 2^16 1.29 against 1.22; 2^14 0.81 against 0.99): r = 0x12ab... x 2^240 fills only
+    // 0.58 of its top window's buckets, whose runs are then twice as long as anybody else's and set the kernel's time.
+    static const bool on = [] { const char* e = getenv("ARK_HIP_MSM_SMALL_SPLIT"); return !(e && e[0] == '0'); }();
+    const bool fp2 = mul_cost > 2.0;
+    int logn = 0;
+    while (((size_t)1 << logn) < n) logn++;
+    if (on && n >= 256 && n <= (fp2 ? (size_t)24576 : bits == 253 ? (size_t)20480 : (size_t)73728)) {
+      const int cap = fp2 ? 11 : 12;
+      best_c = logn - 2 < cap ? logn - 2 : cap;
+      parts = (!fp2 && (n >> (best_c - 1)) >= 32) ? 8u : 4u;
+    }
+  }
   MsmPlan p;
   p.c = best_c;
   p.shared = shared;
+  p.parts = parts;
   msm_window_layout(best_c, bits, &p.W, &p.narrow);
   if (!shared && getenv("ARK_HIP_MSM_UNIFORM")) {  // A/B knob: the older uniform-width layout
     p.W = (bits + 1 + best_c - 1) / best_c;
@@ -1658,7 +1681,8 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   const MsmPlan pl = prepared ? *prepared
                      : piece  ? *piece->plan
                      : have_widths ? msm_plan_for_widths(n, C::S::BITS, msm_mul_cost(C::ID), C::LAZY_A, widths)
-                                   : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A);
+                                   : msm_make_plan(n, plan_bits, msm_mul_cost(C::ID), false, C::LAZY_A, nullptr,
+                                                   C::LAZY_A && msm_lazy_enabled());
   // K0c: a quarter or more of the scalars zero (known exactly from the probe's class 0) -> they leave before the sort.
   // From here on `n` is the number of scalars the pipeline carries; base indices come back through ws.cidx after the sort.
   const size_t n_all = n;
@@ -1891,6 +1915,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     }
     const double mean_run = expect / (double)nb;
     while (run_parts < 8 && nb * (size_t)(2 * run_parts) <= lanes_target && mean_run >= 32.0 * (2 * run_parts)) run_parts *= 2;
+    if (pl.parts) run_parts = pl.parts;   // small plain MSMs: the plan's narrow windows count on split runs (msm_make_plan)
     if (const char* e = getenv("ARK_HIP_MSM_RUN_PARTS")) {   // test / tuning knob: force 1, 2, 4 or 8 lanes per run
       const int v = atoi(e);
       if (v == 1 || v == 2 || v == 4 || v == 8) run_parts = (u32)v;

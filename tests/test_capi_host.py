@@ -183,7 +183,10 @@ def test_msm_plan_is_host_only_and_sane():
     # cost model must not silently move them
     measured = {(1, 24, 0): (20, 13), (1, 24, 1): (22, 12), (1, 25, 1): (22, 12), (1, 26, 1): (24, 11), (1, 23, 1): (22, 12),
                 (1, 20, 1): (19, 14), (1, 16, 1): (17, 15), (0, 24, 1): (22, 12), (0, 23, 1): (22, 12), (3, 22, 1): (20, 13),
-                (3, 16, 1): (17, 15), (4, 16, 1): (17, 15), (3, 12, 1): (17, 15), (3, 22, 0): (19, 14)}
+                (3, 16, 1): (17, 15), (4, 16, 1): (17, 15), (3, 12, 1): (17, 15), (3, 22, 0): (19, 14),
+                # small plain MSMs: narrow windows with split runs (profiles/r5_small_n_run_parts.txt)
+                (1, 16, 0): (12, 22), (1, 14, 0): (12, 22), (1, 12, 0): (10, 26), (1, 8, 0): (6, 43), (0, 16, 0): (12, 22),
+                (3, 14, 0): (11, 23), (3, 12, 0): (10, 26), (1, 17, 0): (15, 17), (3, 16, 0): (14, 19)}
     for (curve, logn, prepared), want in measured.items():
         c, w = C.c_int(), C.c_int()
         assert L.ark_hip_msm_plan(curve, 1 << logn, prepared, C.byref(c), C.byref(w)) == 0
