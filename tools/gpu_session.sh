@@ -13,7 +13,8 @@
 #   env:VAR=VAL          export VAR=VAL for the steps that follow (A/B switches: ARK_HIP_FFT_LAZY=0, ARK_HIP_MSM_LAZY=0)
 #   n2gloo               bench.py --gpus 2 over gloo, ranks sharing the GPU   -> bench_n2_gloo.json
 #   soak:N               tools/soak.py N                                      -> soak.log
-#   skewsoak:N[:SEED]    tools/skew_soak.py N SEED (random width-class mixtures, five curves) -> skew_soak.log
+#   skewsoak:N[:SEED[:LO:HI]]  tools/skew_soak.py N SEED [LO HI] (random width-class mixtures, five curves; sizes
+#                        2^LO..2^HI instead of 2^17..2^21)                    -> skew_soak.log (appended)
 #   ktpy:SCRIPT[:ARGS]   rocprofv3 --kernel-trace of python tools/SCRIPT ARGS; KT_TIMELINE=N also lists the last N launches
 #                        in start order with the idle gaps between them        -> kernel_stats_SCRIPT_ARGS.txt
 #   pyv:SCRIPT[:ARGS]    python tools/SCRIPT on the shipped library and on every algebra_amd/variants/*.so -> pyv_SCRIPT.txt
@@ -77,7 +78,7 @@ for step in "$@"; do
     n2gloo)
       (ARK_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 3 --warmup 1 --log-n 21 --log-total 22 --fft-log-n 20 --fft-steps 4 > $O/bench_n2_gloo.json) 2> $O/bench_n2_gloo.err ;;
     soak) (timeout 1200 python tools/soak.py ${a[1]:-200} 2>&1 | tail -4) > $O/soak.log ;;
-    skewsoak) (timeout 1500 python tools/skew_soak.py ${a[1]:-100} ${a[2]:-2024} 2>&1 | grep -v "^it " | tail -8) > $O/skew_soak.log ;;
+    skewsoak) (timeout 1500 python tools/skew_soak.py ${a[1]:-100} ${a[2]:-2024} ${a[3]} ${a[4]} 2>&1 | grep -v "^it " | tail -8) >> $O/skew_soak.log ;;
     mulbench)
       for b in algebra_amd/csrc/ubench/mulbench_*.bin; do (echo "== $b"; timeout 120 $b) >> $O/mulbench.txt 2>> $O/mulbench.err; done ;;
     msm)

@@ -3,7 +3,8 @@
 runs walked by several lanes, narrow-scalar planner): random curve, size 2^17 .. 2^21, random mixture of the width classes
 (zeros, +-1, +-u8, +-u16, +-u32, +-u64, 100-bit, full width, a few equal scalars), device-resident msm_bigint /
 msm_unchecked (Montgomery) / host-pointer entry, now and then with forced window size or forced run parts -- every result
-against k*G in closed form (tools/synth.py).   python tools/skew_soak.py [iterations] [seed]"""
+against k*G in closed form (tools/synth.py).   python tools/skew_soak.py [iterations] [seed] [log_lo log_hi]
+(log_lo / log_hi: another size range, e.g. 8 16 for the small-n plan with split runs)"""
 import os
 import sys
 
@@ -20,6 +21,8 @@ from algebra_amd import curves as cv
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
 rng = np.random.default_rng(seed)
+LOG_LO = int(sys.argv[3]) if len(sys.argv) > 4 else 17
+LOG_HI = int(sys.argv[4]) if len(sys.argv) > 4 else None
 CURVES = ("BLS12_381_G1", "BN254_G1", "BLS12_377_G1", "BLS12_377_G2", "BLS12_381_G2")
 LOGMAX = {"BLS12_381_G1": 21, "BN254_G1": 21, "BLS12_377_G1": 21, "BLS12_377_G2": 20, "BLS12_381_G2": 20}
 bases = {}
@@ -64,11 +67,11 @@ for it in range(iters):
     cname = CURVES[int(rng.integers(0, len(CURVES)))]
     cid = cv.curve_id(cname)
     r = S.R[cv.scalar_field(cid)]
-    logn = int(rng.integers(17, LOGMAX[cname] + 1))
-    n = (1 << logn) - int(rng.integers(0, 1000))
+    logn = int(rng.integers(LOG_LO, (LOG_HI if LOG_HI is not None else LOGMAX[cname]) + 1))
+    n = (1 << logn) - int(rng.integers(0, min(1000, 1 << (logn - 1))))
     ab = cv.affine_words(cid) * 8                     # bytes per affine point (grow_bases returns a flat uint8 tensor)
     if cname not in bases:
-        bases[cname] = S.grow_bases(cid, 1 << LOGMAX[cname], S.A0, S.B0, r)
+        bases[cname] = S.grow_bases(cid, 1 << (LOG_HI if LOG_HI is not None else LOGMAX[cname]), S.A0, S.B0, r)
     b = bases[cname][: n * ab]
     # a random mixture: 1-4 classes with random weights
     k = int(rng.integers(1, 5))
@@ -96,10 +99,10 @@ for it in range(iters):
             got = A.msm_bigint(cid, b, d)
         elif mode == 1:   # Fr elements in Montgomery form (what the trait's msm passes) on a 4096-pair prefix, then the whole vector
             R = (1 << 256) % r
-            ms = limbs([(S.scalar_int(row) * R) % r for row in sc[:4096]])
+            ms = limbs([(S.scalar_int(row) * R) % r for row in sc[:4096]])   # (the whole vector when n < 4096)
             d1 = torch.from_numpy(np.ascontiguousarray(ms).view(np.int64)).cuda()
             kg1 = S.mul_gen(cid, S.dlog_of_msm(sc[:4096], S.A0, S.B0, r), r)
-            if not np.array_equal(A.into_affine(cid, A.msm_unchecked(cid, b[: 4096 * ab], d1)), kg1):
+            if not np.array_equal(A.into_affine(cid, A.msm_unchecked(cid, b[: min(n, 4096) * ab], d1)), kg1):
                 bad += 1
                 print("MONTGOMERY MISMATCH", cname, n, kinds, env, flush=True)
             d = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
