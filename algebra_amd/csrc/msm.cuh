@@ -1285,7 +1285,7 @@ struct MsmPlan {
 // 0.18 ns per addition at full occupancy)
 static inline double msm_mul_cost(int curve_id) { return curve_id == 0 ? 0.5 : (curve_id >= 3 ? 2.7 : 1.0); }
 // curves whose additions run on 28-bit limbs (C::LAZY_A: the Fp384 G1 curves)
-static inline bool msm_lazy28(int curve_id) { return curve_id == 1 || curve_id == 2; }
+static inline bool msm_lazy28(int curve_id) { return curve_id <= 2; }   // (BN254 since round 4: 9 x 29 bits -- the device path plans with C::LAZY_A)
 // ARK_HIP_MSM_LAZY=0: the saturated kernels on those curves too (A/B measurements)
 static inline bool msm_lazy_enabled() {
   static const bool on = [] {
@@ -1381,17 +1381,38 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
         const double chain = (load + 3.0 * sqrt(load) + 2.0) * 38e-6;
         if (chain > acc) acc = chain;
       } else {
-        // Fp384 G1 on 28-bit limbs (round 3): 7.0e9 instead of 5.5e9 mixed additions/s (plain_k = 0.79; BN254, on
-        // saturated limbs, scales by its mul_cost alone).  (That the first point of a bucket is only a copy does not show
-        // in the aggregate rate: 6.5e9/s at 2^22 with c = 19 against 6.8e9/s with c = 17.)
+        // G1 on carry-free limbs (round 3; BN254 since round 4, scaled by its mul_cost): 7.0e9 instead of 5.5e9 mixed
+        // additions/s (plain_k = 0.79).
         // One lane walks one (window, bucket) run, and the kernel lasts at least as long as its most loaded lane: measured
         // 19 us per dependent addition for BLS12-381 whatever the occupancy (2^15 / 2^16, mean loads 2 .. 128:
         // profiles/r3_window_sweep.txt), 14-18 us for BN254.
         const double load = entries / nbk;
-        acc *= plain_k;
+        // (round 5, profiles/r5_window_sweep_mid_sizes.txt) the first point of a bucket is a copy, not an addition:
+        // entries - occupied buckets additions (2^19, c = 16 / 17: 7.86e6 / 6.88e6 additions in 1.13 / 1.00 ms; 2^20, c = 17:
+        // 1.475e7 in 2.07 ms), and a launch of only ~2 rounds over the chip's 131 072 resident lanes pays for its ragged last
+        // round: c = 15 (2.78e5 lanes) runs 5-9 % over the rate at 2^18 / 2^19 where c = 16 (four rounds) and wider match it
+        // That saving is there while the bucket array stays in the 256 MB last-level cache (<= ~1e6 buckets of 192 B); beyond,
+        // a bucket's first touch and its store cost what the copy saves (2^22: c = 19 / 20, 2.2e6 / 5.5e6 buckets, run at
+        // 6.5e9 entries/s against c = 17's 6.8e9): the credit fades out between 1e6 and 4e6 buckets.
+        const double rounds = nbk / 131072.0;
+        const double credit = nbk <= 1e6 ? 1.0 : (nbk >= 4e6 ? 0.0 : (4e6 - nbk) / 3e6);
+        acc = (entries - credit * nbk * (1.0 - exp(-load))) * madd * plain_k * (rounds >= 1.0 ? 1.0 + 0.3 / (rounds * rounds) : 1.0);
         const double lmax = load + 3.0 * sqrt(load) + 2.0;
-        const double chain = lmax * (lazy28 ? 19e-6 : 32e-6 * mul_cost);
+        // one dependent addition: 19 us on 14 x 28-bit limbs, 13.5 us on BN254's 9 x 29 (2^17, c = 15 / 16: 0.24 / 0.165 ms)
+        const double chain = lmax * (lazy28 ? (mul_cost < 1.0 ? 13.5e-6 : 19e-6) : 32e-6 * mul_cost);
         if (chain > acc) acc = chain;
+        if (!widths && (narrow > 0 || W * c == bits)) {
+          // the TOP window: scalars below r (folded below r / 2) reach only r / 2^bits of its buckets -- 0.58 for BLS12-377's
+          // r = 0x12ab..., 0.76 for BN254's, 0.91 for BLS12-381's -- so its runs are that much longer than the layout says and,
+          // sorted to the front, are what the kernel's last waves are still walking: ~11 us per dependent addition once few
+          // waves are left (BLS12-377 G1 2^18: accumulate 0.89 ms with c = 15, 0.57 with c = 16, where BLS12-381 takes 0.63 /
+          // 0.55; 2^17: 0.51 / 0.32; 2^16, c = 14: 0.47 against 0.36)
+          const double frac = bits == 253 ? 0.583 : (bits == 254 ? 0.756 : (bits == 255 ? 0.906 : 1.0));
+          const int wt = narrow > 0 ? c - 1 : c;
+          const double load_top = (double)n / (frac * ldexp(1.0, wt - 1));
+          const double chain_top = (load_top + 3.0 * sqrt(load_top) + 2.0) * 11e-6 * (mul_cost < 1.0 ? 0.7 : 1.0);
+          if (chain_top > acc) acc = chain_top;
+        }
       }
       // level 0 of the reduction: 2 full additions per bucket; over Fp2 with ONE bucket set (a lane PAIR per bucket: half
       // the lanes, the same chain length) the kernels run at ~40 % of the addition throughput (measured: BLS12-377 G2 2^16, 2^18 buckets 1.7 ms,
@@ -1412,8 +1433,15 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
       if (!shared && !fp2) {
         // plain path, fitted on BLS12-381 2^16 .. 2^24 (profiles/r3_window_sweep.txt): 0.2 ms + 0.45 ns per bucket
         // + 1.4 ns per bucket for the first 3e5 (few buckets leave the chip's lanes idle, the chains dominate)
-        red0 = nbk * 2.0 * fadd * plain_k;
-        bits_stage = (0.25e-3 + (nbk < 3e5 ? nbk : 3e5) * 1.75e-9) * mul_cost * plain_k;
+        // (round 5 refit on the split-level kernels, BLS12-381 G1: 1.56e5 buckets 0.43 ms, 2.8e5 0.54, 5.2e5 0.65-0.71, 9.8e5
+        // 0.95, 3.7e6 2.1, 6.8e6 3.6; BN254 half of that: 0.40 ms + 0.47 ns per bucket + 0.10 ns for the first 1e6.  The older
+        // fit -- 0.2 ms + 0.40 ns + 1.4 ns for the first 3e5 -- was 0.1 ms high between 3e5 and 1e6 buckets, 0.25 ms low at 6.8e6)
+        // Counted half way between the occupied slots and W 2^(c-1): the reduction walks every window at full width, and the
+        // empty upper half of a narrow one costs it its lanes' launch and barriers but no additions (2^23, c = 19: 2.09 ms with
+        // 11 of 14 windows narrow on BLS12-381, 1.67 with 13 of 14 on BLS12-377; c = 18, uniform, 1.26)
+        const double nred = 0.5 * (nbk + (double)W * ldexp(1.0, c - 1));
+        red0 = (nred * 0.47e-9 + (nred < 1e6 ? nred : 1e6) * 0.10e-9) * mul_cost;
+        bits_stage = 0.40e-3 * mul_cost;
       }
       // partition sort: per entry, plus a per-(window, bucket) term.  On the shared path at n >= 2^23 the latter is
       // measured nearly flat up to c = 22 (9 super-bucket bits + 12 bits finished in LDS, msm_part_split); beyond that the
@@ -1435,6 +1463,10 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
         else if (!shared && !fp2 && bits <= 129 && tb > 5 && tb < c - 3) cost *= 1.4;
       }
       if ((size_t)n * (size_t)W >= (1ull << 32)) continue;  // 32-bit sort positions
+      static const bool dbg = getenv("ARK_HIP_PLAN_DEBUG") != nullptr;   // the model's terms per candidate, on stderr
+      if (dbg)
+        fprintf(stderr, "plan n=%zu c=%d W=%d narrow=%d: accumulate %.3f reduce %.3f + %.3f sort %.3f -> %.3f ms\n", n, c, W, narrow,
+                acc * 1e3, red0 * 1e3, bits_stage * 1e3, sort * 1e3, cost * 1e3);
       if (cost < best) { best = cost; best_c = c; }
     }
   }
@@ -1748,6 +1780,11 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     // one shared bucket set (prepared base set), measured per bucket count (profiles/r2_msm_sweeps.txt, sessions L0 / AN):
     // 2^18 buckets L0 = 8, 2^19 .. 2^21 L0 = 16 (2^19: reduction 1.32 -> 0.99 ms against L0 = 8)
     if (Wr == 1 && nbr > ((size_t)1 << 18)) L0 = nbr <= ((size_t)1 << 21) ? 16 : 32;
+    // (round 5) 2^19 .. 2^20 buckets on the one-lane-per-point curves (c = 17: 2^21 / 2^22 pairs): with L0 = 16 the two-wave
+    // level-0 form still fits one round of the chip (2 x 61 440 lanes, 17 steps) and hands the bit-sliced stage half the pairs
+    // of L0 = 8, whose 245 760 split lanes do not fit and whose one-wave form walks 16 steps: reduction 1.18 -> 0.95 ms,
+    // 2^21 6.35 -> 5.99 ms, 2^22 11.20 -> 10.82 (profiles/r5_reduce_geometry_sweep.txt, session r5rs2)
+    if (Wr > 1 && C::FA::LANES == 1 && nbr > ((size_t)1 << 19) && nbr <= ((size_t)1 << 20)) L0 = 16;
     if (const char* e0 = getenv("ARK_HIP_MSM_L0")) {  // tuning knob
       int v = atoi(e0);
       if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L0 = (u32)v;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small-n accumulate latency: the longest bucket sets the kernel's time below ~2^18 pairs.  Sweeps the window size
 (ARK_HIP_MSM_C) against lanes per run (ARK_HIP_MSM_RUN_PARTS) in one process, plain entry, every result exact.
-    python tools/parts_sweep.py [CURVE] [log_n ...]"""
+    python tools/parts_sweep.py [CURVE] [log_n ...] [c-only]"""
 import ctypes as C
 import os
 import sys
@@ -20,6 +20,7 @@ from algebra_amd._lib import check, lib
 
 curve = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].isdigit() else "BLS12_381_G1"
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [16, 17, 18]
+C_ONLY = "c-only" in sys.argv   # window size alone, c = the plan's +- 2
 cid = cv.curve_id(curve)
 r = S.R[cv.scalar_field(cid)]
 L = lib()
@@ -45,8 +46,16 @@ for logn in sizes:
     sc = S.gen_scalars(n, 5, r)
     d = torch.from_numpy(sc.view(np.int64)).cuda()
     kg = S.mul_gen(cid, S.dlog_of_msm(sc, S.A0, S.B0, r), r)
-    for c in (None,) + tuple(range(max(6, logn - 6), logn)):
-        for parts in (None, 2, 4, 8):
+    os.environ.pop("ARK_HIP_MSM_C", None)
+    os.environ.pop("ARK_HIP_MSM_RUN_PARTS", None)
+    if C_ONLY:
+        wb, ww = C.c_int(), C.c_int()
+        check(L.ark_hip_msm_plan(cid, n, 0, C.byref(wb), C.byref(ww)), "plan")
+        cands = (None,) + tuple(range(wb.value - 2, wb.value + 3))
+    else:
+        cands = (None,) + tuple(range(max(6, logn - 6), logn))
+    for c in cands:
+        for parts in ((None,) if C_ONLY else (None, 2, 4, 8)):
             for k, v in (("ARK_HIP_MSM_C", c), ("ARK_HIP_MSM_RUN_PARTS", parts)):
                 if v is None:
                     os.environ.pop(k, None)
