@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <math.h>
 #include "curves.cuh"
@@ -1556,6 +1557,7 @@ struct MsmJob {
   u32 Q = 0;
   size_t npairs = 0;
   const char* d_sums = nullptr;   // the job's part sums in device memory (npairs XYZZ points): read by the sharded combine
+  bool short_job = false;         // a couple of milliseconds of GPU work at most: the host tail is a visible share of the call
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -2195,6 +2197,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
   job.pl = pl;
   job.nbits = nbits;
   job.log2L0 = log2L0;
+  job.short_job = (double)n * (double)W <= 6.0e6;   // (up to ~2^18 full-width pairs)
   job.Q = Q;
   job.npairs = npairs;
   job.d_sums = d_sums;
@@ -2231,6 +2234,34 @@ static inline hipError_t msm_wait_event(hipEvent_t ev) {
 // off_w + log2 L0 + b, so the chain doubles once per scalar bit (<= 256 doublings) instead of once per bit inside every
 // window and again between windows (~2 c W).  parts: [w][q] XYZZ points, q < nbits: U_(w,q), q == nbits: A_w, row
 // stride Q; off: Wr + 1 bit offsets.  A prepared base set has a single T (Wr = 1).
+// window w's own sum  T_w = A_w + 2^log2L0 sum_b 2^b U_(w,b)
+template <class C>
+XYZZ<typename C::F> msm_host_window_sum(const char* parts, u32 Q, int nbits, int log2L0, int w) {
+  typedef typename C::F F;
+  typedef XYZZ<F> Pt;
+  auto part_at = [&](u32 q) { return Pt::load(parts + ((size_t)w * Q + q) * Pt::BYTES); };
+  Pt h = Pt::zero();
+  for (int b = nbits - 1; b >= 0; b--) {
+    h = xyzz_dbl<F>(h);
+    Pt ub = part_at((u32)b);
+    xyzz_add<F>(h, ub);
+  }
+  for (int i = 0; i < log2L0; i++) h = xyzz_dbl<F>(h);
+  Pt asum = part_at((u32)nbits);
+  xyzz_add<F>(h, asum);
+  return h;
+}
+// total = sum_w 2^(off_w) T_w: the doublings between the windows, the only serial part of the tail
+template <class C>
+XYZZ<typename C::F> msm_host_combine_windows(const XYZZ<typename C::F>* T, int Wr, const int* off) {
+  typedef typename C::F F;
+  XYZZ<F> total = T[(size_t)Wr - 1];
+  for (int w = Wr - 2; w >= 0; w--) {
+    for (int i = off[w]; i < off[w + 1]; i++) total = xyzz_dbl<F>(total);   // the width of window w
+    xyzz_add<F>(total, T[(size_t)w]);
+  }
+  return total;
+}
 template <class C>
 XYZZ<typename C::F> msm_host_fold(const char* parts, u32 Q, int Wr, int nbits, int log2L0, const int* off) {
   typedef typename C::F F;
@@ -2243,30 +2274,14 @@ XYZZ<typename C::F> msm_host_fold(const char* parts, u32 Q, int Wr, int nbits, i
   static const bool threaded_env = [] { const char* e = getenv("ARK_HIP_HOST_TAIL_THREADS"); return !(e && e[0] == '0'); }();
   if (C::FA::LANES == 2 && Wr >= 4 && threaded_env) {
     std::vector<Pt> T((size_t)Wr);
-    auto window = [&](int w) {
-      Pt h = Pt::zero();
-      for (int b = nbits - 1; b >= 0; b--) {
-        h = xyzz_dbl<F>(h);
-        Pt ub = part_at(w, (u32)b);
-        xyzz_add<F>(h, ub);
-      }
-      for (int i = 0; i < log2L0; i++) h = xyzz_dbl<F>(h);
-      Pt asum = part_at(w, (u32)nbits);
-      xyzz_add<F>(h, asum);
-      T[(size_t)w] = h;
-    };
+    auto window = [&](int w) { T[(size_t)w] = msm_host_window_sum<C>(parts, Q, nbits, log2L0, w); };
     const int nt = Wr < 8 ? Wr : 8;
     std::vector<std::thread> th;
     for (int t = 1; t < nt; t++)
       th.emplace_back([&, t]() { for (int w = t; w < Wr; w += nt) window(w); });
     for (int w = 0; w < Wr; w += nt) window(w);
     for (auto& x : th) x.join();
-    Pt total = T[(size_t)Wr - 1];
-    for (int w = Wr - 2; w >= 0; w--) {
-      for (int i = off[w]; i < off[w + 1]; i++) total = xyzz_dbl<F>(total);   // the width of window w
-      xyzz_add<F>(total, T[(size_t)w]);
-    }
-    return total;
+    return msm_host_combine_windows<C>(T.data(), Wr, off);
   }
   int top = 0;
   for (int w = 0; w < Wr; w++) top = std::max(top, off[w] + log2L0 + nbits - 1);
@@ -2311,10 +2326,53 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     if (out_xyz) Jac<F>::zero().store(out_xyz);
     return 0;
   }
-  ARK_HIP_TRY(msm_wait_event(job.done));
   const MsmPlan& pl = job.pl;
   const int c = pl.c, W = pl.W, Wr = pl.red_windows(), nbits = job.nbits;
   const u32 Q = job.Q;
+  // Short jobs (round 5): the tail -- ~5400 field products over Fp384, 0.2 ms -- is a fifth of a 2^16 call, and half of it is
+  // the windows' own sums, which are independent.  Threads started for them once the parts are here cost more than they save
+  // (1.01 -> 1.12 ms, profiles/r5_g2_host_tail_threads.txt); started BEFORE the wait for the GPU their creation hides under the
+  // kernels, and they spin until the parts have landed (a millisecond or two of up to seven cores: short jobs only, and only
+  // while the GPU is still working -- a finished job keeps the single Horner).  ARK_HIP_HOST_TAIL_THREADS=0: never.
+  struct EarlyTail {
+    std::vector<std::thread> th;
+    std::vector<Pt> T;
+    std::atomic<int> go{0};   // 0: wait, 1: the parts are in job.pinned, -1: no tail after all
+    ~EarlyTail() {
+      int expect = 0;
+      go.compare_exchange_strong(expect, -1);
+      for (auto& x : th) x.join();
+    }
+  } early;
+  static const bool early_env = [] { const char* e = getenv("ARK_HIP_HOST_TAIL_THREADS"); return !(e && e[0] == '0'); }();
+  int early_nt = 0;
+  if (early_env && out_xyz && !job.no_result && job.short_job && Wr >= 8 && hipEventQuery(job.done) == hipErrorNotReady) {
+    (void)hipGetLastError();
+    early_nt = 8;
+    early.T.resize((size_t)Wr);
+    const char* parts = (const char*)job.pinned;
+    const int l0 = job.log2L0;
+    try {
+      for (int t = 1; t < early_nt; t++)
+        early.th.emplace_back([&early, parts, Q, nbits, l0, Wr, t, nt = early_nt]() {
+          int g;
+          while ((g = early.go.load(std::memory_order_acquire)) == 0) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+          }
+          if (g < 0) return;
+          for (int w = t; w < Wr; w += nt) early.T[(size_t)w] = msm_host_window_sum<C>(parts, Q, nbits, l0, w);
+        });
+    } catch (...) {   // no threads to be had: the single Horner
+      early.go.store(-1, std::memory_order_release);
+      for (auto& x : early.th) x.join();
+      early.th.clear();
+      early.go.store(0);
+      early_nt = 0;
+    }
+  }
+  ARK_HIP_TRY(msm_wait_event(job.done));
   const u32 h_err = *(const u32*)((const char*)job.pinned + job.npairs * Pt::BYTES);
   if (h_err) return -4;  // scalar out of range
   if (job.no_result) {  // a non-final piece of a streamed MSM: out_xyz untouched
@@ -2330,7 +2388,16 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     std::vector<int> off((size_t)Wr + 1);
     off[0] = 0;
     for (int w = 0; w < Wr; w++) off[w + 1] = off[w] + msm_window_width(w, c, W, pl.narrow);
-    const Pt total = msm_host_fold<C>((const char*)job.pinned, Q, Wr, nbits, job.log2L0, off.data());
+    Pt total;
+    if (early_nt) {
+      early.go.store(1, std::memory_order_release);
+      for (int w = 0; w < Wr; w += early_nt) early.T[(size_t)w] = msm_host_window_sum<C>((const char*)job.pinned, Q, nbits, job.log2L0, w);
+      for (auto& x : early.th) x.join();
+      early.th.clear();
+      total = msm_host_combine_windows<C>(early.T.data(), Wr, off.data());
+    } else {
+      total = msm_host_fold<C>((const char*)job.pinned, Q, Wr, nbits, job.log2L0, off.data());
+    }
     xyzz_to_jac<F>(total).store(out_xyz);
   }
 
