@@ -24,6 +24,8 @@
  * Environment: ARK_HIP_WAIT=block makes an MSM wait for the GPU with a blocking hipEventSynchronize; by default the
  * calling thread polls the completion event (the MSM is on its caller's critical path; a sleeping thread was measured
  * to add up to 1 ms per call on some hosts).  ARK_HIP_MSM_C / ARK_HIP_MSM_C_PREPARED force the window size (tuning).
+ * ARK_HIP_HOST_TAIL_THREADS=0: the host tail of an MSM on the calling thread alone (by default a SHORT job -- up to ~2^18 pairs --
+ * keeps up to seven more threads spinning for its last millisecond or two so that the windows' own sums run in parallel).
  * ARK_HIP_COPY_THREADS=n (default 0 = the HIP runtime's own pageable path): n worker threads stage uploads from ordinary
  * host memory through page-locked buffers.  ARK_HIP_STREAM_PIECES: pieces a host-scalar MSM is cut into (default
  * n / 2^18, at most 8).  ARK_HIP_BASE_CACHE_MB / ARK_HIP_AUTO_PREPARE: see ark_hip_msm_cache_config.
