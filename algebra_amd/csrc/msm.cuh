@@ -1428,6 +1428,8 @@ static inline MsmPlan msm_make_plan(size_t n, int bits, double mul_cost, bool sh
         // (round 5 refit, profiles/r5_g2_window_sweep.txt: the lane-pair kernels of round 4 reduce 1.97e6 buckets in 4.6 ms,
         // 4.98e6 in 10.6, 1.36e7 in 23 -- 1.7 ns per bucket beyond the first 1.2e6, not the 1.25 of the saturated kernels this
         // line was fitted on; the old figure made c = 19 look 1.7 ms cheaper than it is and cost BLS12-377 G2 2^20 14 %)
+        // (the L0 = 16 rule of the same round made 2.8e5 .. 9.8e5 buckets 0.3-0.5 ms cheaper than this line says; a refit on that moved
+        // 2^20 to c = 17 and lost 8 % on BLS12-381 G2 -- 9.72 against 8.98 ms, profiles/r5_window_sweep_mid_sizes.txt -- so it stays)
         red0 = 0.45e-3 + (nbk < 1.2e6 ? nbk : 1.2e6) * 2.6e-9 + (nbk > 1.2e6 ? nbk - 1.2e6 : 0.0) * 1.7e-9;
         bits_stage = 0.0;
       }
@@ -1787,6 +1789,11 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     // of L0 = 8, whose 245 760 split lanes do not fit and whose one-wave form walks 16 steps: reduction 1.18 -> 0.95 ms,
     // 2^21 6.35 -> 5.99 ms, 2^22 11.20 -> 10.82 (profiles/r5_reduce_geometry_sweep.txt, session r5rs2)
     if (Wr > 1 && C::FA::LANES == 1 && nbr > ((size_t)1 << 19) && nbr <= ((size_t)1 << 20)) L0 = 16;
+    // (round 5) the lane-pair curves (G2) from 2^18 to 2^20 buckets (c = 15 .. 17: 2^17 .. 2^21 pairs): their bit-sliced stage is the
+    // expensive half, and twice the chain for half the pairs pays -- BLS12-377 G2 reduction 1.58 -> 1.28 ms at 2.8e5 buckets
+    // (2^18: 4.65 -> 4.25 ms), 1.70 -> 1.38 at 5.2e5 (2^19 6.69 -> 6.30, 2^20 10.49 -> 10.10; BLS12-381 G2 2^20 10.13 -> 9.64),
+    // 2.93 -> 2.46 at 9.8e5 (2^21 18.04 -> 17.52); at 1.6e5 buckets L0 = 8 stays the best cell (same sweeps, sessions r5g2r / r5g2r2)
+    if (Wr > 1 && C::FA::LANES == 2 && nbr > ((size_t)1 << 18) && nbr <= ((size_t)1 << 20)) L0 = 16;
     if (const char* e0 = getenv("ARK_HIP_MSM_L0")) {  // tuning knob
       int v = atoi(e0);
       if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L0 = (u32)v;

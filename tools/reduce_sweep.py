@@ -46,9 +46,9 @@ for logn in [int(x) for x in sys.argv[2:]]:
         os.environ.pop(k, None)
     ms, red, ok = run()
     print("%s 2^%d plan %s: library choice %.3f ms (reduce %.3f)%s" % (curve, logn, A.msm_plan(cid, n), ms, red, "" if ok else " WRONG"), flush=True)
-    for l0 in ((1, 2, 4, 8, 16) if logn < 22 else (8, 16, 32, 64)):
+    for l0 in ((1, 2, 4, 8, 16) if logn < 16 else (4, 8, 16, 32) if logn < 22 else (8, 16, 32, 64)):
         line = "  L0=%-2d" % l0
-        for ch in ((256, 512, 1024, 2048, 4096) if logn < 22 else (1024, 2048, 4096, 8192)):
+        for ch in ((256, 512, 1024, 2048, 4096) if logn < 16 else (512, 1024, 2048) if logn < 22 else (1024, 2048, 4096, 8192)):
             os.environ["ARK_HIP_MSM_L0"] = str(l0)
             os.environ["ARK_HIP_MSM_CHUNK"] = str(ch)
             ms, red, ok = run()
