@@ -1789,11 +1789,19 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     // of L0 = 8, whose 245 760 split lanes do not fit and whose one-wave form walks 16 steps: reduction 1.18 -> 0.95 ms,
     // 2^21 6.35 -> 5.99 ms, 2^22 11.20 -> 10.82 (profiles/r5_reduce_geometry_sweep.txt, session r5rs2)
     if (Wr > 1 && C::FA::LANES == 1 && nbr > ((size_t)1 << 19) && nbr <= ((size_t)1 << 20)) L0 = 16;
-    // (round 5) the lane-pair curves (G2) from 2^18 to 2^20 buckets (c = 15 .. 17: 2^17 .. 2^21 pairs): their bit-sliced stage is the
+    // (round 5) the lane-pair curves (G2) from 2^18 buckets (c >= 15: 2^17 pairs and up): their bit-sliced stage is the
     // expensive half, and twice the chain for half the pairs pays -- BLS12-377 G2 reduction 1.58 -> 1.28 ms at 2.8e5 buckets
     // (2^18: 4.65 -> 4.25 ms), 1.70 -> 1.38 at 5.2e5 (2^19 6.69 -> 6.30, 2^20 10.49 -> 10.10; BLS12-381 G2 2^20 10.13 -> 9.64),
     // 2.93 -> 2.46 at 9.8e5 (2^21 18.04 -> 17.52); at 1.6e5 buckets L0 = 8 stays the best cell (same sweeps, sessions r5g2r / r5g2r2)
-    if (Wr > 1 && C::FA::LANES == 2 && nbr > ((size_t)1 << 18) && nbr <= ((size_t)1 << 20)) L0 = 16;
+    // -- and the same holds further up: 9.8e5 buckets L0 = 32 (2.46 -> 2.13 ms); 3.7e6 (2^22, c = 19) L0 = 64 on BLS12-377 G2 (13 of
+    // its 14 windows are narrow: 4.32 -> 3.95 ms, session r5g2l) but 32 on BLS12-381 G2 (11 narrow: 5.85 against 6.5 ms, r5g2l3).
+    // One rule covers every cell measured: the power of two at or above buckets / 32 768, from 8 to 32 (BLS12-377: 64).
+    if (Wr > 1 && C::FA::LANES == 2 && nbr > ((size_t)1 << 18)) {
+      const u32 cap = C::S::BITS == 253 ? 64u : 32u;
+      u32 g = 8;
+      while (g < cap && (size_t)g * 32768 < nbr) g <<= 1;
+      L0 = g;
+    }
     if (const char* e0 = getenv("ARK_HIP_MSM_L0")) {  // tuning knob
       int v = atoi(e0);
       if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) L0 = (u32)v;
