@@ -226,6 +226,34 @@ struct Fp {
     for (int i = 0; i < N; i++) r.l[i] = P::R[i];
     return r;
   }
+#if !defined(__HIP_DEVICE_COMPILE__)
+  // host-only helpers: the element on 64-bit limbs (N is even for every field here)
+  static_assert(N % 2 == 0, "64-bit host limbs");
+  static constexpr u64 host_p(int i) { return ((u64)P::P[2 * i + 1] << 32) | P::P[2 * i]; }
+  static void host_limbs(const Fp& a, u64* x) {
+    for (int i = 0; i < N / 2; i++) x[i] = ((u64)a.l[2 * i + 1] << 32) | a.l[2 * i];
+  }
+  static Fp host_from_limbs(const u64* x) {
+    Fp r;
+    for (int i = 0; i < N / 2; i++) {
+      r.l[2 * i] = (u32)x[i];
+      r.l[2 * i + 1] = (u32)(x[i] >> 32);
+    }
+    return r;
+  }
+  static Fp host_reduce_once(const u64* t) {   // t < 2p: t - p if that is not negative
+    u64 d[N / 2];
+    unsigned long long bw = 0;
+    for (int i = 0; i < N / 2; i++) d[i] = __builtin_subcll(t[i], host_p(i), bw, &bw);
+    Fp r;
+    for (int i = 0; i < N / 2; i++) {
+      const u64 v = bw ? t[i] : d[i];
+      r.l[2 * i] = (u32)v;
+      r.l[2 * i + 1] = (u32)(v >> 32);
+    }
+    return r;
+  }
+#endif
   ARK_HD bool is_zero() const {
     u32 o = 0;
 #pragma unroll
@@ -242,6 +270,13 @@ struct Fp {
   // Carry chains are written with __builtin_addc/__builtin_subc: hipcc lowers them to one
   // v_add_co/v_addc_co (v_sub_co/v_subb_co) per limb.
   ARK_HD static Fp reduce_once(const u32* t) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {   // host (the MSM's serial tail): the same on 64-bit limbs -- the 32-bit carry chains below cost the host more than its products
+      u64 x[N / 2];
+      for (int i = 0; i < N / 2; i++) x[i] = ((u64)t[2 * i + 1] << 32) | t[2 * i];
+      return host_reduce_once(x);
+    }
+#endif
     u32 d[N];
     u32 borrow = 0;
 #pragma unroll
@@ -256,6 +291,16 @@ struct Fp {
     return r;
   }
   ARK_HD static Fp add(const Fp& a, const Fp& b) {  // montgomery_backend.rs:129-136
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+      u64 x[N / 2], y[N / 2];
+      host_limbs(a, x);
+      host_limbs(b, y);
+      unsigned long long c = 0;
+      for (int i = 0; i < N / 2; i++) x[i] = __builtin_addcll(x[i], y[i], c, &c);
+      return host_reduce_once(x);   // (a + b < 2p < 2^(32 N): no carry out)
+    }
+#endif
     u32 t[N];
     u32 c = 0;
 #pragma unroll
@@ -267,6 +312,15 @@ struct Fp {
     return reduce_once(t);
   }
   ARK_HD static Fp dbl(const Fp& a) {  // montgomery_backend.rs:151-171
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+      u64 x[N / 2];
+      host_limbs(a, x);
+      for (int i = N / 2 - 1; i > 0; i--) x[i] = (x[i] << 1) | (x[i - 1] >> 63);
+      x[0] <<= 1;
+      return host_reduce_once(x);
+    }
+#endif
     u32 t[N];
 #pragma unroll
     for (int i = N - 1; i > 0; i--) t[i] = (a.l[i] << 1) | (a.l[i - 1] >> 31);
@@ -274,6 +328,19 @@ struct Fp {
     return reduce_once(t);
   }
   ARK_HD static Fp sub(const Fp& a, const Fp& b) {  // montgomery_backend.rs:138-149
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+      u64 x[N / 2], y[N / 2];
+      host_limbs(a, x);
+      host_limbs(b, y);
+      unsigned long long bw = 0;
+      for (int i = 0; i < N / 2; i++) x[i] = __builtin_subcll(x[i], y[i], bw, &bw);
+      const u64 mask = 0ull - (u64)bw;
+      unsigned long long c = 0;
+      for (int i = 0; i < N / 2; i++) x[i] = __builtin_addcll(x[i], host_p(i) & mask, c, &c);
+      return host_from_limbs(x);
+    }
+#endif
     u32 d[N];
     u32 borrow = 0;
 #pragma unroll
@@ -294,6 +361,18 @@ struct Fp {
     return r;
   }
   ARK_HD static Fp neg(const Fp& a) {  // 0 stays 0 (fp/mod.rs Neg)
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+      u64 x[N / 2], r[N / 2];
+      host_limbs(a, x);
+      u64 nz64 = 0;
+      for (int i = 0; i < N / 2; i++) nz64 |= x[i];
+      const u64 mask = nz64 ? ~0ull : 0ull;
+      unsigned long long bw = 0;
+      for (int i = 0; i < N / 2; i++) r[i] = __builtin_subcll(host_p(i) & mask, x[i], bw, &bw);
+      return host_from_limbs(r);
+    }
+#endif
     u32 nz = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) nz |= a.l[i];
@@ -352,12 +431,7 @@ struct Fp {
       t[M - 1] = (u64)c;
       t[M] = t[M + 1] + (u64)(c >> 64);
     }
-    u32 tt[N];
-    for (int i = 0; i < M; i++) {
-      tt[2 * i] = (u32)t[i];
-      tt[2 * i + 1] = (u32)(t[i] >> 32);
-    }
-    return reduce_once(tt);
+    return host_reduce_once(t);
 #endif
   }
   ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }  // montgomery_backend.rs:250-317
