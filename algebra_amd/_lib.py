@@ -132,6 +132,7 @@ SYMBOLS = {
     "ark_hip_fft_last_timing": (C.c_int, [C.POINTER(C.c_double)]),
     "ark_hip_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_test_basefield_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ark_hip_test_host_basefield_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_test_point_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_test_msm_sharded_emulated": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.POINTER(C.c_int)]),

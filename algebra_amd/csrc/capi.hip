@@ -535,6 +535,26 @@ XYZZ<F> jac_to_xyzz(const uint64_t* p) {
   F zz = F::sqr(z);
   return XYZZ<F>{x, y, zz, F::mul(zz, z)};
 }
+// The HOST builds of the base field's arithmetic (fp.cuh: 64-bit limbs; what the MSM's serial tail runs on), element by
+// element on the calling thread: no GPU involved.  op as ark_hip_test_basefield_op (0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 dbl).
+template <class F>
+static void host_field_ops(int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n) {
+  constexpr size_t W = F::BYTES / 8;
+  for (size_t i = 0; i < n; i++) {
+    const F x = F::load(a + i * W);
+    const F y = b ? F::load(b + i * W) : F::zero();
+    F z;
+    switch (op) {
+      case 0: z = F::add(x, y); break;
+      case 1: z = F::sub(x, y); break;
+      case 2: z = F::mul(x, y); break;
+      case 3: z = F::sqr(x); break;
+      case 4: z = F::neg(x); break;
+      default: z = F::dbl(x); break;
+    }
+    z.store(r + i * W);
+  }
+}
 // the MSM's host tail on caller-supplied bit sums (ark_hip_test_msm_host_fold)
 template <class C>
 int host_fold(const uint64_t* parts, int windows, int nbits, int log2_l0, const int* widths, uint64_t* out_xyz) {
@@ -2970,6 +2990,20 @@ int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64
   if (curve < 0 || curve > 4 || !a || !r || op < 0 || op > 5) return ARK_HIP_ERR_ARG;
   size_t fb = (size_t)CURVES[curve].fe_words * 8;
   return run_elementwise(n * fb, b ? n * fb : 0, n * fb, a, b, r, basefield_op_fn(curve), op, n);
+}
+
+int ark_hip_test_host_basefield_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n) {
+  if (curve < 0 || curve > 4 || !a || !r || op < 0 || op > 5 || (op <= 2 && !b)) return ARK_HIP_ERR_ARG;
+  switch (curve) {
+#ifndef ARK_HIP_DEV
+    case ARK_HIP_BN254_G1: host_field_ops<BN254_G1::F>(op, a, b, r, n); return 0;
+    case ARK_HIP_BLS12_377_G1: host_field_ops<BLS12_377_G1::F>(op, a, b, r, n); return 0;
+    case ARK_HIP_BLS12_377_G2: host_field_ops<BLS12_377_G2::F>(op, a, b, r, n); return 0;
+    case ARK_HIP_BLS12_381_G2: host_field_ops<BLS12_381_G2::F>(op, a, b, r, n); return 0;
+#endif
+    case ARK_HIP_BLS12_381_G1: host_field_ops<BLS12_381_G1::F>(op, a, b, r, n); return 0;
+  }
+  return ARK_HIP_ERR_ARG;
 }
 
 int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64_t* other, uint64_t* out, size_t n) {

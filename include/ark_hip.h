@@ -402,6 +402,9 @@ int ark_hip_fft_last_timing(double out[10]);
  * the carry-free 28-bit-limb form of the accumulate kernels (device product, square, sum of two products) */
 int ark_hip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
 int ark_hip_test_basefield_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
+/* the same ops (0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 dbl) through the HOST builds of the field arithmetic -- what the MSM's serial
+ * tail runs on (64-bit limbs) -- on the calling thread: no GPU involved */
+int ark_hip_test_host_basefield_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
 /* kind: 2 bucket += affine, 3 bucket -= affine, 4 bucket += bucket, 5 bucket double, 6 bucket -> jacobian,
  * 7 affine double_to_bucket.  acc/other/out are arrays of n elements. */
 int ark_hip_test_point_op(int curve, int kind, const uint64_t* acc, const uint64_t* other, uint64_t* out, size_t n);

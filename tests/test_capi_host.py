@@ -373,3 +373,44 @@ def test_verified_cache_tag_is_keyed_128_bits_and_sees_what_the_round4_hash_miss
     z = np.zeros(8192 * 2, dtype=np.uint64)
     assert _tag(z) != _tag(z[:8192]) and _tag(z) != 0
     assert len({_tag(rng.integers(0, 1 << 62, size=64, dtype=np.uint64)) for _ in range(200)}) == 200
+
+
+@pytest.mark.parametrize("cname", O.CURVES)
+def test_host_field_arithmetic_on_edge_values(cname):
+    # The MSM's serial tail runs on the HOST builds of the base field's arithmetic (fp.cuh: products, additions, subtractions,
+    # doublings and negation on 64-bit limbs -- montgomery_backend.rs:129-246 restated twice, once per side).  Edge values where a
+    # carry / borrow / the final subtraction decides: 0, 1, 2, p - 1, p - 2, (p - 1) / 2, (p + 1) / 2, limbs of all ones below p,
+    # and seeded random elements, every pair of them through add / sub / mul and each one through sqr / neg / dbl -- against the oracle.
+    import ctypes as C
+    cid = O.CID[cname]
+    bf, sf, ext = O.curve_info(cid)
+    fw = O.fe_words(cid)
+    comp = fw // ext                                   # words per Fp component
+    p = sum(int(v) << (64 * k) for k, v in enumerate(O.field_const(bf, 0)))
+    rng = np.random.default_rng(20240925)
+    ints = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << (64 * (comp - 1))) - 1, ((1 << (p.bit_length() - 1)) - 1),
+            1 << 64, (1 << 64) - 1, p - (1 << 64)] + [int.from_bytes(rng.bytes(8 * comp), "little") % p for _ in range(6)]
+
+    def elem(vals):                                     # ext components, canonical integers -> Montgomery limbs as the library holds them
+        raw = np.array([[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(comp)] for v in vals], dtype=np.uint64).reshape(-1)
+        return raw
+    # treat the integers as Montgomery residues directly: every N-limb value below p is a valid element
+    elems = []
+    for i, v in enumerate(ints):
+        elems.append(elem([v] + [ints[(i * 7 + 3) % len(ints)]] * (ext - 1)))
+    m = len(elems)
+    a = np.stack([elems[i] for i in range(m) for _ in range(m)])
+    b = np.stack([elems[j] for _ in range(m) for j in range(m)])
+    L = _lib.lib()
+    for op in ("add", "sub", "mul"):
+        got = np.zeros_like(a)
+        assert L.ark_hip_test_host_basefield_op(cid, O.OPS[op], a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                got.ctypes.data_as(C.c_void_p), a.shape[0]) == 0
+        assert np.array_equal(got.reshape(-1), O.basefield_op(cid, op, a, b)), (cname, op)
+    one = np.stack(elems)
+    for op in ("sqr", "neg", "dbl"):
+        got = np.zeros_like(one)
+        assert L.ark_hip_test_host_basefield_op(cid, O.OPS[op], one.ctypes.data_as(C.c_void_p), None,
+                                                got.ctypes.data_as(C.c_void_p), one.shape[0]) == 0
+        assert np.array_equal(got.reshape(-1), O.basefield_op(cid, op, one)), (cname, op)
+    assert L.ark_hip_test_host_basefield_op(cid, 0, one.ctypes.data_as(C.c_void_p), None, None, 1) != 0   # argument check
