@@ -414,3 +414,26 @@ def test_host_field_arithmetic_on_edge_values(cname):
                                                 got.ctypes.data_as(C.c_void_p), one.shape[0]) == 0
         assert np.array_equal(got.reshape(-1), O.basefield_op(cid, op, one)), (cname, op)
     assert L.ark_hip_test_host_basefield_op(cid, 0, one.ctypes.data_as(C.c_void_p), None, None, 1) != 0   # argument check
+
+
+def test_msm_plan_is_defined_for_every_size():
+    # the cost model divides by bucket counts, takes exp / sqrt / ldexp of loads and rounds: every size from 1 to 2^28 pairs -- the rule
+    # boundaries of the small-n plan (256, 20 480, 24 576, 73 728) and their neighbours included -- must give a layout that covers the scalar,
+    # keeps the sort's 32-bit positions and does not depend on anything but (curve, n, prepared)
+    import ctypes as C
+    L = _lib.lib()
+    bits = {0: 254, 1: 255, 2: 253, 3: 253, 4: 255}
+    sizes = sorted(set([1, 2, 3, 5, 17, 100, 255, 256, 257, 1000, 4095, 4096, 20479, 20480, 20481, 24575, 24576, 24577, 65535, 65536, 65537,
+                        73727, 73728, 73729, 100000] + [(1 << k) + d for k in range(17, 29) for d in (-1, 0, 1)]))
+    for curve in range(5):
+        for prepared in (0, 1):
+            for n in sizes:
+                if n > (1 << 28):
+                    continue
+                c, w = C.c_int(), C.c_int()
+                assert L.ark_hip_msm_plan(curve, n, prepared, C.byref(c), C.byref(w)) == 0
+                assert 3 <= c.value <= 26 and 1 <= w.value <= 90, (curve, prepared, n, c.value, w.value)
+                assert c.value * w.value >= bits[curve], (curve, prepared, n, c.value, w.value)
+                assert n * w.value < (1 << 32), (curve, prepared, n, c.value, w.value)
+                c2, w2 = C.c_int(), C.c_int()
+                assert L.ark_hip_msm_plan(curve, n, prepared, C.byref(c2), C.byref(w2)) == 0 and (c2.value, w2.value) == (c.value, w.value)
