@@ -69,6 +69,7 @@ SYMBOLS = {
     "ark_hip_shutdown": (None, []),
     "ark_hip_synchronize": (C.c_int, []),
     "ark_hip_version": (C.c_char_p, []),
+    "ark_hip_host_threads": (C.c_int, [C.POINTER(C.c_int)]),
     "ark_hip_curve_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
     "ark_hip_malloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "ark_hip_free": (C.c_int, [C.c_void_p]),

@@ -874,51 +874,86 @@ inline Hash128 nh_block(const uint64_t* p, size_t words, uint64_t a, uint64_t b,
   const unsigned __int128 r = acc0 + acc1;
   return Hash128{(uint64_t)r, (uint64_t)(r >> 64)};
 }
+// The first level runs as ranges of blocks on the process-wide helper pool (hostpool.hpp) together with the calling thread
+// -- rounds 4-5 created up to eight threads per pass.  ARK_HIP_HASH_THREADS (default 8) caps the number of ranges in flight
+// by cutting the pass into that many ranges per "wave"; the pool's size bounds the threads whatever it says.
 int hash_threads() {
   static int nt = -1;
   if (nt < 0) {
     const char* e = getenv("ARK_HIP_HASH_THREADS");
     int v = e ? atoi(e) : 8;
-    const int hw = (int)std::thread::hardware_concurrency();
-    if (hw > 0 && v > hw) v = hw;
+    if (v > 64) v = 64;
     nt = v < 1 ? 1 : v;
   }
   return nt;
 }
-Hash128 base_hash(const uint64_t* p, size_t words) {
-  const HashKey& hk = hash_key();
-  const size_t nblocks = (words + HASH_BLOCK_WORDS - 1) / HASH_BLOCK_WORDS;
-  std::vector<Hash128> bh(nblocks);
-  auto range = [&](size_t b0, size_t b1) {
+struct HashPass {   // one pass over a host slice: first-level block hashes by ranges, then the second level
+  const uint64_t* p = nullptr;
+  size_t words = 0, nblocks = 0, per = 0;
+  int nranges = 0;
+  std::vector<Hash128> bh;
+  std::atomic<int> left{0};
+  std::chrono::steady_clock::time_point t0, t1;
+  HostPool::Handle batch;
+  static void task(void* ctx, int r) {
+    HashPass& h = *(HashPass*)ctx;
+    const HashKey& hk = hash_key();
+    const size_t b0 = (size_t)r * h.per, b1 = b0 + h.per < h.nblocks ? b0 + h.per : h.nblocks;
     for (size_t b = b0; b < b1; b++) {
       const size_t off = b * HASH_BLOCK_WORDS;
-      bh[b] = nh_block(p + off, words - off < HASH_BLOCK_WORDS ? words - off : HASH_BLOCK_WORDS, (uint64_t)b, (uint64_t)words, hk.k);
+      h.bh[b] = nh_block(h.p + off, h.words - off < HASH_BLOCK_WORDS ? h.words - off : HASH_BLOCK_WORDS, (uint64_t)b,
+                         (uint64_t)h.words, hk.k);
     }
-  };
-  int nt = hash_threads();
-  if (nblocks < 64) nt = 1;
-  if (nt <= 1) {
-    range(0, nblocks);
-  } else {
-    std::vector<std::thread> th;
-    const size_t per = (nblocks + (size_t)nt - 1) / (size_t)nt;
-    for (int t = 1; t < nt; t++) {
-      const size_t b0 = (size_t)t * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-      if (b0 < b1) th.emplace_back(range, b0, b1);
-    }
-    range(0, per < nblocks ? per : nblocks);
-    for (auto& t : th) t.join();
+    if (h.left.fetch_sub(1, std::memory_order_acq_rel) == 1) h.t1 = std::chrono::steady_clock::now();
   }
-  // second level: NH over the block values with a key stream of its own (generated on the fly: 2 words per block)
-  unsigned __int128 acc = 0;
-  uint64_t st = hk.seed2;
-  for (size_t b = 0; b < nblocks; b++) {
+  // lay the pass out and let the pool's helpers start on it; the caller goes on with its own work
+  void begin(const uint64_t* p_, size_t words_) {
+    p = p_;
+    words = words_;
+    nblocks = (words + HASH_BLOCK_WORDS - 1) / HASH_BLOCK_WORDS;
+    bh.resize(nblocks);
+    // ranges of >= 16 blocks (1 MiB), several per thread so that a late helper still finds work
+    size_t nr = nblocks / 16;
+    const size_t cap = (size_t)hash_threads() * 4;
+    if (nr > cap) nr = cap;
+    if (nr < 1 || hash_threads() <= 1) nr = 1;
+    nranges = (int)nr;
+    per = (nblocks + nr - 1) / nr;
+    if (per < 1) per = 1;
+    nranges = (int)((nblocks + per - 1) / per);
+    if (nranges < 1) nranges = 1;
+    left.store(nranges);
+    t0 = t1 = std::chrono::steady_clock::now();
+    batch = HostPool::instance().open(&HashPass::task, this, nranges);
+    if (batch) HostPool::instance().start_async(batch);
+  }
+  // join: finish what is left on this thread, then the second level.  ms: duration of the pass (start to last block).
+  Hash128 end(double* ms) {
+    if (batch) {
+      HostPool::instance().run(batch);
+      batch.reset();
+    } else {   // no pool: the pass runs here, after the work it could not hide under (its own duration is what is reported)
+      t0 = std::chrono::steady_clock::now();
+      for (int r = 0; r < nranges; r++) task(this, r);
+    }
+    if (ms) *ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    const HashKey& hk = hash_key();
+    // second level: NH over the block values with a key stream of its own (generated on the fly: 2 words per block)
+    unsigned __int128 acc = 0;
+    uint64_t st = hk.seed2;
+    for (size_t b = 0; b < nblocks; b++) {
+      const uint64_t k0 = splitmix64(st), k1 = splitmix64(st);
+      acc += (unsigned __int128)(bh[b].lo + k0) * (bh[b].hi + k1);
+    }
     const uint64_t k0 = splitmix64(st), k1 = splitmix64(st);
-    acc += (unsigned __int128)(bh[b].lo + k0) * (bh[b].hi + k1);
+    acc += (unsigned __int128)((uint64_t)words + k0) * ((uint64_t)nblocks + k1);
+    return Hash128{(uint64_t)acc, (uint64_t)(acc >> 64)};
   }
-  const uint64_t k0 = splitmix64(st), k1 = splitmix64(st);
-  acc += (unsigned __int128)((uint64_t)words + k0) * ((uint64_t)nblocks + k1);
-  return Hash128{(uint64_t)acc, (uint64_t)(acc >> 64)};
+};
+Hash128 base_hash(const uint64_t* p, size_t words) {
+  HashPass h;
+  h.begin(p, words);
+  return h.end(nullptr);
 }
 
 void cache_configure(Context* c) {
@@ -1087,12 +1122,10 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
   const Clk::time_point t_call = Clk::now();
   Hash128 h;
   double hash_ms = 0;
-  std::thread hasher([&h, &hash_ms, bases, n, wpp, ms_since]() {
-    const Clk::time_point t0 = Clk::now();
-    h = base_hash(bases, n * wpp);
-    hash_ms = ms_since(t0);
-  });
-  auto hash_done = [&]() {   // after hasher.join(): fold this pass into the smoothed rate
+  HashPass pass;   // the pool's helpers hash the slice while this thread runs the MSM; join_hash() finishes what is left
+  pass.begin(bases, n * wpp);
+  auto join_hash = [&]() { h = pass.end(&hash_ms); };
+  auto hash_done = [&]() {   // after join_hash(): fold this pass into the smoothed rate
     c->cache_stats.last_hash_ms = hash_ms;
     if (hash_ms > 0) {
       const double r = (double)bytes / hash_ms, old = c->cache_stats.hash_bytes_per_ms;
@@ -1107,7 +1140,7 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
     }
     idx = cache_find_exact(c, curve, bases, n, false);
     int rc = run(c->base_cache[(size_t)idx].dev.p, false, &c->base_cache[(size_t)idx]);   // speculative
-    hasher.join();
+    join_hash();
     hash_done();
     BaseCacheEntry& e = c->base_cache[(size_t)idx];
     if (h == e.hash) {
@@ -1136,7 +1169,7 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
   ne.n = n;
   ne.last_use = c->cache_clock;
   if (!cache_make_room(c, (long long)(bytes + bytes / 8 + 256)) || ne.dev.ensure(bytes)) {
-    hasher.join();   // no room on the device right now: not an error, the bases stream instead
+    join_hash();   // no room on the device right now: not an error, the bases stream instead
     hash_done();
     return run(nullptr, false, nullptr);
   }
@@ -1144,7 +1177,7 @@ int msm_with_bases(Context* c, int curve, const uint64_t* bases, size_t n, Run r
   c->base_cache.push_back(ne);
   const int rc = run(ne.dev.p, true, nullptr);
   const double fill_ms = ms_since(t_call);   // bases + scalars over PCIe under the call's kernels: the streamed call's cost
-  hasher.join();
+  join_hash();
   hash_done();
   if (rc) {
     cache_forget(c, curve, bases, n, false);
@@ -1682,7 +1715,13 @@ int ark_hip_synchronize(void) {
   return 0;
 }
 
-const char* ark_hip_version(void) { return "ark_hip 0.3 (gfx950)"; }
+const char* ark_hip_version(void) { return "ark_hip 0.4 (gfx950)"; }
+int ark_hip_host_threads(int out[2]) {
+  if (!out) return ARK_HIP_ERR_ARG;
+  out[0] = HostPool::instance().helpers();
+  out[1] = HostPool::instance().threads_created();
+  return 0;
+}
 
 int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_field, int* ext_degree) {
   if (curve < 0 || curve > 4) return ARK_HIP_ERR_ARG;
@@ -2178,6 +2217,19 @@ int ark_hip_msm_sw_chunks(int curve, const uint64_t* bases, size_t n_bases, cons
   return msm_stream(sc.c, curve, nullptr, b0, scalars, n_scalars, 1, step, out_xyz, false);
 }
 
+// fn(g) for every device g < n_gpus, each on its own persistent host thread (DeviceThreads, hostpool.hpp); device 0's share on
+// the calling thread.  Without threads to be had the shares run one after another.
+extern "C++" {
+template <class Fn>
+static void for_each_device(int n_gpus, Fn&& fn) {
+  struct Tr {
+    Fn* f;
+    static void call(void* ctx, int g) { (*((Tr*)ctx)->f)(g); }
+  } tr{&fn};
+  if (!DeviceThreads::instance().run(n_gpus, &Tr::call, &tr))
+    for (int g = 0; g < n_gpus; g++) fn(g);
+}
+}
 // One MSM over the GPUs of this node from ONE host process: base-range shards (the reference's own split,
 // variable_base/mod.rs:521-557), one host thread and one context per device, partials (3 field elements each) summed
 // on the host.  The data path has no collective: RCCL would add nothing to a 144-byte exchange inside one process.
@@ -2188,14 +2240,13 @@ int ark_hip_msm_sw_multi_device(int curve, int n_gpus, const void* const* d_base
   const size_t pw = (size_t)CURVES[curve].fe_words * 3;
   std::vector<uint64_t> partials((size_t)n_gpus * pw);
   std::vector<int> rcs((size_t)n_gpus, 0);
-  std::vector<std::thread> th;
-  for (int g = 0; g < n_gpus; g++)
-    th.emplace_back([&, g]() {
-      int rc = ark_hip_set_device(g);
-      if (rc == 0) rc = ark_hip_msm_sw_device(curve, d_bases[g], d_scalars[g], n_per_gpu[g], mont, &partials[(size_t)g * pw]);
-      rcs[(size_t)g] = rc;
-    });
-  for (auto& t : th) t.join();
+  const int caller_dev = ark_hip_get_device();
+  for_each_device(n_gpus, [&](int g) {
+    int rc = ark_hip_set_device(g);
+    if (rc == 0) rc = ark_hip_msm_sw_device(curve, d_bases[g], d_scalars[g], n_per_gpu[g], mont, &partials[(size_t)g * pw]);
+    rcs[(size_t)g] = rc;
+  });
+  if (caller_dev >= 0) (void)ark_hip_set_device(caller_dev);   // share 0 ran on this thread
   for (int g = 0; g < n_gpus; g++)
     if (rcs[(size_t)g]) return rcs[(size_t)g];
   return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);
@@ -2207,16 +2258,15 @@ int ark_hip_msm_sw_multi(int curve, int n_gpus, const uint64_t* bases, const uin
   const size_t pw = (size_t)CURVES[curve].fe_words * 3, aw = (size_t)CURVES[curve].fe_words * 2;
   std::vector<uint64_t> partials((size_t)n_gpus * pw);
   std::vector<int> rcs((size_t)n_gpus, 0);
-  std::vector<std::thread> th;
-  for (int g = 0; g < n_gpus; g++)
-    th.emplace_back([&, g]() {
-      const size_t q = n / (size_t)n_gpus, r = n % (size_t)n_gpus;
-      const size_t lo = (size_t)g * q + ((size_t)g < r ? (size_t)g : r), cnt = q + ((size_t)g < r ? 1 : 0);
-      int rc = ark_hip_set_device(g);
-      if (rc == 0) rc = ark_hip_msm_sw(curve, bases + lo * aw, scalars + lo * 4, cnt, mont, &partials[(size_t)g * pw]);
-      rcs[(size_t)g] = rc;
-    });
-  for (auto& t : th) t.join();
+  const int caller_dev = ark_hip_get_device();
+  for_each_device(n_gpus, [&](int g) {
+    const size_t q = n / (size_t)n_gpus, r = n % (size_t)n_gpus;
+    const size_t lo = (size_t)g * q + ((size_t)g < r ? (size_t)g : r), cnt = q + ((size_t)g < r ? 1 : 0);
+    int rc = ark_hip_set_device(g);
+    if (rc == 0) rc = ark_hip_msm_sw(curve, bases + lo * aw, scalars + lo * 4, cnt, mont, &partials[(size_t)g * pw]);
+    rcs[(size_t)g] = rc;
+  });
+  if (caller_dev >= 0) (void)ark_hip_set_device(caller_dev);   // share 0 ran on this thread
   for (int g = 0; g < n_gpus; g++)
     if (rcs[(size_t)g]) return rcs[(size_t)g];
   return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);
@@ -2239,18 +2289,14 @@ int ark_hip_msm_prepared_multi(int n_gpus, const ark_hip_msm_bases* const* shard
   const size_t pw = (size_t)CURVES[curve].fe_words * 3;
   std::vector<uint64_t> partials((size_t)n_gpus * pw);
   std::vector<int> rcs((size_t)n_gpus, 0);
-  std::vector<std::thread> th;
-  size_t lo = 0;
-  for (int g = 0; g < n_gpus; g++) {
+  std::vector<size_t> los((size_t)n_gpus, 0);
+  for (int g = 1; g < n_gpus; g++) los[(size_t)g] = los[(size_t)g - 1] + ((const PreparedBases*)shards[g - 1])->n;
+  for_each_device(n_gpus, [&](int g) {
     const PreparedBases* pb = (const PreparedBases*)shards[g];
+    const size_t lo = los[(size_t)g];
     const size_t cnt = lo >= n ? 0 : (n - lo < pb->n ? n - lo : pb->n);
-    const uint64_t* sc = scalars + lo * 4;
-    th.emplace_back([&, g, cnt, sc]() {
-      rcs[(size_t)g] = ark_hip_msm_prepared(shards[g], sc, cnt, mont, &partials[(size_t)g * pw]);  // runs on the shard's device
-    });
-    lo += pb->n;
-  }
-  for (auto& t : th) t.join();
+    rcs[(size_t)g] = ark_hip_msm_prepared(shards[g], scalars + lo * 4, cnt, mont, &partials[(size_t)g * pw]);  // runs on the shard's device
+  });
   for (int g = 0; g < n_gpus; g++)
     if (rcs[(size_t)g]) return rcs[(size_t)g];
   return ark_hip_sw_sum(curve, partials.data(), (size_t)n_gpus, out_xyz);

@@ -78,7 +78,7 @@ ARK_HD XYZZ<Fp<P>> lazy_to_bucket(const XYZZL<P>& a) {
 // affine doubling (mdbl-2008-s-1, a = 0), all in 28-bit limbs; x2, y2 the operands of lazy_from_affine (< 256 p).  Rare
 // branch (equal points in one bucket): out of line so that its registers do not burden the hot loops.
 template <class P>
-__host__ __device__ __attribute__((noinline)) void xyzz_mdbl_lazy_xy(XYZZL<P>& acc, const FpL<P>& x2, const FpL<P>& y2) {
+ARK_COLD_HD void xyzz_mdbl_lazy_xy(XYZZL<P>& acc, const FpL<P>& x2, const FpL<P>& y2) {
   typedef FpL<P> F;
   const F one = F::one();
   const F x1 = F::mul(x2, one);                                   // < 1.13 (n)
@@ -99,7 +99,7 @@ __host__ __device__ __attribute__((noinline)) void xyzz_mdbl_lazy_xy(XYZZL<P>& a
 // the same for the base at `src` (reference layout, canonical limbs; neg: the digit's sign): the accumulate kernels'
 // form -- it re-reads the base, so that nothing of their hot loop has to stay alive for a doubling that almost never comes
 template <class P>
-__host__ __device__ __attribute__((noinline)) void xyzz_mdbl_lazy(XYZZL<P>& acc, const char* src, bool neg) {
+ARK_COLD_HD void xyzz_mdbl_lazy(XYZZL<P>& acc, const char* src, bool neg) {
   const Affine<Fp<P>> b = Affine<Fp<P>>::load(src);
   FpL<P> x2, y2;
   lazy_from_affine<P>(b.x, Fp<P>::cond_neg(b.y, neg), x2, y2);
@@ -152,7 +152,7 @@ ARK_HD bool xyzz_madd_lazy(XYZZL<P>& acc, const FpL<P>& x2, const FpL<P>& y2) {
 //   U1 = X1 ZZ2 < 5.01 * 256 / 2048 + 1 < 1.63, U2 = X2 ZZ1 < 1.13, S1 = Y1 ZZZ2 < 1.15, S2 = Y2 ZZZ1 < 1.13  (n)
 //   P = U2 - U1 + 2p in (0.37, 3.13), R = S2 - S1 + 2p in (0.85, 3.13)  (s);  PP < 1.01, PPP, Q < 1.01  (n)
 //   X3 = R^2 - PPP - 2 Q + 4p in (0.99, 5.01) (n);  Y3 < (3.13 * 7.01 + 2 * 1.01) / 2048 + 1 < 1.02;  ZZ3, ZZZ3 < 1.01
-// equal points (P = R = 0 mod p): the doubling goes through the canonical form and the saturated formulas (rare).
+// equal points (P = R = 0 mod p): xyzz_dbl_lazy, in place (rare).
 template <class P>
 struct XYZZOperands { FpL<P> x, y, zz, zzz; bool inf; };
 template <class P>
@@ -165,10 +165,20 @@ ARK_HD XYZZOperands<P> lazy_operands_of(const XYZZ<Fp<P>>& b) {   // a stored bu
   r.zzz = FpL<P>::unpack32_shl(b.zzz.l);
   return r;
 }
+// acc = 2 acc (dbl-2008-s-1, a = 0; bucket.rs:112-146) for an accumulator that is not at infinity, in 28-bit limbs: X3 and
+// Y3 of the XYZZ doubling are functions of (X1, Y1) alone -- exactly the affine doubling's -- and ZZ3 = V ZZ1, ZZZ3 = W ZZZ1
+// with the V, W it leaves in zz / zzz.  acc.x < 5.07, acc.y < 1.23 (n) are legal operands of xyzz_mdbl_lazy_xy (< 256 p), whose
+// first two products bring them below 1.13 again.  (Rounds 3-5 went through the canonical form and the saturated formulas, out
+// of line: the accumulator handed to that call lived in scratch memory.)
 template <class P>
-__host__ __device__ __attribute__((noinline)) void xyzz_dbl_via_canonical(XYZZL<P>& acc) {
-  const XYZZ<Fp<P>> c = lazy_to_bucket<P>(acc);
-  acc = lazy_from_bucket<P>(xyzz_dbl<Fp<P>>(c));
+ARK_COLD_HD void xyzz_dbl_lazy(XYZZL<P>& acc) {
+  typedef FpL<P> F;
+  XYZZL<P> d;
+  xyzz_mdbl_lazy_xy<P>(d, acc.x, acc.y);
+  acc.zz = F::mul(d.zz, acc.zz);                                  // < 1.01
+  acc.zzz = F::mul(d.zzz, acc.zzz);                               // < 1.01
+  acc.x = d.x;
+  acc.y = d.y;
 }
 template <class P>
 ARK_HD void xyzz_add_lazy(XYZZL<P>& acc, const FpL<P>& bx, const FpL<P>& by, const FpL<P>& bzz, const FpL<P>& bzzz, bool binf) {
@@ -192,9 +202,7 @@ ARK_HD void xyzz_add_lazy(XYZZL<P>& acc, const FpL<P>& bx, const FpL<P>& by, con
   const F pp = F::sqr(pd);
   if (pp.is_zero_or_p()) {
     if (F::sqr(rd).is_zero_or_p()) {
-      XYZZL<P> d = acc;   // a copy goes out of line (an accumulator whose address escapes would live in scratch memory)
-      xyzz_dbl_via_canonical<P>(d);
-      acc = d;
+      xyzz_dbl_lazy<P>(acc);
     } else {
       acc.inf = true;
     }

@@ -1,7 +1,7 @@
 // Bucket additions over Fp2 (G2) on carry-free 28-bit limbs, one element per lane pair (fp28x2.cuh).
 //
 // Formulas and branches: ec/src/models/short_weierstrass/bucket.rs:168-238 (madd-2008-s), :256-337 (add-2008-s); equal
-// points go through the canonical form and the saturated lane-pair formulas (ec.cuh over Fp2Half; rare).  Bases and buckets
+// points are doubled in the same limbs (lazy2_mdbl / lazy2_dbl below; rare).  Bases and buckets
 // live in HBM in the reference's canonical radix-2^384 form; a gathered coordinate enters by the shifted repack (the
 // residue itself in radix 2^392, below 256 p: Fp2L::from_canonical) as the B operand of a product whose A operand is one of
 // the accumulator's small coordinates; buckets leave through a division by 2^8 mod p (Fp2L::to_canonical).
@@ -46,21 +46,50 @@ ARK_DEV XYZZ<typename FL2::M> lazy2_to_bucket(const XYZZL2<FL2>& a) {
   return XYZZ<M>{a.x.to_canonical(), a.y.to_canonical(), a.zz.to_canonical(), a.zzz.to_canonical()};  // x: 7.2 / 256 + 1 < 2
 }
 
-// acc = 2 (base at `src`, canonical layout; neg: the digit's sign): the saturated lane-pair doubling, out of line
+// ---- doubling (equal points in one bucket: duplicate bases only) -- mdbl-2008-s-1 / dbl-2008-s-1 with a = 0
+// (affine.rs:169-201, bucket.rs:112-146) on the lane pair's carry-free limbs, expanded in place.  (Rounds 4-5 went through the
+// canonical form and the saturated lane-pair formulas out of line; the accumulator handed to that call lived in scratch.)
+// acc = 2 (x1, y1) for an affine point with both coordinates normalised and below 1.5 p:
+//   U = 2 Y1 < 2.3 (n);  V = U^2: c0 < 3.1 (s), c1 < 1.01;  W = U V < (2.3 * 3.1 + NB 4 * 1.01) / R' + 1 < 1.02;  S = X1 V < 1.01;
+//   XX = X1^2 brought below 1.01 by a product with 1;  M = 3 XX < 3.03 (n);  M^2: c0 < 3.1 (s), c1 < 1.01;
+//   X3 = M^2 - 2 S + 4p in (1.9, 7.1) (n);  t = S - X3 + 8p in (0.9, 7.12) (n);  Y3 = M t - Y1 W < 1.04 (as the mixed addition's)
 template <class FL2>
-__device__ __attribute__((noinline)) void lazy2_mdbl(XYZZL2<FL2>& acc, const char* src, bool neg) {
+ARK_COLD_DEV void lazy2_mdbl_small(XYZZL2<FL2>& acc, const FL2& x1, const FL2& y1) {
+  typedef FL2 F;
+  typedef typename F::B B;
+  const F u = F{B::template sub<0>(B::add_lazy(y1.v, y1.v), B::zero())};
+  const F v = F::template sqr<4>(u);
+  const F w = F::template mul<4>(u, v);
+  const F s = F::template mul<2>(x1, v);
+  const F xx = F::reduce_small(F::template sqr<2>(x1));
+  const F m = F{B::template sub<0>(B::add_lazy(B::add_lazy(xx.v, xx.v), xx.v), B::zero())};
+  const F x3 = F::template sub_b_2c_norm<4>(F::template sqr<4>(m), F::zero(), s);
+  const F t = F::template sub_sweep<8>(s, x3);
+  acc.y = F::template mul_sub<4, 2>(m, t, y1, w);
+  acc.x = x3;
+  acc.zz = F::reduce_small(v);                                    // < 1.01, normalised (V's c0 is semi-normalised)
+  acc.zzz = w;
+  acc.inf = false;
+}
+// acc = 2 (base at `src`, canonical layout; neg: the digit's sign): the accumulate kernels' form -- it re-reads the base, so
+// that nothing of their hot loop has to stay alive for a doubling that almost never comes
+template <class FL2>
+ARK_COLD_DEV void lazy2_mdbl(XYZZL2<FL2>& acc, const char* src, bool neg) {
   typedef typename FL2::M M;
   const Affine<M> b = Affine<M>::load(src);
-  acc = lazy2_from_bucket<FL2>(xyzz_mdbl<M>(b.x, M::cond_neg(b.y, neg)));
+  lazy2_mdbl_small<FL2>(acc, FL2::reduce_small(FL2::from_canonical(b.x)),
+                        FL2::reduce_small(FL2::from_canonical(M::cond_neg(b.y, neg))));
 }
+// acc = 2 acc for an accumulator that is not at infinity: X3, Y3 are the affine doubling's of (X1, Y1); ZZ3 = V ZZ1, ZZZ3 = W ZZZ1
 template <class FL2>
-__device__ __attribute__((noinline)) void lazy2_mdbl_xy(XYZZL2<FL2>& acc, const typename FL2::M& x, const typename FL2::M& y) {
-  acc = lazy2_from_bucket<FL2>(xyzz_mdbl<typename FL2::M>(x, y));
-}
-template <class FL2>
-__device__ __attribute__((noinline)) void lazy2_dbl_via_canonical(XYZZL2<FL2>& acc) {
-  typedef typename FL2::M M;
-  acc = lazy2_from_bucket<FL2>(xyzz_dbl<M>(lazy2_to_bucket<FL2>(acc)));
+ARK_COLD_DEV void lazy2_dbl(XYZZL2<FL2>& acc) {
+  typedef FL2 F;
+  XYZZL2<FL2> d;
+  lazy2_mdbl_small<FL2>(d, F::reduce_small(acc.x), acc.y);        // x < 7.2 -> 1.01; y < 1.11
+  acc.zz = F::template mul<2>(d.zz, acc.zz);                      // < 1.01
+  acc.zzz = F::template mul<2>(d.zzz, acc.zzz);                   // < 1.01
+  acc.x = d.x;
+  acc.y = d.y;
 }
 
 // acc += (x2, y2): a non-identity base (Fp2L::from_canonical: n, < 256; the digit's sign already in y2).  Returns true when
@@ -141,9 +170,7 @@ ARK_DEV void xyzz_add_lazy2(XYZZL2<FL2>& acc, const FL2& bx, const FL2& by, cons
     bool rz;
     (void)F::template sqr<4>(rd, &rz);
     if (rz) {
-      XYZZL2<FL2> d = acc;   // a copy goes out of line (an accumulator whose address escapes would live in scratch memory)
-      lazy2_dbl_via_canonical<FL2>(d);
-      acc = d;
+      lazy2_dbl<FL2>(acc);
     } else {
       acc.inf = true;
     }

@@ -25,6 +25,19 @@ typedef uint64_t u64;
 
 #define ARK_DEV __device__ __forceinline__
 #define ARK_HD __host__ __device__ __forceinline__
+// The equal-points branch of a bucket addition (a doubling: duplicate bases only).  ARK_COLD_INLINE=1 (default since round 6)
+// expands it in place so that no kernel carries a call frame in scratch memory; 0 restores the out-of-line calls of rounds
+// 3-5 (an accumulator handed to a call by reference lives in scratch: 240-368 B per lane) for A/B builds.
+#ifndef ARK_COLD_INLINE
+#define ARK_COLD_INLINE 1
+#endif
+#if ARK_COLD_INLINE
+#define ARK_COLD_HD __host__ __device__ __forceinline__
+#define ARK_COLD_DEV __device__ __forceinline__
+#else
+#define ARK_COLD_HD __host__ __device__ __attribute__((noinline))
+#define ARK_COLD_DEV __device__ __attribute__((noinline))
+#endif
 
 // ---- 96-bit column accumulator --------------------------------------------------------------
 // One product step: {lo64, hi32} += A * B.  FIRST opens a column: the carry initialises the top word (0 + 0 + carry),

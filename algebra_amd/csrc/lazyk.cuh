@@ -34,17 +34,6 @@ struct LazyK<C, 1> {
     return xyzz_madd_lazy<P>(acc, lx, ly);
   }
   ARK_HD static void mdbl(Acc& out, const char* src, bool neg) { xyzz_mdbl_lazy<P>(out, src, neg); }
-  // acc += (x, y) with the doubling handled here (the heavy-run kernels: no memory copy of the base to re-read); the
-  // doubling itself stays OUT OF LINE -- inlined, its registers cost the heavy-run kernel a wave of occupancy
-  ARK_HD static void madd_xy(Acc& acc, const FM& x, const FM& y) {
-    FL lx, ly;
-    lazy_from_affine<P>(x, y, lx, ly);
-    if (xyzz_madd_lazy<P>(acc, lx, ly)) {
-      Acc d;
-      xyzz_mdbl_lazy_xy<P>(d, lx, ly);
-      acc = d;
-    }
-  }
   ARK_HD static void add(Acc& acc, const XYZZ<FM>& b) {
     const XYZZOperands<P> o = lazy_operands_of<P>(b);
     xyzz_add_lazy<P>(acc, o.x, o.y, o.zz, o.zzz, o.inf);
@@ -93,13 +82,6 @@ struct LazyK<C, 2> {
     return xyzz_madd_lazy2<FL>(acc, FL::from_canonical(p.x), FL::from_canonical(FM::cond_neg(p.y, neg)));
   }
   ARK_DEV static void mdbl(Acc& out, const char* src, bool neg) { lazy2_mdbl<FL>(out, src, neg); }
-  ARK_DEV static void madd_xy(Acc& acc, const FM& x, const FM& y) {
-    if (xyzz_madd_lazy2<FL>(acc, FL::from_canonical(x), FL::from_canonical(y))) {
-      Acc d;
-      lazy2_mdbl_xy<FL>(d, x, y);
-      acc = d;
-    }
-  }
   ARK_DEV static void add(Acc& acc, const XYZZ<FM>& b) {
     const XYZZOperands2<FL> o = lazy2_operands_of<FL>(b);
     xyzz_add_lazy2<FL>(acc, o.x, o.y, o.zz, o.zzz, o.inf);

