@@ -131,6 +131,11 @@ SYMBOLS = {
     "ark_hip_fft_set_kernel": (C.c_int, [C.c_int]),
     "ark_hip_fft_set_timing": (C.c_int, [C.c_int]),
     "ark_hip_fft_last_timing": (C.c_int, [C.POINTER(C.c_double)]),
+}
+
+# the test hooks: exported by libark_hip_test.so only (the same objects as libark_hip.so + csrc/capi_test.hip); declared in
+# include/ark_hip.h under ARK_HIP_TEST_HOOKS
+TEST_SYMBOLS = {
     "ark_hip_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_test_basefield_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ark_hip_test_host_basefield_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -140,8 +145,10 @@ SYMBOLS = {
     "ark_hip_test_base_hash": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "ark_hip_test_msm_host_fold": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
+TEST_LIB_PATH = os.path.join(_HERE, "libark_hip_test.so")
 
 _lib = None
+_test_lib = None
 
 
 def lib():
@@ -161,17 +168,40 @@ def lib():
         except ImportError:
             pass
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            try:
-                fn = getattr(l, name)  # AttributeError if the library does not export it
-            except AttributeError:
-                if os.environ.get("ARK_HIP_LIB"):   # an A/B build of an older revision (tools/): its entries only
-                    continue
-                raise
-            fn.restype = res
-            fn.argtypes = args
+        _bind(l, SYMBOLS, not os.environ.get("ARK_HIP_LIB"))   # an A/B build of an older revision (tools/): its entries only
         _lib = l
     return _lib
+
+
+def _bind(l, table, strict):
+    for name, (res, args) in table.items():
+        try:
+            fn = getattr(l, name)  # AttributeError if the library does not export it
+        except AttributeError:
+            if not strict:
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+
+
+def test_lib():
+    """libark_hip_test.so: the product library's objects PLUS the ark_hip_test_* hooks (device field / point arithmetic, the
+    host tail, the hashing pass) -- for tests/ and tools/ only.  A separate shared object, hence a separate library instance
+    (its own contexts and helper pool) next to lib()."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise ImportError("algebra_amd: %s not found (run `make -C algebra_amd/csrc -j8`)" % TEST_LIB_PATH)
+        try:
+            import torch  # noqa: F401  (one HIP runtime per process: see lib())
+        except ImportError:
+            pass
+        l = C.CDLL(TEST_LIB_PATH)
+        _bind(l, SYMBOLS, True)
+        _bind(l, TEST_SYMBOLS, True)
+        _test_lib = l
+    return _test_lib
 
 
 def check(code, what):

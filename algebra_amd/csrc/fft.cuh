@@ -107,8 +107,10 @@ static constexpr int FFT_MAX_EPT = 4;  // elements per lane: tiles of up to 1024
 #ifndef ARK_FFT_MIN_WAVES
 #define ARK_FFT_MIN_WAVES 1   // A/B builds: 5 caps the kernel at 96 registers (27 spilled) for a fifth workgroup per CU
 #endif
-template <class FP>
-__global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
+// TH: threads per workgroup = a quarter of the largest tile (256: 1024-element tiles, 32 KiB of LDS, four workgroups per CU;
+// 512 / 1024: 2048- / 4096-element tiles of the round-6 plans with fewer passes -- 64 / 128 KiB, two / one per CU)
+template <class FP, int TH = FFT_THREADS>
+__global__ void __launch_bounds__(TH, TH == FFT_THREADS ? ARK_FFT_MIN_WAVES : 1) fft_pass_kernel(const u32* __restrict__ src, u32* __restrict__ dst,
                                                                FftPassArgs a) {
   typedef Fp<FP> F;
   extern __shared__ uint4 lds[];
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
     size_t ps[FFT_MAX_EPT];
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT; it++) {
-      u32 e = tid + it * FFT_THREADS;
+      u32 e = tid + it * TH;
       if (e < E) {
         size_t pos;
         if (!a.last) {
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
     }
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT; it++) {
-      u32 e = tid + it * FFT_THREADS;
+      u32 e = tid + it * TH;
       if (e < E) {
         const size_t pos = ps[it];
         const size_t spos = a.zskip ? (pos & (((size_t)1 << (k - a.zskip)) - 1)) : pos;
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
     bool ha0[FFT_MAX_EPT / 4], hb[FFT_MAX_EPT / 4];
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
-      const u32 g = tid + it * FFT_THREADS;
+      const u32 g = tid + it * TH;
       ha0[it] = hb[it] = false;
       if (g < E / 4) {
         u32 gq, r;
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
     }
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT / 4; it++) {
-      const u32 g = tid + it * FFT_THREADS;
+      const u32 g = tid + it * TH;
       if (g < E / 4) {
         F x0 = fft_unpack<F>(pl0[idx[it][0]], pl1[idx[it][0]]);
         F x1 = fft_unpack<F>(pl0[idx[it][1]], pl1[idx[it][1]]);
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
     bool hasw[FFT_MAX_EPT / 2];
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT / 2; it++) {
-      u32 b = tid + it * FFT_THREADS;
+      u32 b = tid + it * TH;
       hasw[it] = false;
       if (b < E / 2) {
         u32 i0, i1;
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
     }
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT / 2; it++) {
-      u32 b = tid + it * FFT_THREADS;
+      u32 b = tid + it * TH;
       if (b < E / 2) {
         const u32 i0 = i0s[it], i1 = i1s[it];
         F lo = fft_unpack<F>(pl0[i0], pl1[i0]);
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
   if (!a.last) {
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT; it++) {
-      u32 e = tid + it * FFT_THREADS;
+      u32 e = tid + it * TH;
       if (e < E) {
         u32 q = e >> t, r = e & T1;
         size_t pos = ((size_t)hi_bits << (k - a.s0)) | ((size_t)q << lo_shift) | ((size_t)mid << t) | r;
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(FFT_THREADS, ARK_FFT_MIN_WAVES) fft_pass_kerne
     const size_t tile_rev = bitrev32(tile, tb);
 #pragma unroll
     for (int it = 0; it < FFT_MAX_EPT; it++) {
-      u32 e = tid + it * FFT_THREADS;
+      u32 e = tid + it * TH;
       if (e < E) {
         u32 r2 = e & T1, q2 = e >> t;  // output-side coordinates
         size_t opos = ((size_t)q2 << (k - kp)) | (tile_rev << t) | r2;
@@ -1205,6 +1207,24 @@ int fft_roots_run(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t st
 // post4:  inverse: h^-1 or nullptr;  postc4: constant multiplier of every output (size_inv) or nullptr
 // zlog:   degree-aware forward transform (fft.rs:29-71): only the first 2^(k - zlog) elements of d_data are input
 //         (the rest is treated as zero whatever it holds) and the first zlog stages are not executed; 0 = plain.
+// more than 64 KiB of dynamic LDS must be granted per function and device, once
+static inline hipError_t fft_allow_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, bool> done;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev)) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  bool& d = done[std::make_pair(fn, dev)];
+  if (d) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) d = true;
+  return e;
+}
+// tile size (log2 elements) of a transform of kx executed stages on the saturated kernel: see fft_run_device
+static inline int fft_default_tile_log(int kx) {
+  (void)kx;
+  return 10;
+}
 template <class FP>
 int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4,
                    const uint64_t* post4, const uint64_t* postc4, int zlog, hipStream_t stream, FftTimings* tm) {
@@ -1257,12 +1277,22 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
   // pass plan over the kx = k - zlog executed stages
   const int kx = k - zlog;
   int P, kps[8], t;
+  // tile size (log2 elements): 10 = the 1024-element tiles of rounds 1-5; 11 / 12 (round 6, saturated kernel only): 2048- /
+  // 4096-element tiles, i.e. up to 10 / 11 stages per pass -- 2^22 in TWO passes of 11 stages over 64-byte segments instead of
+  // three (8 + 8 + 6).  ARK_HIP_FFT_TILE_LOG forces one; the default follows fft_default_tile_log (measured)
+  int tile_log = 10;
+  if (!lazy29 && k > FFT_SINGLE_MAX) {
+    tile_log = fft_default_tile_log(kx);
+    if (const char* e = getenv("ARK_HIP_FFT_TILE_LOG"))
+      if (atoi(e) >= 10 && atoi(e) <= 12) tile_log = atoi(e);
+  }
   if (k <= FFT_SINGLE_MAX) {
     P = 1; kps[0] = k; t = 0;
   } else {
     int maxkp = FFT_MAX_KP;
     const char* env = getenv("ARK_HIP_FFT_KP");
     if (env && atoi(env) >= 5 && atoi(env) <= 8) maxkp = atoi(env);
+    if (tile_log > 10) maxkp = tile_log - 1;   // larger tiles: up to tile_log - 1 stages per pass over >= 2 adjacent columns
     P = (kx + maxkp - 1) / maxkp;
     int base = kx / P, rem = kx % P;
     for (int i = 0; i < P; i++) kps[i] = base + (i < rem ? 1 : 0);
@@ -1276,6 +1306,22 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
             kps[j]--;
             break;
           }
+    }
+    // an explicit plan (experiments): ARK_HIP_FFT_PLAN=12,10 -- stage counts per pass, each <= tile_log, summing to kx
+    if (const char* pe = getenv("ARK_HIP_FFT_PLAN")) {
+      int q[8], nq = 0, sum = 0;
+      bool ok = true;
+      for (const char* c = pe; *c && nq < 8;) {
+        q[nq] = atoi(c);
+        if (q[nq] < 1 || q[nq] > tile_log) ok = false;
+        sum += q[nq++];
+        while (*c && *c != ',') c++;
+        if (*c == ',') c++;
+      }
+      if (ok && sum == kx && nq >= 1) {
+        P = nq;
+        for (int i = 0; i < P; i++) kps[i] = q[i];
+      }
     }
     t = FFT_LANE_BITS;
   }
@@ -1295,8 +1341,9 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
     // fewer stages take more adjacent columns, i.e. longer contiguous segments
     int ti = t;
     if (P > 1) {
-      ti = 10 - kps[i];
-      if (ti < FFT_LANE_BITS) ti = FFT_LANE_BITS;
+      ti = tile_log - kps[i];
+      const int min_t = tile_log > 10 ? 0 : FFT_LANE_BITS;
+      if (ti < min_t) ti = min_t;
       const int room = (i == P - 1) ? (k - kps[i]) : (k - s0 - kps[i]);  // bits available for columns
       if (ti > room) ti = room;
     }
@@ -1332,7 +1379,16 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
       hipLaunchKernelGGL((fft_pass29_kernel<FP>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, pa);
     } else {
       size_t lds_bytes = ((size_t)2 << (kps[i] + ti)) * sizeof(uint4);
-      hipLaunchKernelGGL((fft_pass_kernel<FP>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, a);
+      const int tl = kps[i] + ti;
+      if (tl <= 10) {
+        hipLaunchKernelGGL((fft_pass_kernel<FP, 256>), dim3(tiles), dim3(256), lds_bytes, stream, src, dst, a);
+      } else if (tl == 11) {
+        ARK_HIP_TRY(fft_allow_lds((const void*)fft_pass_kernel<FP, 512>, 64 << 10));
+        hipLaunchKernelGGL((fft_pass_kernel<FP, 512>), dim3(tiles), dim3(512), lds_bytes, stream, src, dst, a);
+      } else {
+        ARK_HIP_TRY(fft_allow_lds((const void*)fft_pass_kernel<FP, 1024>, 128 << 10));
+        hipLaunchKernelGGL((fft_pass_kernel<FP, 1024>), dim3(tiles), dim3(1024), lds_bytes, stream, src, dst, a);
+      }
     }
     if (tm) ARK_HIP_TRY(hipEventRecord(ev[nev++], stream));
     s0 += kps[i];

@@ -1,14 +1,14 @@
-// Instantiation of the radix-2 FFT and the field-arithmetic test hook for BLS12_377_FR.
+// Instantiation of the radix-2 FFT and the pointwise field kernels for BLS12_377_FR.
 #include "fft.cuh"
-#include "testops.cuh"
+#include "devops.cuh"
 #include "internal.hpp"
 namespace arkhip {
 int fft_run_BLS12_377_FR(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4, const uint64_t* post4,
                const uint64_t* postc4, int zlog, hipStream_t stream, FftTimings* tm) {
   return fft_run_device<BLS12_377_FR>(ws, d_data, k, root4, pre4, post4, postc4, zlog, stream, tm);
 }
-int test_field_op_BLS12_377_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
-  return test_field_op_launch<Fp<BLS12_377_FR>, true>(op, a, b, r, n, s);
+int field_op_BLS12_377_FR(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
+  return field_op_launch<Fp<BLS12_377_FR>, true>(op, a, b, r, n, s);
 }
 int fft_roots_BLS12_377_FR(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t s, const uint32_t** out) {
   return fft_roots_run<BLS12_377_FR>(ws, k, root4, s, out);

@@ -44,7 +44,7 @@ ARK_DECL_CURVE(BLS12_381_G2)
 #define ARK_DECL_FIELD(NAME)                                                                                    \
   int fft_run_##NAME(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4, const uint64_t* pre4,         \
                      const uint64_t* post4, const uint64_t* postc4, int zlog, hipStream_t stream, FftTimings* tm);          \
-  int test_field_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);          \
+  int field_op_##NAME(int op, const void* d_a, const void* d_b, void* d_r, size_t n, hipStream_t s);          \
   int fr_scale_##NAME(const void* d_a, const uint64_t* k4, void* d_r, size_t n, hipStream_t s);                     \
   int fr_div_##NAME(const void* d_num, const void* d_den, void* d_r, size_t n, hipStream_t s);                      \
   int fft_roots_##NAME(FftWorkspace& ws, int k, const uint64_t* root4, hipStream_t s, const uint32_t** out);        \

@@ -1,8 +1,8 @@
-// Instantiation of the MSM pipeline and the point-arithmetic test hooks for BLS12_381_G1 (one TU per curve so
+// Instantiation of the MSM pipeline, the fixed-base batch multiplication and the point-array kernels for BLS12_381_G1 (one TU per curve so
 // the five heavy template expansions compile in parallel).
 #include "msm.cuh"
 #include "batchmul.cuh"
-#include "testops.cuh"
+#include "devops.cuh"
 #include "gfft.cuh"
 #include "internal.hpp"
 namespace arkhip {
@@ -29,12 +29,6 @@ int batchmul_build_BLS12_381_G1(const void* h_base_affine, int window, void* d_s
 size_t batchmul_build_scratch_BLS12_381_G1(int window) { return batchmul_build_scratch<BLS12_381_G1>(window); }
 int batchmul_run_BLS12_381_G1(const void* d_table, int window, const void* d_scalars, size_t n, int mont, void* d_tmp, void* d_out, hipStream_t s) {
   return batchmul_run<BLS12_381_G1>(d_table, window, d_scalars, n, mont, d_tmp, d_out, s);
-}
-int test_basefield_op_BLS12_381_G1(int op, const void* a, const void* b, void* r, size_t n, hipStream_t s) {
-  return test_field_op_launch<BLS12_381_G1::F, false>(op, a, b, r, n, s);
-}
-int test_point_op_BLS12_381_G1(int kind, const void* acc, const void* other, void* out, size_t n, hipStream_t s) {
-  return test_point_op_launch<BLS12_381_G1>(kind, acc, other, out, n, s);
 }
 int sw_add_affine_BLS12_381_G1(const void* in, void* out, size_t n, const void* d_delta, hipStream_t s) {
   return sw_add_affine_launch<BLS12_381_G1>(in, out, n, d_delta, s);

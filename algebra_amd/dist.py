@@ -7,7 +7,7 @@ reduction operator is elliptic-curve addition, which RCCL does not offer as a re
 all-gather (latency-bound, a few microseconds over xGMI):
   * inside the library (comm_init done, device-resident shards): every rank contributes its per-window PART SUMS
     (a 64-byte header + at most 1024 XYZZ points, ~40 KB) straight from device memory, one kernel adds the copies of
-    every part and ONE host tail runs on the sums of the whole job (capi.hip: ark_hip_msm_sw_device_sharded);
+    every part and ONE host tail runs on the sums of the whole job (csrc/capi_comm.hip: ark_hip_msm_sw_device_sharded);
   * on torch.distributed (gloo on CPU, or no library communicator): every rank contributes one finished Projective point
     (3 field elements: 144 B for BLS12-381 G1) and world_size - 1 point additions follow on the host.
 No other data-path collective exists: bases and scalars never leave their GPU.
@@ -80,7 +80,7 @@ def msm_sharded(curve, bases_shard, scalars_shard, group=None):
 
 
 # ---- the library's own RCCL communicator ------------------------------------------------------------------------------
-# The data-path collectives run INSIDE libark_hip.so (capi.hip, "one process per GPU"): torch.distributed is only the
+# The data-path collectives run INSIDE libark_hip.so (csrc/capi_comm.hip): torch.distributed is only the
 # control plane that carries rank 0's RCCL unique id to the other ranks -- exactly what an MPI or Rust host would do with
 # its own broadcast.  With the gloo backend (CPU tests, ranks sharing one GPU) there is no RCCL: the same algorithms run
 # with torch.distributed as the transport.

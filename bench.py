@@ -27,7 +27,9 @@ The roofline figures of the dominant kernel are measured with HIP events on the 
 
 Synthetic inputs (tools/synth.py): bases P_i = (a + i*b)*G grown on the GPU from the generator; uniform
 scalars in [0, r).  After timing, every result is checked bit-exactly against k*G with k = sum_i s_i (a + i b) mod r
-(exact big-integer identity).
+(exact big-integer identity) -- and k*G itself comes from the ORACLE's scalar multiplication (oracle/, CPU: independent of the
+device arithmetic; `kG_source` in the line says so), as the at-size tests take it.  oracle/ is test infrastructure: this file
+uses it as the checker and, in the two `cpu_baseline` legs, as the thing timed on the host -- never on the measured path.
 """
 import argparse
 import ctypes as C
@@ -72,6 +74,25 @@ limbs4 = S.limbs4
 
 def gen_scalars(n, seed):
     return S.gen_scalars(n, seed, R_MOD)
+
+
+_ORACLE = [None, "unset"]
+
+
+def kg_affine(cid, k, r):
+    """k*G as affine limbs, the expected value of every checked leg: from the oracle's scalar multiplication (CPU), or --
+    only when the oracle library is not there -- from the product's own 1-point MSM (the line's `kG_source` says which)."""
+    if _ORACLE[1] == "unset":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O  # test infrastructure: here only as the checker of the timed results
+            _ORACLE[0], _ORACLE[1] = O, "oracle/ scalar_mul on the host (independent of the device arithmetic)"
+        except Exception as e:  # noqa: BLE001
+            _ORACLE[0], _ORACLE[1] = None, "the product's own 1-point MSM (oracle library unavailable: %s)" % repr(e)[:80]
+    O = _ORACLE[0]
+    if O is None:
+        return S.mul_gen(cid, k, r)
+    return O.to_affine(cid, O.scalar_mul(cid, O.generator(cid), S.limbs4(k % r)))
 
 
 def fft_issue_bound(kf, nf, dev_ms):
@@ -125,7 +146,7 @@ def pmc_traffic(kernel, log_n):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json,
     produced by tools/pmc_traffic.py on this same command; FETCH_SIZE / WRITE_SIZE collected in separate passes,
     corrected as MI355X_MICROARCH.md prescribes).  None when no matching measurement is committed."""
-    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -286,7 +307,7 @@ def main():
             ks = [None] * world
             dist.all_gather_object(ks, k)
             k = sum(ks) % R_MOD
-        return S.mul_gen(cid, k, R_MOD) if rank == 0 else None
+        return kg_affine(cid, k, R_MOD) if rank == 0 else None
 
     def run_timed(local_msm, sc, warmup, steps, sharded=None):
         """K steps of: local MSM on this rank's shard, then (N > 1) all-gather of the partials + EC sum"""
@@ -322,21 +343,26 @@ def main():
         start_guard.cancel()
 
     # ---- the line is assembled by a closure over the legs' results, so that a watchdog can print what is there ------
-    prepared = pipelined = trait = config4 = others = fft = fft_sharded = cpu = None
+    prepared = pipelined = trait = config4 = others = fft = fft_sharded = cpu = sizes = None
     side_legs = {}
+
+    def accumulate_fracs(n_, ph):
+        """(HBM GB/s on algorithmic bytes, mixed additions, v_mad_u64_u32 lane-ops/s) of one accumulate launch"""
+        acc_ms_, W_, cbits_ = float(ph[3]), int(ph[7]), int(ph[6])
+        ach = 128.0 * n_ / (acc_ms_ * 1e-3) / 1e9  # algorithmic bytes: 96 B base + 32 B scalar per pair
+        # mixed additions actually executed by the accumulate kernel: one per (scalar, window) with a non-zero digit,
+        # minus the first point of every non-empty bucket (a copy, not an addition)
+        entries = n_ * W_ * (1.0 - 2.0 ** -cbits_)
+        nbuckets = W_ * (1 << (cbits_ - 1))
+        madds_ = entries - nbuckets * (1.0 - np.exp(-entries / nbuckets))
+        return ach, madds_, madds_ * MADS_PER_MIXED_ADD["lazy28" if LAZY else "saturated"] / (acc_ms_ * 1e-3)
 
     def build_line():
         acc_ms = float(phases[3])
         W = int(phases[7])
         cbits = int(phases[6])
-        achieved = 128.0 * n / (acc_ms * 1e-3) / 1e9  # algorithmic bytes: 96 B base + 32 B scalar per pair
-        # mixed additions actually executed by the accumulate kernel: one per (scalar, window) with a non-zero digit,
-        # minus the first point of every non-empty bucket (a copy, not an addition)
-        entries = n * W * (1.0 - 2.0 ** -cbits)
-        nbuckets = W * (1 << (cbits - 1))
-        madds = entries - nbuckets * (1.0 - np.exp(-entries / nbuckets))
+        achieved, madds, mads_per_s = accumulate_fracs(n, phases)
         mads_per_add = MADS_PER_MIXED_ADD["lazy28" if LAZY else "saturated"]
-        mads_per_s = madds * mads_per_add / (acc_ms * 1e-3)
         traffic, traffic_src = pmc_traffic(ACC_KERNEL, log_local)
         out = {
             "metric": "G1 scalar-muls/sec (MSM, 2^%d%s)" % (int(round(np.log2(n_total))), "" if world == 1 else
@@ -364,6 +390,7 @@ def main():
                        "pairs_per_gpu": n, "sharding": "base-range, %d rank(s), partials all-gathered" % world,
                        "exchange": exchange},
             "bit_exact_vs_kG": exact,
+            "kG_source": _ORACLE[1],
             "phases_ms": {"digits": phases[0], "partition_hist_scan": phases[1], "partition_sort_order": phases[2],
                           "accumulate": phases[3], "reduce": phases[4], "device_total": phases[5]},
             "roofline": {"bound": "hbm", "kernel": ACC_KERNEL,
@@ -378,7 +405,7 @@ def main():
                                  "mixed_additions": madds, "achieved": mads_per_s, "peak": MAD_U64_U32_PER_S,
                                  "frac": mads_per_s / MAD_U64_U32_PER_S,
                                  "two_waves": {"what": "the same instruction's issue rate at the kernel's occupancy (two "
-                                                       "waves per SIMD, 219 VGPRs)",
+                                                       "waves per SIMD, 211 VGPRs)",
                                                "peak": MAD_U64_U32_PER_S_TWO_WAVES,
                                                "frac": mads_per_s / MAD_U64_U32_PER_S_TWO_WAVES},
                                  "peak_source": "profiles/r3_issue_rates.txt: v_mad_u64_u32, four independent chains per "
@@ -390,6 +417,7 @@ def main():
             "prepared": prepared,
             "pipelined": pipelined,
             "config4_strong_2_26": config4 if world == 1 else "this line's `value` (N > 1: the headline IS config 4)",
+            "north_star_sizes": sizes,
             "other_scalings": side_legs if world > 1 else None,
             "other_configs": others,
             "fft": fft,
@@ -576,6 +604,37 @@ def main():
                     bpb.free()
                 except Exception as e:  # noqa: BLE001
                     config4["prepared"] = {"error": repr(e)[:200]}
+            # ---- the north star's size axis on one GPU: 2^20 .. 2^26, plain entry, each with its phase times, the accumulate
+            # kernel's HBM fraction (algorithmic bytes) and multiply-issue fraction, checked against k*G.  The inputs are
+            # PREFIXES of the 2^26 job's (P_i = (a + i b)G, i < 2^k; the first 2^k scalars), so nothing is generated twice.
+            if world == 1 and config4 is not None:
+                sizes = {}
+                for lg in range(20, LOG_CONFIG4 + 1):
+                    try:
+                        nk = 1 << lg
+                        bk, sk = bb[: nk * ab], bs[:nk]
+                        stk = 10 if lg <= 22 else (5 if lg <= 24 else 2)
+                        if lg == LOG_CONFIG4:
+                            res_k, el_k, ph_k, stk = res_b, el_b, ph_b, st
+                            wk = kb
+                        else:
+                            res_k, el_k, ph_k = run_timed(lambda sc: A.msm_bigint(cid, bk, sc), sk, 1, stk)
+                            wk = kg_affine(cid, S.dlog_of_msm(bsh[:nk], A0, B0, R_MOD), R_MOD)
+                        ach_k, madds_k, mads_k = accumulate_fracs(nk, ph_k)
+                        sizes["2^%d" % lg] = {
+                            "ms_per_step": el_k * 1e3 / stk, "value": nk * stk / el_k, "steps": stk,
+                            "window_bits": int(ph_k[6]), "windows": int(ph_k[7]),
+                            "phases_ms": {"digits": ph_k[0], "sort": ph_k[1] + ph_k[2], "accumulate": ph_k[3], "reduce": ph_k[4],
+                                          "device_total": ph_k[5]},
+                            "hbm_frac": ach_k / HBM_PEAK_GBPS, "alu_frac": mads_k / MAD_U64_U32_PER_S,
+                            "bit_exact_vs_kG": bool(np.array_equal(A.into_affine(cid, res_k), wk))}
+                    except Exception as e:  # noqa: BLE001
+                        sizes["2^%d" % lg] = {"error": repr(e)[:200]}
+                sizes["what"] = ("BLS12-381 G1 MSM, plain entry, device resident, one GPU: the north star's 2^20 .. 2^26 axis; "
+                                 "hbm_frac = 128 B x n / accumulate time / 8 TB/s, alu_frac = the accumulate kernel's "
+                                 "v_mad_u64_u32 lane-ops/s over the chip's best measured issue rate (as `roofline`); 2 / 4 / 8 "
+                                 "GPUs: UNMEASURED ON HARDWARE (no multi-GPU node in the build loop; the driver's SCALE run is "
+                                 "the measurement)")
             if nb_ != n:
                 del bb, bs
                 torch.cuda.empty_cache()
@@ -595,7 +654,7 @@ def main():
                 sh2 = S.gen_scalars(n2, 0xC0DE + lg, r2)
                 s2 = torch.from_numpy(sh2.view(np.int64)).cuda()
                 torch.cuda.synchronize()
-                kg2 = S.mul_gen(c2, S.dlog_of_msm(sh2, A0, B0, r2), r2)
+                kg2 = kg_affine(c2, S.dlog_of_msm(sh2, A0, B0, r2), r2)
                 p2 = A.PreparedBases(c2, b2)
                 entry = {}
                 for label, fn in (("plain", lambda: A.msm_bigint(c2, b2, s2)), ("prepared", p2.msm_bigint)):
@@ -646,7 +705,7 @@ def main():
                 sk_h = make()
                 sk = torch.from_numpy(sk_h.view(np.int64)).cuda()
                 torch.cuda.synchronize()
-                want = S.mul_gen(cid, S.dlog_of_msm(sk_h, A0, B0, R_MOD), R_MOD)
+                want = kg_affine(cid, S.dlog_of_msm(sk_h, A0, B0, R_MOD), R_MOD)
                 res_sk = A.msm_bigint(cid, bsk, sk)
                 t1 = time.perf_counter()
                 for _ in range(3):
@@ -804,7 +863,7 @@ def main():
         fft = {
             "metric": "BLS12-381 Fr radix-2 FFT elements/sec (2^%d, in place, device resident)" % kf,
             "value": nf / (fft_ms * 1e-3), "unit": "elements/s", "ms_per_step": fft_ms,
-            "ms_per_step_after_30ms_idle": fft_cold_ms,
+            "ms_per_step_after_30ms_idle": fft_cold_ms, "value_after_30ms_idle": nf / (fft_cold_ms * 1e-3),
             "timing": "%d transforms back to back on the library stream after 50 ms of the same transform (sustained clocks); "
                       "`ms_per_step_after_30ms_idle`: the same loop entered from an idle chip (round 4's figure: the power "
                       "state ramps for the first milliseconds)" % args.fft_steps,
@@ -888,16 +947,27 @@ def main():
             bases, scalars_h, scalars = make_inputs(ns, 0, 0xA11CE)
         hb = bases[: ns * ab].cpu().numpy().view(np.uint64).reshape(ns, -1)
         cores = usable_cores()
-        t1 = time.perf_counter()
-        ref = O.msm(O.CID[CURVE], hb, scalars_h[:ns], O.WNAF, cores)
-        cpu_s = time.perf_counter() - t1
+        # warm-up, then the median of repeated runs.  One small warm-up (2^20: page faults of the bucket arenas,
+        # thread start), then ARK_BENCH_CPU_REPS (default 3) runs of the sample; value = sample size / median
+        nw = min(ns, 1 << 20)
+        O.msm(O.CID[CURVE], hb[:nw], scalars_h[:nw], O.WNAF, cores)
+        reps = max(1, int(os.environ.get("ARK_BENCH_CPU_REPS", "3")))
+        runs = []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            ref = O.msm(O.CID[CURVE], hb, scalars_h[:ns], O.WNAF, cores)
+            runs.append(time.perf_counter() - t1)
+        cpu_s = float(np.median(runs))
         same = bool(np.array_equal(O.to_affine(O.CID[CURVE], ref),
                                    A.into_affine(cid, A.msm_bigint(cid, bases[: ns * ab], scalars[:ns]))))
         cpu = {"value": ns / cpu_s, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
-               "sample": "%s 2^%d of the same bases/scalars, msm_bigint_wnaf restatement (oracle/), %.1f s on %d threads "
+               "runs_s": runs,
+               "sample": "%s 2^%d of the same bases/scalars, msm_bigint_wnaf restatement (oracle/: a plain-C __int128 port, no "
+                         "assembly -- NOT ark-ec's own speed), one 2^%d warm-up then the median of %d runs: %.1f s on %d threads "
                          "(%d logical CPUs visible, affinity / cgroup quota allow %d); GPU result on the sample "
                          "bit-exact: %s"
-                         % ("all" if ns == n else "first", int(np.log2(ns)), cpu_s, cores, os.cpu_count() or 1, cores, same)}
+                         % ("all" if ns == n else "first", int(np.log2(ns)), int(np.log2(nw)), reps, cpu_s, cores,
+                            os.cpu_count() or 1, cores, same)}
 
     if watchdog is not None:
         watchdog.cancel()

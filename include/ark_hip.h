@@ -24,8 +24,9 @@
  * Environment: ARK_HIP_WAIT=block makes an MSM wait for the GPU with a blocking hipEventSynchronize; by default the
  * calling thread polls the completion event (the MSM is on its caller's critical path; a sleeping thread was measured
  * to add up to 1 ms per call on some hosts).  ARK_HIP_MSM_C / ARK_HIP_MSM_C_PREPARED force the window size (tuning).
- * ARK_HIP_HOST_TAIL_THREADS=0: the host tail of an MSM on the calling thread alone (by default a SHORT job -- up to ~2^18 pairs --
- * keeps up to seven more threads spinning for its last millisecond or two so that the windows' own sums run in parallel).
+ * ARK_HIP_HOST_TAIL_THREADS=k (default 7; 0: none): size of the ONE process-wide pool of parked helper threads that shares
+ * the short host-side tails with the calling thread -- the windows' own sums of a short MSM's tail, the verified cache's hashing
+ * pass.  Created on first use, never per call; see ark_hip_host_threads.
  * ARK_HIP_COPY_THREADS=n (default 0 = the HIP runtime's own pageable path): n worker threads stage uploads from ordinary
  * host memory through page-locked buffers.  ARK_HIP_STREAM_PIECES: pieces a host-scalar MSM is cut into (default
  * n / 2^18, at most 8).  ARK_HIP_BASE_CACHE_MB / ARK_HIP_AUTO_PREPARE: see ark_hip_msm_cache_config.
@@ -36,6 +37,11 @@
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
+#endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared between this push and the pop below are its
+ * dynamic symbols. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
 #endif
 
 /* field ids */
@@ -167,7 +173,10 @@ int ark_hip_msm_sw_device(int curve, const void* d_bases, const void* d_scalars,
                           uint64_t* out_xyz);
 /* Asynchronous form: the device work is enqueued and the call returns; ark_hip_msm_wait blocks until the result is
  * there, finishes it (window combine, a few hundred point operations on the host) and frees the job.  Up to 4 jobs
- * may be in flight per device (ARK_HIP_ERR_BUSY beyond).  Inputs must stay valid until the wait returns.
+ * may be in flight per device: an *_async entry reports ARK_HIP_ERR_BUSY beyond that, while the SYNCHRONOUS entries
+ * (ark_hip_msm_sw, _sw_device, _sw_small(_device), _prepared(_device), _prepared_small_device, _sw_chunks) wait for a slot
+ * -- they may be called from any number of host threads at once (the reference's callers are rayon pools) and never
+ * return BUSY.  Inputs must stay valid until the wait returns.
  * With a job already in flight the next one runs on the device's second MSM lane (own stream and workspace): its
  * digits / sort / reduction overlap the first job's accumulate kernel (two jobs in flight: +20 % MSMs/s at 2^20, +5 % at
  * 2^24).  Synchronous calls from one thread never use (or allocate) the second lane.
@@ -402,8 +411,11 @@ int ark_hip_fft_set_timing(int enable);
 /* [total_ms, npass, pass0_ms, pass1_ms, ...] of the last timed device transform */
 int ark_hip_fft_last_timing(double out[10]);
 
+#ifdef ARK_HIP_TEST_HOOKS
 /* ---- device-arithmetic test hooks (used by tests/ to check the kernels' field and point
  * arithmetic against the oracle; host pointers) ----
+ * Exported by libark_hip_test.so ONLY (the same objects as libark_hip.so + csrc/capi_test.hip; `make` builds both): the shipped
+ * library has no ark_hip_test_* symbol.  Declared when ARK_HIP_TEST_HOOKS is defined.
  * op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 dbl, 7 into_bigint, 8 from_bigint; 20 / 21 / 22: x y, x^2, 2 x y computed through
  * the carry-free 28-bit-limb form of the accumulate kernels (device product, square, sum of two products) */
 int ark_hip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n);
@@ -428,6 +440,11 @@ int ark_hip_test_base_hash(const uint64_t* p, size_t words, uint64_t out[2]);
 int ark_hip_test_msm_host_fold(int curve, const uint64_t* parts, int windows, int nbits, int log2_l0, const int* widths,
                                uint64_t* out_xyz);
 
+#endif /* ARK_HIP_TEST_HOOKS */
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,6 @@ pub mod msm;
 pub use ark_hip_sys as sys;
 pub use ark_hip_sys::{BLS12_377_G1, BLS12_377_G2, BLS12_381_G1, BLS12_381_G2, BN254_G1};
 pub use device::{DeviceError, DeviceEvaluations, DeviceVec};
-pub use msm::{sw_msm, sw_msm_bigint};
+pub use msm::{serve_group_coefficients, sw_msm, sw_msm_bigint, HipServed};
 #[cfg(feature = "ec-hook")]
 pub use msm::{sw_batch_mul, sw_msm_small, sw_normalize_batch};

@@ -15,6 +15,45 @@ use core::mem::{offset_of, size_of, MaybeUninit};
 
 type BigIntOf<P> = <<P as ark_ec::CurveConfig>::ScalarField as PrimeField>::BigInt;
 
+/// Marker of the curve configs libark_hip.so serves: `CURVE` is the library's id of THIS curve.
+///
+/// Every typed entry point of this module is bounded by it, so a config that has not declared itself served does not
+/// compile against them, and the id a call passes is checked against the declaration (rounds 3-5 trusted the integer and, for
+/// the transform over group elements, recognised `Projective<P>` by `core::any::type_name` strings).  Implemented by the
+/// patched curve crates behind their `hip` feature (patches/0002: one `unsafe impl` per config) and by [`hip_sw_config!`]
+/// for the wrapper configs of unmodified arkworks.
+///
+/// # Safety
+/// The implementor asserts that `CURVE` names this very curve in include/ark_hip.h -- the same base field, equation,
+/// scalar field and prime-order subgroup -- and that the config's `Affine` / `Projective` use `ZeroFlag = ()`: the library
+/// computes in the arithmetic of the curve the id names and reads the points as raw limbs ([`layout_ok`] still checks sizes
+/// and offsets at run time).
+pub unsafe trait HipServed: SWCurveConfig {
+    const CURVE: c_int;
+    /// the library's id of `Self::ScalarField`
+    const SCALAR_FIELD: c_int = match Self::CURVE {
+        sys::BN254_G1 => sys::BN254_FR,
+        sys::BLS12_381_G1 | sys::BLS12_381_G2 => sys::BLS12_381_FR,
+        _ => sys::BLS12_377_FR,
+    };
+}
+
+/// Makes `Projective<P>` known to the transform over group elements (`fft_in_place::<Projective<P>>` through ark-poly's
+/// hook, `ark_hip_sys::radix2_fft_in_place`): ark-poly sits below ark-ec and cannot name the type, so the typed layer
+/// registers its `TypeId`.  Every entry point of this module does it on the way in (a read-locked scan of at most five
+/// entries); call it directly when a program transforms points before its first MSM.
+pub fn serve_group_coefficients<P: HipServed>() {
+    sys::register_group_type::<Projective<P>>(P::CURVE, P::SCALAR_FIELD);
+}
+
+/// the id the caller passed against the one the config declares (the declaration wins)
+#[inline]
+fn served_id<P: HipServed>(curve: c_int) -> c_int {
+    debug_assert_eq!(curve, P::CURVE, "ark-hip: curve id passed does not match the config's HipServed::CURVE");
+    serve_group_coefficients::<P>();
+    P::CURVE
+}
+
 /// u64 words of one base-field element for a library curve id
 pub const fn fe_words(curve: c_int) -> usize {
     match curve {
@@ -92,7 +131,8 @@ fn cpu_msm_bigint<P: SWCurveConfig>(bases: &[Affine<P>], bigints: &[BigIntOf<P>]
 
 /// `SWCurveConfig::msm` (short_weierstrass/mod.rs:112-119): `Err(min_len)` when the lengths differ, else the sum
 /// on the GPU -- the `into_bigint` pass of variable_base/mod.rs:60-62 included (scalars cross as Montgomery residues).
-pub fn sw_msm<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalars: &[P::ScalarField]) -> Result<Projective<P>, usize> {
+pub fn sw_msm<P: HipServed>(curve: c_int, bases: &[Affine<P>], scalars: &[P::ScalarField]) -> Result<Projective<P>, usize> {
+    let curve = served_id::<P>(curve);
     if bases.len() != scalars.len() {
         return Err(bases.len().min(scalars.len()));
     }
@@ -103,7 +143,8 @@ pub fn sw_msm<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalars: &[P:
 }
 
 /// `VariableBaseMSM::msm_bigint` (variable_base/mod.rs:80-85): truncates to the shorter input like the reference.
-pub fn sw_msm_bigint<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Projective<P> {
+pub fn sw_msm_bigint<P: HipServed>(curve: c_int, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Projective<P> {
+    let curve = served_id::<P>(curve);
     device_msm::<P, BigIntOf<P>>(curve, bases, bigints, false).unwrap_or_else(|| cpu_msm_bigint::<P>(bases, bigints))
 }
 
@@ -112,11 +153,12 @@ pub fn sw_msm_bigint<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], bigint
 /// `bool` = one byte) and the device builds only the windows their bits reach; truncates to the shorter input like the
 /// reference's `preamble` (:349-369).  Any device or layout problem falls back to the reference's CPU bodies.
 #[cfg(feature = "ec-hook")]
-pub fn sw_msm_small<P: SWCurveConfig>(
+pub fn sw_msm_small<P: HipServed>(
     curve: c_int,
     bases: &[Affine<P>],
     scalars: ark_ec::scalar_mul::variable_base::SmallScalars<'_>,
 ) -> Projective<P> {
+    let curve = served_id::<P>(curve);
     use ark_ec::scalar_mul::variable_base::SmallScalars as S;
     let (ptr, len, bytes, bits): (*const c_void, usize, c_int, c_int) = match scalars {
         S::U1(s) => (s.as_ptr() as *const c_void, s.len(), 1, 1), // bool: guaranteed 0x00 / 0x01, one byte
@@ -140,7 +182,8 @@ pub fn sw_msm_small<P: SWCurveConfig>(
 
 /// `VariableBaseMSM::msm_chunks` (variable_base/mod.rs:119-150) over slices: streams aligned at their end, steps of
 /// 2^20 pairs, the next step's upload overlapping the current step's kernels.  `None` on device error.
-pub fn sw_msm_chunks<P: SWCurveConfig>(curve: c_int, bases: &[Affine<P>], scalars: &[P::ScalarField]) -> Option<Projective<P>> {
+pub fn sw_msm_chunks<P: HipServed>(curve: c_int, bases: &[Affine<P>], scalars: &[P::ScalarField]) -> Option<Projective<P>> {
+    let curve = served_id::<P>(curve);
     assert!(scalars.len() <= bases.len());
     if !layout_ok::<P, P::ScalarField>(curve) {
         return None;
@@ -174,10 +217,11 @@ pub struct ResidentBases<'a, P: SWCurveConfig> {
     device: c_int,
     bases: &'a [Affine<P>],
 }
-impl<'a, P: SWCurveConfig> ResidentBases<'a, P> {
+impl<'a, P: HipServed> ResidentBases<'a, P> {
     /// `None` if the layout check fails, no device is present or the copy does not fit (callers then simply run unpinned).
     /// The pin lives in the context of the device that is current NOW; the guard remembers it and unpins there.
     pub fn pin(curve: c_int, bases: &'a [Affine<P>]) -> Option<Self> {
+        let curve = served_id::<P>(curve);
         if bases.is_empty() || !layout_ok::<P, P::ScalarField>(curve) {
             return None;
         }
@@ -185,6 +229,8 @@ impl<'a, P: SWCurveConfig> ResidentBases<'a, P> {
         let rc = unsafe { sys::ark_hip_msm_bases_pin(curve, bases.as_ptr() as *const u64, bases.len()) };
         (rc == 0).then_some(Self { curve, device, bases })
     }
+}
+impl<'a, P: SWCurveConfig> ResidentBases<'a, P> {
     pub fn bases(&self) -> &'a [Affine<P>] {
         self.bases
     }
@@ -227,7 +273,8 @@ pub fn base_cache_stats() -> Option<[u64; 8]> {
 }
 
 /// One MSM over `n_gpus` GPUs of this node, driven from this process (base-range shards, variable_base/mod.rs:521-557).
-pub fn msm_multi<P: SWCurveConfig>(curve: c_int, n_gpus: usize, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Option<Projective<P>> {
+pub fn msm_multi<P: HipServed>(curve: c_int, n_gpus: usize, bases: &[Affine<P>], bigints: &[BigIntOf<P>]) -> Option<Projective<P>> {
+    let curve = served_id::<P>(curve);
     if !layout_ok::<P, BigIntOf<P>>(curve) {
         return None;
     }
@@ -286,8 +333,9 @@ pub struct PreparedBases<P: SWCurveConfig> {
 }
 unsafe impl<P: SWCurveConfig> Send for PreparedBases<P> {}
 unsafe impl<P: SWCurveConfig> Sync for PreparedBases<P> {} // the library locks per device
-impl<P: SWCurveConfig> PreparedBases<P> {
+impl<P: HipServed> PreparedBases<P> {
     pub fn new(curve: c_int, bases: &[Affine<P>]) -> Option<Self> {
+        let curve = served_id::<P>(curve);
         if !layout_ok::<P, P::ScalarField>(curve) {
             return None;
         }
@@ -295,6 +343,8 @@ impl<P: SWCurveConfig> PreparedBases<P> {
         let rc = unsafe { sys::ark_hip_msm_bases_prepare(curve, bases.as_ptr() as *const u64, bases.len(), &mut h) };
         (rc == 0).then(|| Self { handle: h, n: bases.len(), _p: PhantomData })
     }
+}
+impl<P: SWCurveConfig> PreparedBases<P> {
     pub fn len(&self) -> usize {
         self.n
     }
@@ -354,9 +404,10 @@ pub struct BatchMulTable<P: SWCurveConfig> {
     handle: *mut sys::ark_hip_batch_mul_table,
     _p: PhantomData<P>,
 }
-impl<P: SWCurveConfig> BatchMulTable<P> {
+impl<P: HipServed> BatchMulTable<P> {
     /// `BatchMulPreprocessing::new(base, num_scalars)`
     pub fn new(curve: c_int, base: Projective<P>, num_scalars: usize) -> Option<Self> {
+        let curve = served_id::<P>(curve);
         if !layout_ok::<P, P::ScalarField>(curve) {
             return None;
         }
@@ -364,6 +415,8 @@ impl<P: SWCurveConfig> BatchMulTable<P> {
         let rc = unsafe { sys::ark_hip_batch_mul_table_new(curve, &base as *const _ as *const u64, num_scalars, &mut h) };
         (rc == 0).then(|| Self { handle: h, _p: PhantomData })
     }
+}
+impl<P: SWCurveConfig> BatchMulTable<P> {
     /// `BatchMulPreprocessing::batch_mul`
     pub fn batch_mul(&self, v: &[P::ScalarField]) -> Option<Vec<Affine<P>>> {
         let mut out: Vec<Affine<P>> = Vec::with_capacity(v.len());
@@ -386,7 +439,8 @@ impl<P: SWCurveConfig> Drop for BatchMulTable<P> {
 /// Affine points (identity -> `Affine::identity()`, the all-zero encoding of `ZeroFlag = ()`).  The hook patches/0004 adds
 /// to `SWCurveConfig` calls this; `None` (the CPU path runs) below 2^12 points, on a layout mismatch or a device error.
 #[cfg(feature = "ec-hook")]
-pub fn sw_normalize_batch<P: SWCurveConfig>(curve: c_int, v: &[Projective<P>]) -> Option<Vec<Affine<P>>> {
+pub fn sw_normalize_batch<P: HipServed>(curve: c_int, v: &[Projective<P>]) -> Option<Vec<Affine<P>>> {
+    let curve = served_id::<P>(curve);
     const MIN_POINTS: usize = 1 << 12; // PCIe both ways: 240 B per BLS12-381 G1 point against ~0.2 us of CPU work
     if v.len() < MIN_POINTS || !layout_ok::<P, P::ScalarField>(curve) {
         return None;
@@ -405,7 +459,8 @@ pub fn sw_normalize_batch<P: SWCurveConfig>(curve: c_int, v: &[Projective<P>]) -
 /// device's own cost rule), the batch is one mixed addition per table row and scalar, the affine results come back once.
 /// The hook patches/0004 adds to `SWCurveConfig` calls this; `None` below 2^10 scalars, on a layout mismatch or an error.
 #[cfg(feature = "ec-hook")]
-pub fn sw_batch_mul<P: SWCurveConfig>(curve: c_int, base: &Projective<P>, v: &[P::ScalarField]) -> Option<Vec<Affine<P>>> {
+pub fn sw_batch_mul<P: HipServed>(curve: c_int, base: &Projective<P>, v: &[P::ScalarField]) -> Option<Vec<Affine<P>>> {
+    let curve = served_id::<P>(curve);
     const MIN_SCALARS: usize = 1 << 10;
     if v.len() < MIN_SCALARS {
         return None;
@@ -475,6 +530,10 @@ macro_rules! hip_sw_config {
             fn proj_from_up(p: ark_ec::short_weierstrass::Projective<$up>) -> ark_ec::short_weierstrass::Projective<Self> {
                 ark_ec::short_weierstrass::Projective::<Self>::new_unchecked(p.x, p.y, p.z)
             }
+        }
+        // the wrapper config IS the upstream curve (every item delegated below) under the library id the macro was given
+        unsafe impl $crate::msm::HipServed for $name {
+            const CURVE: core::ffi::c_int = $id;
         }
         impl ark_ec::CurveConfig for $name {
             type BaseField = <$up as ark_ec::CurveConfig>::BaseField;

@@ -1,14 +1,15 @@
-"""Test-side helpers around the product's C ABI (algebra_amd._lib) -- numpy in, numpy out."""
+"""Test-side helpers around the product's C ABI (algebra_amd._lib) -- numpy in, numpy out.  The ark_hip_test_* hooks live in
+libark_hip_test.so (test_lib()): the shipped libark_hip.so does not export them."""
 import ctypes as C
 
 import numpy as np
 
 import algebra_amd as A
 from algebra_amd import curves as cv
-from algebra_amd._lib import check, lib
+from algebra_amd._lib import check, lib, test_lib
 
 OPS = dict(add=0, sub=1, mul=2, sqr=3, neg=4, dbl=5, into_bigint=7, from_bigint=8,
-           lazy_mul=20, lazy_sqr=21, lazy_sop2=22)   # the 28-bit-limb device forms (csrc/testops.cuh)
+           lazy_mul=20, lazy_sqr=21, lazy_sop2=22)   # the 28-bit-limb device forms (csrc/devops.cuh: field_op_kernel)
 PKIND = dict(bkt_add_aff=2, bkt_sub_aff=3, bkt_add_bkt=4, bkt_double=5, bkt_to_jac=6, aff_double_to_bkt=7,
              lazy_add_aff=12, lazy_sub_aff=13, lazy_add_bkt=14, lazy_add_acc=15)   # carry-free forms (LazyK, testops.cuh)
 
@@ -23,7 +24,7 @@ def field_op(field, op, a, b=None):
     n = a.size // words
     bb = None if b is None else np.ascontiguousarray(b, dtype=np.uint64)
     r = np.zeros_like(a)
-    check(lib().ark_hip_test_field_op(field, OPS[op], _p(a), _p(bb), _p(r), n), "test_field_op")
+    check(test_lib().ark_hip_test_field_op(field, OPS[op], _p(a), _p(bb), _p(r), n), "test_field_op")
     return r
 
 
@@ -32,7 +33,7 @@ def basefield_op(curve, op, a, b=None):
     n = a.size // cv.fe_words(curve)
     bb = None if b is None else np.ascontiguousarray(b, dtype=np.uint64)
     r = np.zeros_like(a)
-    check(lib().ark_hip_test_basefield_op(curve, OPS[op], _p(a), _p(bb), _p(r), n), "test_basefield_op")
+    check(test_lib().ark_hip_test_basefield_op(curve, OPS[op], _p(a), _p(bb), _p(r), n), "test_basefield_op")
     return r
 
 
@@ -43,7 +44,7 @@ def point_op(curve, kind, acc, other=None):
     n = acc.size // (fw * (2 if k == 7 else 4))
     o = None if other is None else np.ascontiguousarray(other, dtype=np.uint64)
     out = np.zeros((n, fw * (3 if k == 6 else 4)), dtype=np.uint64)
-    check(lib().ark_hip_test_point_op(curve, k, _p(acc), _p(o), _p(out), n), "test_point_op")
+    check(test_lib().ark_hip_test_point_op(curve, k, _p(acc), _p(o), _p(out), n), "test_point_op")
     return out
 
 

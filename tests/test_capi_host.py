@@ -19,13 +19,36 @@ B4 = np.array([0xB0B, 3, 0, 0], dtype=np.uint64)
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ark_hip.h")).read()
-    declared = set(re.findall(r"\b(ark_hip_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 20
+    i, j = hdr.index("#ifdef ARK_HIP_TEST_HOOKS"), hdr.index("#endif /* ARK_HIP_TEST_HOOKS */")
+    public = set(re.findall(r"\b(ark_hip_[a-z0-9_]+)\s*\(", hdr[:i] + hdr[j:]))
+    hooks = set(re.findall(r"\b(ark_hip_[a-z0-9_]+)\s*\(", hdr[i:j]))
+    assert len(public) >= 20 and hooks and all(h.startswith("ark_hip_test_") for h in hooks)
+    assert not any(p.startswith("ark_hip_test_") for p in public)
     L = _lib.lib()  # raises if the .so is missing
-    for name in declared:
+    for name in public:
         assert hasattr(L, name), name
-    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert public == set(_lib.SYMBOLS), public ^ set(_lib.SYMBOLS)
+    assert hooks == set(_lib.TEST_SYMBOLS), hooks ^ set(_lib.TEST_SYMBOLS)
     assert b"gfx950" in L.ark_hip_version()
+    T = _lib.test_lib()
+    for name in public | hooks:
+        assert hasattr(T, name), name
+
+
+def test_shipped_library_exports_the_c_abi_and_nothing_else():
+    """`nm -D libark_hip.so | grep test_` is empty -- the hooks live in libark_hip_test.so -- and with
+    -fvisibility=hidden the dynamic symbol table holds the functions of include/ark_hip.h, not the library's C++ internals."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-2] in ("T", "t", "W", "w", "B", "D", "V", "u")]
+    assert not [s for s in syms if "test_" in s], [s for s in syms if "test_" in s][:5]
+    ours = [s for s in syms if s.startswith("ark_hip_")]
+    assert set(ours) == set(_lib.SYMBOLS), set(ours) ^ set(_lib.SYMBOLS)
+    # nothing of namespace arkhip leaks (mangled names start with _ZN6arkhip)
+    assert not [s for s in syms if "6arkhip" in s], [s for s in syms if "6arkhip" in s][:5]
+    outt = subprocess.run(["nm", "-D", "--defined-only", _lib.TEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for h in _lib.TEST_SYMBOLS:
+        assert (" T " + h) in outt, h
 
 
 def test_curve_info_matches_oracle():
@@ -312,19 +335,19 @@ def test_msm_host_tail_folds_bit_sums_like_the_window_combine(cname):
         out = np.zeros(3 * fw, dtype=np.uint64)
         wid = (C.c_int * windows)(*widths)
         parts = np.ascontiguousarray(parts)
-        rc = _lib.lib().ark_hip_test_msm_host_fold(cid, parts.ctypes.data_as(C.c_void_p), windows, nbits, l0, wid,
+        rc = _lib.test_lib().ark_hip_test_msm_host_fold(cid, parts.ctypes.data_as(C.c_void_p), windows, nbits, l0, wid,
                                                    out.ctypes.data_as(C.c_void_p))
         assert rc == 0
         sc = np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in weights], dtype=np.uint64)
         want = O.to_affine(cid, O.msm(cid, np.stack(pts), sc, O.NAIVE))
         assert np.array_equal(A.into_affine(cid, out), want), (cname, windows, nbits, l0)
-    assert _lib.lib().ark_hip_test_msm_host_fold(cid, None, 1, 1, 0, None, None) != 0      # argument check
+    assert _lib.test_lib().ark_hip_test_msm_host_fold(cid, None, 1, 1, 0, None, None) != 0      # argument check
 
 
 def _tag(a):
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1)
     out = (C.c_uint64 * 2)()
-    assert A.lib().ark_hip_test_base_hash(a.ctypes.data_as(C.c_void_p), a.size, out) == 0
+    assert _lib.test_lib().ark_hip_test_base_hash(a.ctypes.data_as(C.c_void_p), a.size, out) == 0
     return int(out[0]) | (int(out[1]) << 64)
 
 
@@ -401,7 +424,7 @@ def test_host_field_arithmetic_on_edge_values(cname):
     m = len(elems)
     a = np.stack([elems[i] for i in range(m) for _ in range(m)])
     b = np.stack([elems[j] for _ in range(m) for j in range(m)])
-    L = _lib.lib()
+    L = _lib.test_lib()
     for op in ("add", "sub", "mul"):
         got = np.zeros_like(a)
         assert L.ark_hip_test_host_basefield_op(cid, O.OPS[op], a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
@@ -444,7 +467,7 @@ def test_helper_pool_is_one_bounded_set_of_threads_under_concurrent_callers():
     Fp2 host tail (eleven windows: the pooled path) and the verified cache's hashing pass at once, on the CPU only; every
     result equals the single-threaded one, and the pool's thread count is what it was before (csrc/hostpool.hpp)."""
     import threading
-    L = _lib.lib()
+    L = _lib.test_lib()   # the hooks' library: a separate instance of the product's objects, with a pool of its own
     out = (C.c_int * 2)()
     assert L.ark_hip_host_threads(out) == 0
     helpers, created = out[0], out[1]

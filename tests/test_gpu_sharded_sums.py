@@ -11,7 +11,7 @@ import pytest
 
 import algebra_amd as A
 import oracle_lib as O
-from algebra_amd._lib import lib
+from algebra_amd._lib import test_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def emulated(cid, bases, scalars, cuts, montgomery=False):
     pn = (C.c_size_t * world)(*[cuts[r + 1] - cuts[r] for r in range(world)])
     out = np.zeros(3 * O.fe_words(cid), dtype=np.uint64)
     path = C.c_int(0)
-    rc = lib().ark_hip_test_msm_sharded_emulated(cid, world, pb, ps, pn, int(montgomery), out.ctypes.data_as(C.c_void_p), C.byref(path))
+    rc = test_lib().ark_hip_test_msm_sharded_emulated(cid, world, pb, ps, pn, int(montgomery), out.ctypes.data_as(C.c_void_p), C.byref(path))
     return rc, out, path.value
 
 

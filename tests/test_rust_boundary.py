@@ -246,23 +246,107 @@ def test_device_vec_closes_the_transform_chain():
 
 def test_group_coefficients_reach_the_device_from_the_domain_hook():
     """VERDICT r4 missing #3: `fft_in_place<T: DomainCoeff<F>>` with T = Projective<P> (poly/src/domain/mod.rs:332-362,
-    exercised by poly/src/test.rs:57) used to fall back to the CPU.  The shim now recognises the Projective of every served
-    curve by name and layout, checks that its scalar field is the domain's, resizes with `T::zero()` (z = 0) and calls the
-    device's transform over points; any other T still returns false (the CPU path)."""
+    exercised by poly/src/test.rs:57) used to fall back to the CPU.  The shim recognises the REGISTERED Projective of a served
+    curve (round 6: by lifetime-erased TypeId, not by name -- VERDICT r5 weak #7), checks that its scalar field is the domain's,
+    resizes with `T::zero()` (z = 0) and calls the device's transform over points; any other T still returns false."""
     sys_rs = open(os.path.join(ROOT, "rust", "ark-hip-sys", "src", "lib.rs")).read()
     assert "fn projective_curve<T>() -> Option<(c_int, c_int, usize)>" in sys_rs
-    for cfg, curve in (("bls12_381::curves::g1::Config", "BLS12_381_G1"), ("bls12_381::curves::g2::Config", "BLS12_381_G2"),
-                       ("bn254::curves::g1::Config", "BN254_G1"), ("bls12_377::curves::g1::Config", "BLS12_377_G1"),
-                       ("bls12_377::curves::g2::Config", "BLS12_377_G2")):
-        assert re.search(r'\("%s", %s, \w+_FR, \d+\)' % (re.escape(cfg), curve), sys_rs), cfg
+    assert "pub fn register_group_type<T>(curve: c_int, scalar_field: c_int)" in sys_rs
     body = sys_rs[sys_rs.index("pub fn radix2_fft_in_place<"):]
     assert "projective_curve::<T>()" in body and "ark_hip_fft_group_in_place(curve, &dom" in body
     assert "curve_field != fid" in body and "coeffs.truncate(len)" in body
     decl = _c_decls()
     assert decl["ark_hip_fft_group_in_place"] == 4 and decl["ark_hip_fft_group_in_place_device"] == 4
-    if os.path.isdir(REF):   # the config paths the name match relies on exist in the reference's curve crates
-        for crate, sub in (("bls12_381", "g1"), ("bls12_381", "g2"), ("bn254", "g1"), ("bls12_377", "g1"), ("bls12_377", "g2")):
-            src = open(os.path.join(REF, "curves", crate, "src", "curves", sub + ".rs")).read()
-            assert "pub struct Config" in src, (crate, sub)
+    if os.path.isdir(REF):
         grp = open(os.path.join(REF, "ec/src/models/short_weierstrass/group.rs")).read()
         assert "pub struct Projective<P: SWCurveConfig>" in grp
+
+
+def _strip_comments(src):
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def test_served_marker_trait_replaces_type_name_sniffing(tmp_path):
+    """no dispatch on `core::any::type_name` strings anywhere in rust/.  `T == F` is decided by a
+    lifetime-erased TypeId (`type_id_of`), the Projective of a served curve by a registry of TypeIds that the typed layer fills
+    for configs implementing the `HipServed` marker; every typed MSM entry point is bounded by that marker; the five curve
+    configs implement it in patches/0002 (checked on the patched tree) and `hip_sw_config!` emits it for wrapper configs."""
+    for root, _, files in os.walk(os.path.join(ROOT, "rust")):
+        for f in files:
+            if f.endswith(".rs"):
+                code = _strip_comments(open(os.path.join(root, f)).read())
+                assert "type_name" not in code, os.path.join(root, f)
+    sys_rs = open(os.path.join(ROOT, "rust", "ark-hip-sys", "src", "lib.rs")).read()
+    assert "pub fn type_id_of<T: ?Sized>() -> core::any::TypeId" in sys_rs
+    assert "type_id_of::<T>() != type_id_of::<F>()" in sys_rs
+    msm_rs = open(os.path.join(ROOT, "rust", "ark-hip", "src", "msm.rs")).read()
+    assert "pub unsafe trait HipServed: SWCurveConfig" in msm_rs and "const CURVE: c_int;" in msm_rs
+    assert "sys::register_group_type::<Projective<P>>(P::CURVE, P::SCALAR_FIELD)" in msm_rs
+    for fn in ("sw_msm", "sw_msm_bigint", "sw_msm_small", "sw_msm_chunks", "msm_multi", "sw_normalize_batch", "sw_batch_mul"):
+        assert re.search(r"pub fn %s<P: HipServed>\(" % fn, msm_rs), fn
+        i = msm_rs.index("pub fn %s<P: HipServed>(" % fn)
+        assert "let curve = served_id::<P>(curve);" in msm_rs[i:i + 700], fn
+    for ty in ("ResidentBases<'a, P>", "PreparedBases<P>", "BatchMulTable<P>"):
+        assert re.search(r"impl<(?:'a, )?P: HipServed> %s \{" % re.escape(ty), msm_rs), ty
+    assert "unsafe impl $crate::msm::HipServed for $name" in msm_rs          # the wrapper-config macro
+    lib_rs = open(os.path.join(ROOT, "rust", "ark-hip", "src", "lib.rs")).read()
+    assert "HipServed" in lib_rs and "serve_group_coefficients" in lib_rs
+    p2 = open(os.path.join(ROOT, "patches", "0002-curves-hip-feature.patch")).read()
+    for cid in ("BLS12_381_G1", "BLS12_381_G2", "BLS12_377_G1", "BLS12_377_G2", "BN254_G1"):
+        assert "+    const CURVE: core::ffi::c_int = ark_hip::%s;" % cid in p2, cid
+    assert p2.count("+unsafe impl ark_hip::HipServed for Config {") == 5
+    if os.path.isdir(REF):   # on the patched tree every impl sits in the file of the config the id names
+        import shutil
+        work = tmp_path / "ref"
+        work.mkdir()
+        shutil.copytree(os.path.join(REF, "curves"), str(work / "curves"), symlinks=True)
+        shutil.copytree(os.path.join(REF, "ec"), str(work / "ec"), symlinks=True)
+        shutil.copy(os.path.join(REF, "Cargo.toml"), str(work / "Cargo.toml"))
+        for p in ("0001-ark-ec-msm_bigint-hook.patch", "0002-curves-hip-feature.patch"):
+            r = subprocess.run(["git", "apply", "-p1", os.path.join(ROOT, "patches", p)], cwd=str(work), capture_output=True, text=True)
+            assert r.returncode == 0, (p, r.stderr)
+        for crate, sub, cid in (("bls12_381", "g1", "BLS12_381_G1"), ("bls12_381", "g2", "BLS12_381_G2"),
+                                ("bls12_377", "g1", "BLS12_377_G1"), ("bls12_377", "g2", "BLS12_377_G2"), ("bn254", "g1", "BN254_G1")):
+            src = open(str(work / "curves" / crate / "src" / "curves" / (sub + ".rs"))).read()
+            assert "pub struct Config" in src
+            assert "unsafe impl ark_hip::HipServed for Config" in src and "ark_hip::%s;" % cid in src, (crate, sub)
+            assert "ark_hip::sw_msm::<Self>(ark_hip::%s, bases, scalars)" % cid in src, (crate, sub)
+
+
+def test_one_command_recipe_and_test_crate_for_a_box_with_cargo():
+    """VERDICT r5 missing #2 / next #7: rust/ci.sh vendors the crates, applies the five patches and runs the reference's own
+    test-suites (`cargo test --features hip` in the curve crates and ark-poly) plus rust/ark-hip-tests, which instantiates
+    `test_group!(..; sw)` -- and with it test-templates/src/msm.rs -- over both routes.  Static checks: the script and the
+    crate exist, the crate's dependency paths are the ones the script's layout produces, the tests name the templates."""
+    ci = os.path.join(ROOT, "rust", "ci.sh")
+    assert os.access(ci, os.X_OK)
+    sh = open(ci).read()
+    layout = dict(re.findall(r'cp -r "\$REPO/rust/([a-z-]+)" ([a-z/-]+)', sh))
+    assert layout == {"ark-hip-sys": "hip-sys", "ark-hip": "hip", "ark-hip-curves": "curves/hip-configs", "ark-hip-tests": "hip-tests"}
+    assert 'for p in "$REPO"/patches/000*.patch' in sh
+    assert "cargo test --release -p ark-bls12-381 -p ark-bls12-377 -p ark-bn254 --features hip" in sh
+    assert "cargo test --release -p ark-poly --features hip" in sh and "(cd hip-tests && cargo test --release)" in sh
+    toml = open(os.path.join(ROOT, "rust", "ark-hip-tests", "Cargo.toml")).read()
+    for dep, path in (("ark-hip", "../hip"), ("ark-hip-sys", "../hip-sys"), ("ark-hip-curves", "../curves/hip-configs"),
+                      ("ark-algebra-test-templates", "../test-templates"), ("ark-bls12-381", "../curves/bls12_381"),
+                      ("ark-bls12-377", "../curves/bls12_377"), ("ark-bn254", "../curves/bn254"), ("ark-poly", "../poly")):
+        assert re.search(r'^%s = \{[^}]*path = "%s"' % (re.escape(dep), re.escape(path)), toml, re.M), dep
+    groups = open(os.path.join(ROOT, "rust", "ark-hip-tests", "tests", "groups.rs")).read()
+    assert len(re.findall(r"^    test_group!\(\w+; \w+; sw\);$", groups, re.M)) == 10
+    for needle in ("Projective<HipBls12_381G1Config>", "Projective<HipBls12_377G2Config>", "Projective<HipBn254G1Config>",
+                   "msm_bigint_default::<G1Projective>", "serve_group_coefficients::<ark_bls12_381::g1::Config>()"):
+        assert needle in groups, needle
+    dom = open(os.path.join(ROOT, "rust", "ark-hip-tests", "tests", "domain.rs")).read()
+    for needle in ("HipRadix2EvaluationDomain as Dom", "fn fft_correctness()", "fn degree_aware_fft_correctness()",
+                   "fn device_matches_the_cpu_domain()", "fn fft_ifft_identity()"):
+        assert needle in dom, needle
+    if os.path.isdir(REF):   # the templates and tests this crate instantiates / restates exist where it says
+        tt = open(os.path.join(REF, "test-templates", "src", "msm.rs")).read()
+        for fn in ("test_var_base_msm", "test_var_base_msm_mixed_scalars", "test_var_base_msm_specialized",
+                   "test_chunked_pippenger", "test_hashmap_pippenger"):
+            assert "pub fn %s<G: VariableBaseMSM>()" % fn in tt, fn
+        r2 = open(os.path.join(REF, "poly", "src", "domain", "radix2", "mod.rs")).read()
+        for fn in ("test_fft_correctness", "degree_aware_fft_correctness", "parallel_fft_consistency", "test_fft_ifft_identity"):
+            assert "fn %s()" % fn in r2, fn
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "rust/ci.sh" in integ

@@ -8,10 +8,10 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 S=$R/algebra_amd/csrc
 O=/tmp/ark_variant_$name
 mkdir -p $O $R/algebra_amd/variants
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-pass-failed -I$S $*"
-/opt/rocm/bin/hipcc $FL -DARK_HIP_DEV -c $S/capi.hip -o $O/capi.o &
+FL="-O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-result -Wno-pass-failed -I$S $*"
+for u in runtime msm fft comm; do /opt/rocm/bin/hipcc $FL -DARK_HIP_DEV -c $S/capi_$u.hip -o $O/capi_$u.o & done
 /opt/rocm/bin/hipcc $FL -c $S/msm_bls12_381_g1.hip -o $O/msm.o &
 /opt/rocm/bin/hipcc $FL -c $S/fft_bls12_381_fr.hip -o $O/fft.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/algebra_amd/variants/libark_hip_$name.so $O/capi.o $O/msm.o $O/fft.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/algebra_amd/variants/libark_hip_$name.so $O/capi_runtime.o $O/capi_msm.o $O/capi_fft.o $O/capi_comm.o $O/msm.o $O/fft.o
 echo built $R/algebra_amd/variants/libark_hip_$name.so

@@ -35,7 +35,7 @@ for step in "$@"; do
   IFS=':' read -r -a a <<< "$step"
   case ${a[0]} in
     tests)
-      if [ -n "${a[1]}" ]; then (timeout 1200 python -m pytest tests -m gpu -q -x -k "${a[1]}" 2>&1 | tail -25) > $O/tests_${a[1]// /_}.log
+      if [ -n "${a[1]}" ]; then (timeout 1200 python -m pytest tests -m gpu -q -x -k "${a[1]}" 2>&1 | tail -25) > $O/tests_${a[1]// /_}${suffix}.log
       else (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -25) > $O/tests.log; fi ;;
     smoke) (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log) 2>&1 ;;
     bench) (timeout 900 python bench.py ${a[@]:1} > $O/bench.json) 2> $O/bench.err ;;

@@ -20,7 +20,7 @@ for cname,windows,nbits,l0,widths in (("BLS12_381_G1",22,9,2,[12]*13+[11]*9),("B
         parts[w,q,3*fw:3*fw+one.size]=one
     out=np.zeros(3*fw,dtype=np.uint64)
     wid=(C.c_int*windows)(*widths)
-    L=_lib.lib()
+    L=_lib.test_lib()
     f=lambda: L.ark_hip_test_msm_host_fold(cid,parts.ctypes.data_as(C.c_void_p),windows,nbits,l0,wid,out.ctypes.data_as(C.c_void_p))
     f(); best=1e9
     for rep in range(5):

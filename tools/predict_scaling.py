@@ -19,7 +19,7 @@ import torch
 import algebra_amd as A
 import synth as S
 from algebra_amd import curves as cv
-from algebra_amd._lib import check, lib
+from algebra_amd._lib import check, lib, test_lib
 
 CURVE = "BLS12_381_G1"
 ALLGATHER_MS = 0.1   # assumption, labelled in the output
@@ -74,7 +74,7 @@ def main():
         path = C.c_int(0)
 
         def run():
-            check(L.ark_hip_test_msm_sharded_emulated(cid, N, pbp, psp, pn, 0, out.ctypes.data_as(C.c_void_p), C.byref(path)), "emulated")
+            check(test_lib().ark_hip_test_msm_sharded_emulated(cid, N, pbp, psp, pn, 0, out.ctypes.data_as(C.c_void_p), C.byref(path)), "emulated")
             return out.copy()
         ms, res = timed(run, 3)
         sub = S.mul_gen(cid, S.dlog_of_msm(sc_h[: N * n8], S.A0, S.B0, r), r)
