@@ -60,6 +60,12 @@ int sums_write_failure(Context* c, char* d_block, int code, MsmSumsHeader* h_out
   ARK_HIP_TRY(hipMemcpyAsync(d_block, hp, sizeof(MsmSumsHeader), hipMemcpyHostToDevice, c->stream));
   return 0;
 }
+// Bounded wait for a stream that carries a collective (the exchange has only ever run with a world of one or
+// emulated ranks -- a peer that never arrives must cost an error code, not a hang): the stream is polled until
+// ARK_HIP_COMM_TIMEOUT_MS (default 120 000; 0 = wait for ever) has passed; then the communicator is aborted (ncclCommAbort,
+// which also ends the stuck kernel), dropped from the context, and the call returns ARK_HIP_ERR_COMM.  Every rank that waits
+// for the same collective runs the same clock, so all of them leave.
+// (comm_sync: declared in capi_core.hpp, defined below)
 // all `world` blocks sit in d_blocks: add them, bring the sums and the headers to the host, decide.  *agree = the ranks
 // share one plan and out_xyz holds the whole job's result; otherwise the caller takes the fallback.  A scalar-range error on
 // ANY rank is every rank's error.
@@ -72,7 +78,7 @@ int sums_reduce(Context* c, int curve, const MsmSumsHeader& mine, const char* d_
     if (int rc = msm_sum_ranks_dispatch(curve, d_blocks, world, bb, mine.npairs, d_out, c->stream)) return rc;
   ARK_HIP_TRY(hipMemcpy2DAsync(hh, sizeof(MsmSumsHeader), d_blocks, bb, sizeof(MsmSumsHeader), (size_t)world, hipMemcpyDeviceToHost, c->stream));
   if (mine.npairs) ARK_HIP_TRY(hipMemcpyAsync(h_sums, d_out, (size_t)mine.npairs * pb, hipMemcpyDeviceToHost, c->stream));
-  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = comm_sync(c, c->stream)) return rc;   // behind the all-gather: bounded
   bool same = mine.npairs != 0, err = false;
   for (int r = 0; r < world; r++)   // a rank that failed before the collective: its code is every rank's (lowest rank's first)
     if (hh[r].err >= SUMS_ERR_LOCAL) {
@@ -105,6 +111,7 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;   // optional: frees a collective that never completes (comm_sync)
   bool tried = false;
 };
 RcclApi g_rccl;
@@ -142,10 +149,51 @@ const RcclApi* rccl_api() {
   ARK_RCCL_SYM(GroupEnd, "ncclGroupEnd")
   ARK_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef ARK_RCCL_SYM
+  a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");
   a.tried = true;
   g_rccl = a;
   return &g_rccl;
 }
+}  // namespace
+namespace arkhip {
+namespace capi {
+int comm_sync(Context* c, hipStream_t st) {
+  static const long limit_ms = [] {
+    const char* e = getenv("ARK_HIP_COMM_TIMEOUT_MS");
+    return e ? atol(e) : 120000L;
+  }();
+  if (limit_ms <= 0 || !c->comm || c->comm_world <= 1) {
+    ARK_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return -1000 - (int)e;
+    }
+    (void)hipGetLastError();   // "not ready" is not an error to leave behind
+    if ((++spins & 1023u) == 0) {
+      const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > limit_ms) break;
+      if (ms > 5) std::this_thread::sleep_for(std::chrono::microseconds(200));   // a long wait: stop burning the core
+    }
+  }
+  fprintf(stderr, "ark_hip: a collective did not complete within %ld ms (ARK_HIP_COMM_TIMEOUT_MS): communicator of rank %d aborted\n",
+          limit_ms, c->comm_rank);
+  const RcclApi* api = rccl_api();
+  if (api && api->CommAbort) (void)api->CommAbort(c->comm);   // ends the stuck kernel; the communicator is gone afterwards
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  return ARK_HIP_ERR_COMM;
+}
+}  // namespace capi
+}  // namespace arkhip
+namespace {
 #define ARK_RCCL_TRY(api, expr)                                                                         \
   do {                                                                                                  \
     ncclResult_t _r = (expr);                                                                           \
@@ -175,7 +223,7 @@ int msm_sharded_combine(Context* c, int curve, const uint64_t* part, uint64_t* o
   ARK_HIP_TRY(hipMemcpyAsync(dsend, hp, pw * 8, hipMemcpyHostToDevice, c->stream));
   ARK_RCCL_TRY(api, api->AllGather(dsend, dall, pw, ncclUint64, c->comm, c->stream));
   ARK_HIP_TRY(hipMemcpyAsync(hp + 36, dall, G * pw * 8, hipMemcpyDeviceToHost, c->stream));
-  ARK_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int rc = comm_sync(c, c->stream)) return rc;   // behind the all-gather: bounded
   return ark_hip_sw_sum(curve, hp + 36, G, out_xyz);
 }
 

@@ -595,5 +595,7 @@ inline int ring_release(Context* c, int k, hipStream_t compute) {
   return 0;
 }
 
+// bounded wait for a stream that carries a collective (capi_comm.hip)
+int comm_sync(Context* c, hipStream_t st);
 }  // namespace capi
 }  // namespace arkhip

@@ -216,6 +216,7 @@ static int gfft_entry(Context* c, int curve, const ark_hip_radix2_domain* dom, v
   const int field = CURVES[curve].scalar_field;
   const int k = (int)dom->log_size_of_group;
   if (k < 0 || k > 26 || dom->size != ((uint64_t)1 << k)) return ARK_HIP_ERR_ARG;
+  if (!domain_is_of_field(field, dom)) return ARK_HIP_ERR_ARG;   // a domain of another scalar field than the curve's
   const size_t n = (size_t)1 << k;
   const bool coset = !field_is_one(field, dom->offset);
   const uint32_t* roots = nullptr;

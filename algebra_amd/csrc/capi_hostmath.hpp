@@ -107,6 +107,29 @@ inline bool field_is_one(int field, const uint64_t* x) {
   }
   return false;
 }
+// Does `dom` belong to field FP?  A domain struct carries no field id; its constants are 32-byte residues of SOME field.  The
+// generator of a size-2^k domain satisfies g^(2^k) = 1 and g * g_inv = 1 in its own field, and (with overwhelming probability) in
+// no other: k squarings and one product on the host (a BN254 domain handed to a BLS12-381 curve's transform over
+// group elements gave garbage points silently).  A residue that is not even canonical in FP (>= p) fails as well.
+template <class FP>
+bool host_domain_is_of_field(const ark_hip_radix2_domain* dom) {
+  typedef Fp<FP> F;
+  const F g = F::load(dom->group_gen), gi = F::load(dom->group_gen_inv);
+  if (!F::eq(g, g.canonical()) || !F::eq(gi, gi.canonical())) return false;
+  F t = g;
+  for (uint32_t i = 0; i < dom->log_size_of_group; i++) t = F::sqr(t);
+  return F::eq(t, F::one()) && F::eq(F::mul(g, gi), F::one());
+}
+inline bool domain_is_of_field(int field, const ark_hip_radix2_domain* dom) {
+  switch (field) {
+#ifndef ARK_HIP_DEV
+    case ARK_HIP_BN254_FR: return host_domain_is_of_field<BN254_FR>(dom);
+    case ARK_HIP_BLS12_377_FR: return host_domain_is_of_field<BLS12_377_FR>(dom);
+#endif
+    case ARK_HIP_BLS12_381_FR: return host_domain_is_of_field<BLS12_381_FR>(dom);
+  }
+  return false;
+}
 template <class FP>
 int domain_new(size_t num_coeffs, ark_hip_radix2_domain* out) {
   typedef Fp<FP> F;

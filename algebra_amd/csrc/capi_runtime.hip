@@ -70,6 +70,11 @@ void ark_hip_shutdown(void) {
 int ark_hip_synchronize(void) {
   ARK_SCOPE(sc);
   ARK_HIP_TRY(hipStreamSynchronize(sc.c->copy_stream));
+  if (sc.c->comm && sc.c->comm_world > 1) {   // collectives may be queued (the sharded FFT is asynchronous): a bounded wait
+    if (int rc = comm_sync(sc.c, sc.c->stream)) return rc;
+    if (sc.c->comm_stream)
+      if (int rc = comm_sync(sc.c, sc.c->comm_stream)) return rc;
+  }
   if (int rc = sync_compute(sc.c)) return rc;
   return 0;
 }

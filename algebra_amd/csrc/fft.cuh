@@ -1117,13 +1117,25 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
     const size_t nlo = k < 0 ? 0 : ((size_t)1 << PW_LO_BITS);
     const size_t nhi = k < 0 ? 0 : (k > PW_LO_BITS ? ((size_t)1 << (k - PW_LO_BITS)) : 1);
     const bool want_full = !form29 && k >= 12 && fft_full_powers_env() && (((size_t)32 << k) <= FFT_POWERS_BUDGET / 4);
-    const size_t nfull = want_full ? ((size_t)1 << k) : 0;
+    size_t nfull = want_full ? ((size_t)1 << k) : 0;
     DevBuf buf;
     struct Guard {
       DevBuf* b;
       ~Guard() { if (b) b->release(); }
     } guard{&buf};
-    if (buf.ensure((nlo + nhi + 3 + nfull) * F::BYTES)) return -3;
+    // the expanded table is OPTIONAL (it saves one product per element: 3 % of a coset transform): under memory pressure -- a
+    // verified cache at its budget, a large prepared table -- the two factor tables (a few hundred KB) are what the transform
+    // needs, and the round-4 two-factor path serves (a failed 2^k x 32 B allocation used to fail the transform)
+    if (nfull) {
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < ((nlo + nhi + 3 + nfull) * F::BYTES) + ((size_t)256 << 20)) nfull = 0;
+    }
+    if (buf.ensure((nlo + nhi + 3 + nfull) * F::BYTES)) {
+      if (!nfull) return -3;
+      (void)hipGetLastError();
+      nfull = 0;
+      if (buf.ensure((nlo + nhi + 3) * F::BYTES)) return -3;
+    }
     u32* base = (u32*)buf.p;
     u32* d_c = base + (nlo + nhi) * F::N;  // [base | mul | 2^261 mod p], then the expanded table
     // host-side scaling of the hi factor / the constant: m 2^261 = mont_mul(m R, 2^261 mod p)

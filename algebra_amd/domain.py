@@ -194,6 +194,9 @@ class Radix2EvaluationDomain:
         from . import curves as cv
         L = lib()
         cid = cv.curve_id(curve)
+        if cv.field_id(cv.scalar_field(cid)) != self.field:   # (the C entry checks it too: the domain's generator in the curve's Fr)
+            raise ValueError("a domain over %s cannot transform points of %s (scalar field %s)"
+                             % (cv.FIELDS[self.field], cv.curve_name(cid), cv.scalar_field(cid)))
         n = self.size()
         if _is_torch(points):
             import torch

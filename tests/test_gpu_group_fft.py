@@ -112,3 +112,23 @@ def test_group_fft_in_several_slabs(cname, monkeypatch):
         assert np.array_equal(slab_f, whole_f) and np.array_equal(slab_i, whole_i) and np.array_equal(slab_dev, whole_f)
         back = d.fft_group_in_place(cname, whole_f.copy(), inverse=True)
         assert np.array_equal(A.into_affine(cid, back), A.into_affine(cid, pts))
+
+
+def test_a_domain_of_another_field_is_refused():
+    """`ark_hip_radix2_domain` carries no field id -- a BN254 domain handed to a BLS12-381 curve's transform over
+    group elements used to be reinterpreted in the wrong field and give garbage points.  The Python mirror compares the field
+    ids; the C entry checks that the domain's generator is a size-th root of unity in the CURVE's scalar field."""
+    import ctypes as C
+    from algebra_amd._lib import lib
+    cid = O.CID["BLS12_381_G1"]
+    n = 1 << 6
+    fw = O.fe_words(cid)
+    pts = np.zeros((n, 3 * fw), dtype=np.uint64)          # identities: z = 0
+    wrong = A.Radix2EvaluationDomain.new("BN254_FR", n)
+    with pytest.raises(ValueError):
+        wrong.fft_group_in_place("BLS12_381_G1", pts)
+    rc = lib().ark_hip_fft_group_in_place(cid, C.byref(wrong._s), pts.ctypes.data_as(C.c_void_p), 0)
+    assert rc == -1                                        # ARK_HIP_ERR_ARG, points untouched
+    assert not pts.any()
+    right = A.Radix2EvaluationDomain.new("BLS12_381_FR", n)
+    assert lib().ark_hip_fft_group_in_place(cid, C.byref(right._s), pts.ctypes.data_as(C.c_void_p), 0) == 0
