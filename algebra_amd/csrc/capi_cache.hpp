@@ -154,7 +154,10 @@ inline Hash128 base_hash(const uint64_t* p, size_t words) {
 
 inline void cache_configure(Context* c) {
   if (c->cache_budget < 0) {
-    // default: a quarter of the device memory (ARK_HIP_BASE_CACHE_MB=0 or ark_hip_msm_cache_config(0, ..) turn it off).
+    // default: 16 GiB, never more than a quarter of the device memory -- room for a 2^26-point G1 SRS or a 2^24-point G2 one; a
+    // library loaded into someone's prover does not claim 72 GB by itself (round 5's default: a quarter of HBM).  Larger sets, or
+    // prepared tables kept with them (auto-prepare, off by default), are opt-in: ARK_HIP_BASE_CACHE_MB / ark_hip_msm_cache_config
+    // (0 turns the cache off).
     // The cache never changes a result: every hit is validated against a hash of the slice's full content, which host
     // threads compute while the device works (2^24 BLS12-381 G1: 40.2 ms per call cached, 40.2 pinned, 47.8 streamed,
     // 36.4 resident -- profiles/r4_trait_modes_sessionA.txt)
@@ -163,6 +166,7 @@ inline void cache_configure(Context* c) {
     if (budget < 0) {
       size_t fr = 0, tot = 0;
       budget = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 4) : (8ll << 30);
+      if (budget > (16ll << 30)) budget = 16ll << 30;
     }
     c->cache_budget = budget;
   }

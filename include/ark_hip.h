@@ -121,7 +121,7 @@ int ark_hip_msm_sw(int curve, const uint64_t* bases, const uint64_t* scalars, si
  * 40 ms per call against 48 ms streamed).  A slice that does not fit the budget streams over PCIe with its scalars, piece
  * k+1 under piece k's kernels.  Least-recently-used sets (with their tables) are dropped beyond the budget.
  *   ark_hip_msm_cache_config(budget_bytes, auto_prepare_after): budget -1 keeps the current value, -2 restores the
- *     default (a quarter of the device memory, or ARK_HIP_BASE_CACHE_MB), 0 disables and empties the cache (every call
+ *     default (16 GiB, at most a quarter of the device memory; ARK_HIP_BASE_CACHE_MB raises or lowers it), 0 disables and empties the cache (every call
  *     then streams bases and scalars and nothing is retained); auto_prepare_after = K > 0 builds the per-window table of a
  *     resident set -- pinned or cached -- once the WHOLE set has been the operand K times (default 0 = never, or
  *     ARK_HIP_AUTO_PREPARE; a cached set's table counts against the budget), < 0 keeps the current value.

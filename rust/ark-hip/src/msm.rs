@@ -253,8 +253,8 @@ impl<'a, P: SWCurveConfig> Drop for ResidentBases<'a, P> {
     }
 }
 
-/// The verified cache behind `sw_msm` / `sw_msm_bigint` (include/ark_hip.h, `ark_hip_msm_cache_*`; on by default with a
-/// quarter of the device memory, `ARK_HIP_BASE_CACHE_MB` overrides): device copies keyed by (curve, address, length),
+/// The verified cache behind `sw_msm` / `sw_msm_bigint` (include/ark_hip.h, `ark_hip_msm_cache_*`; on by default with
+/// 16 GiB -- at most a quarter of the device memory --, `ARK_HIP_BASE_CACHE_MB` overrides): device copies keyed by (curve, address, length),
 /// validated on every call by a hash of the slice's FULL content computed on host threads while the device works from the
 /// copy; a changed slice is refreshed and the MSM rerun, so a result never reflects stale bases.
 /// `budget_bytes = Some(0)` turns it off (every call then streams its bases over PCIe).
