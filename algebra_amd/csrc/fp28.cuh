@@ -476,14 +476,6 @@ struct FpL {
     for (int i = 0; i < L; i++) r.l[i] = neg ? kp_spread<K, 1>(i) - a.l[i] : a.l[i];
     return r;
   }
-  // neg ? K p - a : a for ANY K (a normalised, below K p; limbs below 2^(W+1)): the digit's sign on a repacked coordinate
-  template <int K>
-  ARK_HD static FpL cond_neg_any(const FpL& a, bool neg) {
-    FpL r;
-#pragma unroll
-    for (int i = 0; i < L; i++) r.l[i] = neg ? kp_spread_any<K, 1>(i) - a.l[i] : a.l[i];
-    return r;
-  }
   // a - b - 2 c + K p, NORMALISED (a, b, c normalised): limbs a_i - b_i - 2 c_i + d_i with d_i >= 3 2^28 - 3 stay
   // non-negative, so the carry sweep is unsigned
   template <int K>

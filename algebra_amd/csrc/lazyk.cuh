@@ -2,12 +2,6 @@
 // (canonical limbs: Fp, or the lane-pair Fp2Half), the accumulator in carry-free limbs and the additions on it --
 // ec28.cuh for the prime-field curves (one lane per bucket), ec28x2.cuh for G2 (one lane PAIR per bucket).
 #pragma once
-#ifndef ARK_ACC_SIGN28
-#define ARK_ACC_SIGN28 0   // A/B builds (tools/build_variant.sh): see LazyK<C, 1>::madd
-#endif
-#ifndef ARK_ACC_SKIP_IDENTITY
-#define ARK_ACC_SKIP_IDENTITY 0   // A/B builds: the accumulate kernels do not test gathered bases for the identity (0, 0)
-#endif
 #include "curves.cuh"
 #include "ec28.cuh"
 #include "ec28x2.cuh"
@@ -36,15 +30,7 @@ struct LazyK<C, 1> {
   // acc += (+-) p, a non-identity base as gathered; true: p EQUALS the accumulated point (the caller doubles the base)
   ARK_HD static bool madd(Acc& acc, const Affine<FM>& p, bool neg) {
     FL lx, ly;
-#if ARK_ACC_SIGN28
-    // (experiment, round 6: the digit's sign applied AFTER the repack, limb-wise on the carry-free form -- 2^SH p - y, a legal
-    // multiplication operand below 2^SH p with limbs below 2^(W+1) -- instead of the canonical p - y with its borrow chain
-    // and zero test; measured: profiles/r6_accumulate_diet_ab.txt)
-    lazy_from_affine<P>(p.x, p.y, lx, ly);
-    ly = FL::template cond_neg_any<(1 << FL::SH) + 1>(ly, neg);   // K must exceed the subtrahend's bound (2^SH) by >= 1/2
-#else
     lazy_from_affine<P>(p.x, FM::cond_neg(p.y, neg), lx, ly);
-#endif
     return xyzz_madd_lazy<P>(acc, lx, ly);
   }
   ARK_HD static void mdbl(Acc& out, const char* src, bool neg) { xyzz_mdbl_lazy<P>(out, src, neg); }

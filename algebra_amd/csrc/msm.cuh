@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(256, ARK_LAZY_MIN_WAVES) msm_accumulate_lazy_k
         p_next = Affine<F>::load(bases + (size_t)(e1 & 0x7fffffffu) * Affine<F>::BYTES);
         if (j + 2 < end) e2 = sorted[j + 2];
       }
-      if (ARK_ACC_SKIP_IDENTITY || !p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
+      if (!p.is_zero()) {  // identity base contributes nothing (bucket.rs:171-173)
         if (K::madd(acc, p, (e >> 31) != 0))   // the base equals the accumulated point (duplicate bases): doubling, from a re-read base
           K::mdbl(acc, bases + (size_t)(e & 0x7fffffffu) * Affine<F>::BYTES, (e >> 31) != 0);
       }
