@@ -549,8 +549,9 @@ inline int msm_enqueue_ctx(Context* c, int curve, const void* pts, size_t wstrid
                                   piece);
   return slot < 0 ? slot : lane * MSM_JOBS + slot;
 }
-// May be called WITHOUT the context lock held (ark_hip_msm_wait): the timings go through a local and are published
-// under the (recursive) lock.
+// Called WITHOUT the context lock by ark_hip_msm_wait -- it takes no lock but the lane's and the slot mutex, so a job can always
+// be finished and its slot freed while another thread's streaming body holds the context (round 6; before, a wait queued
+// behind such a body, whose next piece was in turn waiting for the slot: a stall of seconds under mixed callers).
 inline int msm_finish_ctx(Context* c, int curve, int slot, uint64_t* out) {
   if (slot < 0 || slot >= 2 * MSM_JOBS) return ARK_HIP_ERR_ARG;
   MsmTimings tm;
@@ -561,7 +562,7 @@ inline int msm_finish_ctx(Context* c, int curve, int slot, uint64_t* out) {
   }
   c->slot_cv.notify_all();
   if (rc == 0 && tm.c != 0) {
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    std::lock_guard<std::mutex> lk(c->slot_mu);   // (NOT the context lock: a wait must never queue behind a streaming body)
     c->msm_tm = tm;
   }
   return rc;

@@ -27,12 +27,27 @@ static int msm_prepared_small_device_once(const ark_hip_msm_bases* bases, const 
                                       int max_bits, uint64_t* out_xyz);
 static int msm_sw_chunks_once(int curve, const uint64_t* bases, size_t n_bases, const uint64_t* scalars, size_t n_scalars,
                           size_t step, uint64_t* out_xyz);
+static int msm_jobs_in_flight(Context* c) {
+  int busy = 0;
+  for (int l = 0; l < 2; l++) {
+    std::lock_guard<std::mutex> lock(c->msm[l].mu);
+    for (const auto& j : c->msm[l].jobs) busy += j.busy ? 1 : 0;
+  }
+  return busy;
+}
 template <class Body>
 static int retry_while_busy(int logical, Body body) {
   for (;;) {
     Context* c = nullptr;
     uint64_t gen = 0;
-    if (get_ctx(logical == -2 ? t_dev : logical, &c) == 0) gen = c->slot_gen.load(std::memory_order_acquire);
+    if (get_ctx(logical == -2 ? t_dev : logical, &c) == 0) {
+      // callers that outnumber the slots queue HERE, before the body: a body that ends in BUSY has already looked its bases up,
+      // started a hashing pass or staged an upload for nothing (32 mixed callers: 30 calls/s before this check, see
+      // tools/thread_soak.py), and every finished job would wake all of them to do it again
+      std::unique_lock<std::mutex> lk(c->slot_mu);
+      c->slot_cv.wait_for(lk, std::chrono::milliseconds(20), [&]() { return msm_jobs_in_flight(c) < MSM_JOBS; });
+      gen = c->slot_gen.load(std::memory_order_acquire);
+    }
     const int rc = body();
     if (rc != ARK_HIP_ERR_BUSY || !c) return rc;
     std::unique_lock<std::mutex> lk(c->slot_mu);
@@ -62,17 +77,14 @@ int ark_hip_msm_sw_device_async(int curve, const void* d_bases, const void* d_sc
 int ark_hip_msm_wait(ark_hip_msm_job* job, uint64_t* out_xyz) {
   if (!job) return ARK_HIP_ERR_ARG;
   MsmJobHandle* h = (MsmJobHandle*)job;
-  int rc;
-  {
-    Scope sc;
-    rc = sc.enter(h->logical);
-    if (rc == 0) {
-      // the event wait and the host tail run WITHOUT the context lock: other threads may enqueue meanwhile
-      Context* c = sc.c;
-      sc.lk.unlock();
-      uint64_t scratch[36];
-      rc = msm_finish_ctx(c, h->curve, h->slot, out_xyz ? out_xyz : scratch);
-    }
+  // no context lock at all: the event wait and the host tail need the lane's job table only (get_ctx also makes the job's
+  // device this thread's current one).  A wait therefore never queues behind another thread's entry point -- whose streaming
+  // body may itself be waiting for THIS job's slot.
+  Context* c = nullptr;
+  int rc = get_ctx(h->logical, &c);
+  if (rc == 0) {
+    uint64_t scratch[36];
+    rc = msm_finish_ctx(c, h->curve, h->slot, out_xyz ? out_xyz : scratch);
   }
   delete h;
   return rc;
@@ -297,7 +309,11 @@ int ark_hip_msm_set_timing(int enable) {
 int ark_hip_msm_last_timing(double out[8]) {
   if (!out) return ARK_HIP_ERR_ARG;
   ARK_SCOPE(sc);
-  const MsmTimings& t = sc.c->msm_tm;
+  MsmTimings t;
+  {
+    std::lock_guard<std::mutex> lk(sc.c->slot_mu);
+    t = sc.c->msm_tm;
+  }
   out[0] = t.digits; out[1] = t.scan; out[2] = t.scatter; out[3] = t.accumulate; out[4] = t.reduce; out[5] = t.total;
   out[6] = t.c; out[7] = t.W;
   return 0;

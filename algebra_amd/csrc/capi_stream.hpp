@@ -133,7 +133,23 @@ inline int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t
     if (npend == 2) {
       if (int rc = drain_one()) return fail(rc);
     }
-    const int lane = msm_pick_lane(c);  // before anything is put in flight: BUSY must leave nothing behind
+    // a lane with a free job slot -- before anything of this piece is put in flight.  All four taken: first this call's own
+    // oldest piece is finished (its slot is ours to free); then other threads' jobs are given a bounded time to be waited for
+    // (ark_hip_msm_wait takes no context lock, so they can be, although this body holds it); then BUSY, which leaves nothing
+    // behind (the synchronous entries retry the whole call: capi_msm.hip retry_while_busy)
+    int lane = msm_pick_lane(c);
+    if (lane == ARK_HIP_ERR_BUSY && npend) {
+      if (int rc = drain_one()) return fail(rc);
+      lane = msm_pick_lane(c);
+    }
+    for (int tries = 0; lane == ARK_HIP_ERR_BUSY && tries < 25; tries++) {   // <= 25 x 20 ms
+      {
+        std::unique_lock<std::mutex> lk(c->slot_mu);
+        const uint64_t gen = c->slot_gen.load(std::memory_order_acquire);
+        c->slot_cv.wait_for(lk, std::chrono::milliseconds(20), [&]() { return c->slot_gen.load(std::memory_order_acquire) != gen; });
+      }
+      lane = msm_pick_lane(c);
+    }
     if (lane < 0) return fail(lane);
     hipStream_t compute;
     if (int rc = msm_lane_stream(c, lane, &compute)) return fail(rc);

@@ -130,3 +130,23 @@ def test_pool_off_gives_the_same_points(monkeypatch):
     env = dict(os.environ, ARK_HIP_HOST_TAIL_THREADS="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_mixed_entry_points_under_32_threads():
+    """tools/thread_soak.py for ten seconds: 32 threads call a random MIX of entry points (device / host / prepared / asynchronous /
+    narrow / chunked MSMs on three curves, transforms from host and device memory on three fields), every result against the
+    oracle.  Besides parity it guards a stall this round found: a streamed MSM (msm_chunks, the host-pointer entry) whose next
+    piece waited for a job slot while the threads that owned the slots queued, inside ark_hip_msm_wait, for the context lock the
+    stream was holding -- 38 calls in 48 s with asynchronous callers beside it (profiles/r6_thread_soak.txt).  The wait takes no
+    context lock any more and a stream drains its own pieces / waits bounded for a slot: hundreds of calls per second."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "thread_soak.py"), "32", "10", "11"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    m = re.search(r"thread soak: (\d+) calls in ([0-9.]+) s on 32 threads, 0 mismatches, 0 exceptions", r.stdout)
+    assert m, r.stdout[-800:]
+    assert int(m.group(1)) / float(m.group(2)) > 150.0, r.stdout[-400:]   # (measured: ~2000 calls/s; the stall: 0.8)
