@@ -1546,6 +1546,7 @@ struct MsmJob {
   void* pinned = nullptr;
   size_t pinned_cap = 0;
   hipEvent_t done = nullptr;
+  hipEvent_t acc_done = nullptr;   // recorded in front of the bucket reduction: when the host tail's helpers are called in (msm_finish)
   bool busy = false;
   bool empty = false;     // n == 0: identity, nothing enqueued
   bool no_result = false; // a non-final piece of a streamed MSM (MsmPiece): only the scalar-range flag comes back
@@ -1589,6 +1590,7 @@ struct MsmWorkspace {
       j.pinned = nullptr;
       j.pinned_cap = 0;
       if (j.done) (void)hipEventDestroy(j.done);
+      if (j.acc_done) (void)hipEventDestroy(j.acc_done);
       j.done = nullptr;
       for (auto& e : j.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
       j.busy = false;
@@ -1830,6 +1832,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     if (rc) return rc;
   }
   if (!job.done) ARK_HIP_TRY(hipEventCreateWithFlags(&job.done, hipEventDisableTiming));
+  if (!job.acc_done) ARK_HIP_TRY(hipEventCreateWithFlags(&job.acc_done, hipEventDisableTiming));
   if (timing) {
     for (auto& e : job.ev)
       if (!e) ARK_HIP_TRY(hipEventCreate(&e));
@@ -2192,6 +2195,7 @@ int msm_enqueue(MsmWorkspace& ws, const void* d_points, size_t wstride, const Ms
     return slot;
   }
 
+  ARK_HIP_TRY(hipEventRecord(job.acc_done, stream));   // the accumulate kernels are through: the reduction's 0.4-9 ms remain
   if (split_reduce) {
     reduce_windows((size_t)grp[1].w0, (size_t)grp[1].Wg, stream);
     ARK_HIP_TRY(hipStreamWaitEvent(stream, ws.grp_ev[1], 0));   // group 0's sums
@@ -2346,12 +2350,14 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
   const MsmPlan& pl = job.pl;
   const int c = pl.c, W = pl.W, Wr = pl.red_windows(), nbits = job.nbits;
   const u32 Q = job.Q;
-  // Short jobs: the tail -- ~5400 field products over Fp384, 0.2 ms -- is a fifth of a 2^16 call, and half of it is the windows'
-  // own sums, which are independent.  They go to the process-wide helper pool (hostpool.hpp; round 5 created seven threads per
+  // The tail -- ~5400 field products over Fp384, 0.2 ms: a fifth of a 2^16 call, 3 % of a 2^20 one -- is half the windows' own
+  // sums, which are independent.  They go to the process-wide helper pool (hostpool.hpp; round 5 created seven threads per
   // call here and let them spin without bound).  The batch is opened BEFORE the wait for the GPU, so the helpers' wake-up hides
-  // under the kernels; its gate opens when the part sums have landed, and this thread claims windows from the same counter --
-  // helpers that are busy elsewhere or asleep cost nothing but their share.  A job whose GPU work has already finished keeps the
-  // single Horner.  ARK_HIP_HOST_TAIL_THREADS=0: no pool.
+  // under the kernels -- for a short job at once, for a longer one when its accumulate kernels are through (job.acc_done: the
+  // reduction's 0.4-9 ms remain; a helper spins for at most a millisecond, then sleeps in 50 us steps); the gate opens when the
+  // part sums have landed, and this thread claims windows from the same counter -- helpers that are busy elsewhere or asleep
+  // cost nothing but their share.  A job whose GPU work has already finished keeps the single Horner.
+  // ARK_HIP_HOST_TAIL_THREADS=0: no pool.
   std::vector<Pt> early_T;
   MsmWindowSums<C> early_ws{(const char*)job.pinned, Q, nbits, job.log2L0, nullptr};
   HostPool::Handle early;
@@ -2361,9 +2367,9 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
       if (h) HostPool::instance().cancel(h);
     }
   } early_guard{early};
-  if (out_xyz && !job.no_result && job.short_job && Wr >= 8 && HostPool::instance().helpers() > 0 &&
-      hipEventQuery(job.done) == hipErrorNotReady) {
+  if (out_xyz && !job.no_result && Wr >= 8 && HostPool::instance().helpers() > 0 && hipEventQuery(job.done) == hipErrorNotReady) {
     (void)hipGetLastError();
+    if (!job.short_job && job.acc_done) ARK_HIP_TRY(msm_wait_event(job.acc_done));
     try {
       early_T.resize((size_t)Wr);
       early_ws.T = early_T.data();
