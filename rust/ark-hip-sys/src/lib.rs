@@ -57,6 +57,8 @@ extern "C" {
     pub fn ark_hip_shutdown();
     pub fn ark_hip_synchronize() -> c_int;
     pub fn ark_hip_version() -> *const c_char;
+    /// `out[0]` = helper threads of the process-wide pool (parked while idle), `out[1]` = threads it has ever created.
+    pub fn ark_hip_host_threads(out: *mut c_int) -> c_int;
     pub fn ark_hip_malloc(bytes: usize, out_dptr: *mut *mut c_void) -> c_int;
     pub fn ark_hip_free(dptr: *mut c_void) -> c_int;
     pub fn ark_hip_memcpy_h2d(dst_dptr: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
