@@ -2367,7 +2367,9 @@ int msm_finish(MsmWorkspace& ws, int slot, uint64_t* out_xyz, MsmTimings* tm) {
       if (h) HostPool::instance().cancel(h);
     }
   } early_guard{early};
-  if (out_xyz && !job.no_result && Wr >= 8 && HostPool::instance().helpers() > 0 && hipEventQuery(job.done) == hipErrorNotReady) {
+  static const bool tail_all = [] { const char* e = getenv("ARK_HIP_HOST_TAIL_ALL"); return !(e && e[0] == '0'); }();   // A/B: 0 = short jobs only
+  if (out_xyz && !job.no_result && (job.short_job || tail_all) && Wr >= 8 && HostPool::instance().helpers() > 0 &&
+      hipEventQuery(job.done) == hipErrorNotReady) {
     (void)hipGetLastError();
     if (!job.short_job && job.acc_done) ARK_HIP_TRY(msm_wait_event(job.acc_done));
     try {
