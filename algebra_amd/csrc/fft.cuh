@@ -1358,6 +1358,9 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
       if (ti < min_t) ti = min_t;
       const int room = (i == P - 1) ? (k - kps[i]) : (k - s0 - kps[i]);  // bits available for columns
       if (ti > room) ti = room;
+    } else if (tile_log > 10) {   // ONE executed pass of 9 .. 11 stages on the larger tiles: the columns that fit the tile and exist
+      if (kps[i] + ti > tile_log) ti = tile_log - kps[i];
+      if (ti > k - kps[i]) ti = k - kps[i];
     }
     a.k = k; a.s0 = s0; a.kp = kps[i]; a.t = ti; a.last = (i == P - 1) ? 1 : 0;
     a.zskip = (i == 0) ? zlog : 0;
