@@ -1319,6 +1319,19 @@ int fft_run_device(FftWorkspace& ws, void* d_data, int k, const uint64_t* root4,
             break;
           }
     }
+    // the SHORT pass first (round 6): the first pass reads the stage-0 .. twiddles, all distinct, and a pass of fewer stages
+    // takes more adjacent columns -- 2^22 as 6 + 8 + 8 stages is 0.8 % faster than 8 + 8 + 6 single, 2 % in a batch
+    // (profiles/r6_fft_pass_order_ab.txt).  ARK_HIP_FFT_ASCENDING=0: the order of rounds 2-5 (longest first).
+    {
+      static const bool asc = [] { const char* e = getenv("ARK_HIP_FFT_ASCENDING"); return !(e && e[0] == '0'); }();
+      if (asc && P <= 3)   // (four passes, 2^25 and up: measured 1.3 % slower that way -- left longest first)
+        for (int i = 1; i < P; i++)   // insertion sort
+          for (int j = i; j > 0 && kps[j - 1] > kps[j]; j--) {
+            const int tmpk = kps[j];
+            kps[j] = kps[j - 1];
+            kps[j - 1] = tmpk;
+          }
+    }
     // an explicit plan (experiments): ARK_HIP_FFT_PLAN=12,10 -- stage counts per pass, each <= tile_log, summing to kx
     if (const char* pe = getenv("ARK_HIP_FFT_PLAN")) {
       int q[8], nq = 0, sum = 0;
