@@ -110,6 +110,8 @@ def fft_issue_bound(kf, nf, dev_ms):
                 kps[i] += 1
                 kps[j] -= 1
                 break
+    if P <= 3:
+        kps.sort()                                # round 6: the shortest pass first (fft.cuh fft_run_device)
     rounds2 = sum(kp // 2 for kp in kps)          # two-stage rounds: nf / 4 groups of four points each
     rounds1 = sum(kp % 2 for kp in kps)           # single-stage rounds: nf / 2 butterflies, half a group's work each
     groups = nf / 4.0 * (rounds2 + 0.5 * rounds1)
