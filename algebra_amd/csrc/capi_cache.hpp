@@ -91,6 +91,11 @@ struct HashPass {   // one pass over a host slice: first-level block hashes by r
   std::atomic<int> left{0};
   std::chrono::steady_clock::time_point t0, t1;
   HostPool::Handle batch;
+  HashPass() = default;
+  HashPass(const HashPass&) = delete;
+  ~HashPass() {   // a pass that was begun is always joined before its block table goes away (helpers may be inside a task)
+    if (batch) HostPool::instance().run(batch);
+  }
   static void task(void* ctx, int r) {
     HashPass& h = *(HashPass*)ctx;
     const HashKey& hk = hash_key();
