@@ -17,12 +17,63 @@ inline int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t
   const size_t ab = (size_t)CURVES[curve].fe_words * 16;
   const size_t pw = (size_t)CURVES[curve].fe_words * 3;
   if (step == 0 || step > n) step = n;
-  // piece sizes: equal steps, or -- `growing`, scalars-only uploads against resident bases -- each piece twice the one
-  // before it: a piece's upload hides under the previous piece's kernels as long as it is less than ~3x as large (the MSM
+  // piece sizes: equal steps, or -- `growing`, scalars-only uploads against resident bases -- each piece twice (from 2^23
+  // pairs: three times, below) the one before it: a piece's upload hides under the previous piece's kernels as long as it is less than ~3x as large (the MSM
   // spends 2.1 ns per pair, the PCIe copy 0.64 ns per 32-byte scalar), so the one upload nothing hides shrinks to
   // n / (2^P - 1) pairs and the per-piece costs (launches, the read-modify-write of every bucket) are paid P <= 6 times
   std::vector<size_t> sizes;
-  if (growing && n >= ((size_t)3 << 18)) {
+  auto parse_weights = [](const char* e) {   // "a,b,c,..": positive weights; anything else: empty (the variable is ignored)
+    std::vector<size_t> wts;
+    for (const char* q = e; q && *q;) {
+      char* end = nullptr;
+      const size_t v = (size_t)strtoul(q, &end, 10);
+      if (end == q) {   // not a number: strtoul consumed nothing (it used to loop here for ever)
+        wts.clear();
+        break;
+      }
+      if (v) wts.push_back(v);
+      q = end;
+      if (*q == ',') q++;
+    }
+    return wts;
+  };
+  auto by_weights = [&](const std::vector<size_t>& wts) {
+    size_t wsum = 0;
+    for (size_t w : wts) wsum += w;
+    size_t left = n;
+    step = 0;
+    for (size_t k = 0; k < wts.size() && left; k++) {
+      size_t take = k + 1 == wts.size() ? left : ((n / wsum) * wts[k]) & ~(size_t)255;
+      if (take == 0 || take > left) take = left;
+      sizes.push_back(take);
+      left -= take;
+      step = take > step ? take : step;
+    }
+    if (left) {
+      sizes.back() += left;
+      step = sizes.back() > step ? sizes.back() : step;
+    }
+  };
+  const std::vector<size_t> grow_wts = growing ? parse_weights(getenv("ARK_HIP_STREAM_GROW_SCHEDULE")) : std::vector<size_t>();
+  if (growing && n >= ((size_t)3 << 18) && grow_wts.size() >= 2 && grow_wts.size() <= 16) {
+    by_weights(grow_wts);   // experiments: the growing pieces' weights, e.g. "1,3,9,27"
+  } else if (growing && n >= ((size_t)1 << 23)) {
+    // from 2^23 pairs: each piece THREE times the one before it, at most four (round 6, profiles/r6_growing_pieces.txt): a
+    // piece's upload still hides under the previous piece's kernels (0.54 ns of PCIe per scalar against 2.1 ns of MSM per pair
+    // allow a factor of ~3.9), and four pieces pay the per-piece costs -- ~30 launches, sparse runs in the early pieces, the
+    // read-modify-write of every bucket -- four times instead of six: 2^24 40.4 -> 39.25 ms, 2^23 21.4 -> 21.05, 2^25 72.8 -> 71.5,
+    // 2^26 140.0 -> 137.8 (2^22 and below: the doubling pieces remain the faster ones)
+    int P = 1;
+    size_t geo = 1, pw3 = 1;   // geo = 1 + 3 + .. + 3^(P-1)
+    while (P < 4 && n / (geo + pw3 * 3) >= ((size_t)1 << 18)) {
+      pw3 *= 3;
+      geo += pw3;
+      P++;
+    }
+    std::vector<size_t> wts;
+    for (size_t k = 0, w = 1; k < (size_t)P; k++, w *= 3) wts.push_back(w);
+    by_weights(wts);
+  } else if (growing && n >= ((size_t)3 << 18)) {
     int P = 1;
     while (P < 6 && (n / (((size_t)1 << (P + 1)) - 1)) >= ((size_t)1 << 18)) P++;
     size_t first = (n / (((size_t)1 << P) - 1)) & ~(size_t)255;
@@ -41,36 +92,9 @@ inline int msm_stream(Context* c, int curve, const void* d_bases, const uint64_t
     // middle pieces stall the copy (2,4,10,8,4,2,1,1 / 32: 54.4 ms), and a halving tail (.., 4, 2, 1, 1 / 64: 48.7 ms) or
     // sixteenths (49.4 ms) pay more per piece than the shorter last piece saves (profiles/r4_trait_modes_and_schedules_sessionB.txt).
     // ARK_HIP_STREAM_SCHEDULE="a,b,c,.." (weights) overrides for experiments.
-    std::vector<size_t> wts;
-    if (const char* e = getenv("ARK_HIP_STREAM_SCHEDULE")) {
-      for (const char* q = e; *q;) {
-        char* end = nullptr;
-        const size_t v = (size_t)strtoul(q, &end, 10);
-        if (end == q) {   // not a number: strtoul consumed nothing (it used to loop here for ever) -- ignore the variable
-          wts.clear();
-          break;
-        }
-        if (v) wts.push_back(v);
-        q = end;
-        if (*q == ',') q++;
-      }
-    }
+    std::vector<size_t> wts = parse_weights(getenv("ARK_HIP_STREAM_SCHEDULE"));
     if (wts.empty()) wts.assign(8, 1);
-    size_t wsum = 0;
-    for (size_t w : wts) wsum += w;
-    size_t left = n;
-    step = 0;
-    for (size_t k = 0; k < wts.size() && left; k++) {
-      size_t take = k + 1 == wts.size() ? left : ((n / wsum) * wts[k]) & ~(size_t)255;
-      if (take == 0 || take > left) take = left;
-      sizes.push_back(take);
-      left -= take;
-      step = take > step ? take : step;
-    }
-    if (left) {
-      sizes.back() += left;
-      step = sizes.back() > step ? sizes.back() : step;
-    }
+    by_weights(wts);
   } else {
     for (size_t off = 0; off < n; off += step) sizes.push_back(n - off < step ? n - off : step);
   }
