@@ -51,6 +51,25 @@ __global__ void __launch_bounds__(256) fft_pow_table_kernel(const u32* __restric
   }
   r.store(out + (size_t)j * F::N);
 }
+// the same with base and multiplier passed BY VALUE (kernel arguments: nothing to stage, nothing to wait for)
+struct FftElemArg { u32 w[8]; };   // one element of a served scalar field: 4 x 64 bits
+template <class FP>
+__global__ void __launch_bounds__(256) fft_pow_table_val_kernel(FftElemArg base, FftElemArg mulby, int has_mul, u32 count,
+                                                                u32* __restrict__ out) {
+  typedef Fp<FP> F;
+  static_assert(F::N == 8, "FftElemArg holds 8 words");
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  F b = F::load(base.w);
+  F r = has_mul ? F::load(mulby.w) : F::one();
+  u32 e = j;
+  while (e) {
+    if (e & 1) r = F::mul(r, b);
+    b = F::sqr(b);
+    e >>= 1;
+  }
+  r.store(out + (size_t)j * F::N);
+}
 // roots[j] = hi[j >> LO] * lo[j & mask]
 template <class FP>
 __global__ void __launch_bounds__(256) fft_expand_table_kernel(const u32* __restrict__ lo, const u32* __restrict__ hi,
@@ -1192,19 +1211,16 @@ int fft_get_powers(FftWorkspace& ws, int k, const uint64_t* base4, const uint64_
 // out[i] = mul * base^i, i < count (mul = nullptr: 1): the per-position scalars of a transform over GROUP elements
 // (gfft.cuh: h^i before the stages of a coset transform, size_inv * h^-i after the inverse's).  base4 / mul4: host pointers.
 template <class FP>
-int fft_scalars_run(FftWorkspace& ws, const uint64_t* base4, const uint64_t* mul4, size_t count, void* d_out, hipStream_t stream) {
-  typedef Fp<FP> F;
+int fft_scalars_run(FftWorkspace&, const uint64_t* base4, const uint64_t* mul4, size_t count, void* d_out, hipStream_t stream) {
   if (count == 0) return 0;
-  std::lock_guard<std::mutex> lock(ws.mu);
-  if (ws.pw.ensure(2 * F::BYTES)) return -3;
-  u32* d_base = (u32*)ws.pw.p;
-  u32* d_mul = d_base + F::N;
-  ARK_HIP_TRY(hipMemcpyAsync(d_base, base4, F::BYTES, hipMemcpyHostToDevice, stream));
-  if (mul4) ARK_HIP_TRY(hipMemcpyAsync(d_mul, mul4, F::BYTES, hipMemcpyHostToDevice, stream));
-  hipLaunchKernelGGL((fft_pow_table_kernel<FP>), dim3((u32)((count + 255) / 256)), dim3(256), 0, stream, (const u32*)d_base, (u64)1,
-                     (u32)count, mul4 ? (const u32*)d_mul : (const u32*)nullptr, (u32*)d_out);
+  if (count > 0xffffffffull) return -2;
+  // base and multiplier travel as kernel arguments: no staging buffer, no wait -- the entry stays asynchronous
+  FftElemArg b, m;
+  memcpy(b.w, base4, sizeof(b.w));
+  memcpy(m.w, mul4 ? mul4 : base4, sizeof(m.w));
+  hipLaunchKernelGGL((fft_pow_table_val_kernel<FP>), dim3((u32)((count + 255) / 256)), dim3(256), 0, stream, b, m, mul4 ? 1 : 0,
+                     (u32)count, (u32*)d_out);
   ARK_HIP_TRY(hipGetLastError());
-  ARK_HIP_TRY(hipStreamSynchronize(stream));   // base4 / mul4 are caller memory; ws.pw is reused by the next call
   return 0;
 }
 template <class FP>
